@@ -1,0 +1,503 @@
+"""CPU ORACLE for the pyLiDAR-SLAM frame-to-model ICP hot path — TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+A numpy (+ scipy.spatial.cKDTree) restatement of the reference algorithm, function by function, each citing the
+reference file:line (relative to /root/reference) it follows. Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module; the product (`pylidar-slam_amd/`) never does.
+
+Pinning status: the reference holds NO golden vectors for this path. This restatement is pinned by
+  * `tests/golden/*.npz`, produced by running the reference's OWN `ICPFrameToModel` / `GridSample` /
+    `SphericalProjector` / `GaussNewton` unmodified (through the import shims in `oracle/shims/`) on seeded synthetic
+    scans — generator script `oracle/make_golden.py`;
+  * the reference's property tests restated in `tests/test_oracle.py` (tests/test_optimization.py:9-32 least-square
+    variant, tests/test_pointcloud.py:7-25).
+Unpinned third-party arithmetic (stated, not hidden): `pykdtree` (exact kNN; stood in for by cKDTree — same answer
+except on exact distance ties), numba `fastmath` code generation for `voxelise`, LAPACK `sgesdd` rounding for normals.
+
+Everything is float32 where the reference is float32; poses accumulate in float64 (icp_odometry.py:200-202).
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+F32 = np.float32
+
+
+# ======================================================================================================================
+# a1 / a2  spherical projection + z-buffered projection map
+# ======================================================================================================================
+def spherical_projection(pc: np.ndarray, height: int, width: int, up_fov: float, down_fov: float):
+    """reference slam/common/projection.py:11-73 (`torch__spherical_projection`), called with
+    (min_vertical_fov=up_fov, max_vertical_fov=down_fov) by SphericalProjector.project_pointcloud (:474-476).
+
+    pc [N, 3] f32 -> (rows, cols, r) f32; invalid (r == 0) points get row = col = -1, r = 0.
+    """
+    pc = np.asarray(pc, dtype=F32)
+    fov_up = up_fov / 180.0 * np.pi  # :47
+    fov_down = down_fov / 180.0 * np.pi  # :48
+    fov = abs(fov_down) + abs(fov_up)  # :49
+    r = np.sqrt((pc * pc).sum(axis=1, dtype=F32)).astype(F32)  # :52
+    mask_0 = (r == 0.0).astype(F32)  # :55
+    mask_valid = F32(1.0) - mask_0
+    r = mask_0 * F32(0.001) + mask_valid * r  # :57
+    x, y, z = pc[:, 0], pc[:, 1], pc[:, 2]
+    theta = -np.arctan2(y, x)  # :64
+    phi = np.arcsin(z / r)  # :65
+    proj_col = F32(0.5) * (theta / F32(np.pi) + F32(1.0))  # :67
+    proj_row = F32(1.0) - (phi + F32(abs(fov_down))) / F32(fov)  # :68
+    proj_col = proj_col * F32(width)  # :70
+    proj_row = proj_row * F32(height)  # :71
+    return (proj_row * mask_valid - mask_0).astype(F32), (proj_col * mask_valid - mask_0).astype(F32), \
+        (r * mask_valid).astype(F32)  # :73
+
+
+def build_projection_map(pc: np.ndarray, height: int, width: int, up_fov: float, down_fov: float,
+                         channels: Optional[np.ndarray] = None, return_index: bool = False):
+    """reference slam/common/projection.py:331-418 (`Projector.build_projection_map`), batch of 1.
+
+    Nearest point wins each pixel: points are written in order of DESCENDING range, last write wins (:405-415).
+    Ties in range at one pixel are unspecified in the reference (unstable torch.argsort); this oracle fixes them as
+    "stable descending sort, last write wins" = the HIGHEST original index among equal ranges wins.
+
+    Returns vmap [C, H, W] f32 (zeros where empty) and optionally the winning point index per pixel (-1 = empty).
+    """
+    pc = np.asarray(pc, dtype=F32)
+    image_channels = pc[:, :3] if channels is None else np.asarray(channels, dtype=F32)
+    rows, cols, _ = spherical_projection(pc[:, :3], height, width, up_fov, down_fov)
+    r = np.sqrt((pc * pc).sum(axis=1, dtype=F32)).astype(F32)  # :394 (norm over ALL given channels of `pointcloud`)
+    prow = np.round(rows)  # :395 round-half-even
+    pcol = np.round(cols)  # :396
+    invalid = ~((prow >= 0.0) & (prow <= height - 1) & (pcol >= 0.0) & (pcol <= width - 1))  # :398-401
+    r = r.copy()
+    r[invalid] = -1.0  # :404
+    order = np.argsort(-r, kind="stable")  # :405 descending
+    order = order[r[order] > 0.0]  # :409-411
+    ir = prow[order].astype(np.int64)
+    ic = pcol[order].astype(np.int64)
+    c_dest = image_channels.shape[1]
+    dest = np.zeros((c_dest, height, width), dtype=F32)
+    index = np.full((height, width), -1, dtype=np.int64)
+    # sequential "last write wins" (:415). numpy fancy assignment with repeated indices keeps the last value.
+    dest[:, ir, ic] = image_channels[order].T
+    index[ir, ic] = order
+    if return_index:
+        return dest, index
+    return dest
+
+
+def vertex_map_to_points(vmap: np.ndarray) -> np.ndarray:
+    """reference slam/common/geometry.py:181-204 (`projection_map_to_points`, dim=0): [C,H,W] -> [H*W, C]."""
+    c = vmap.shape[0]
+    return np.ascontiguousarray(vmap.reshape(c, -1).T)
+
+
+# ======================================================================================================================
+# a4-a6 voxel grid sampling
+# ======================================================================================================================
+def voxelise(pc: np.ndarray, voxel: float) -> np.ndarray:
+    """reference slam/common/pointcloud.py:54-79. numba types `pointcloud[i, 0] / voxel_x` as f32 / f64 -> f64,
+    rounds half-to-even (`np.round_`) and truncates with `int()`; out is int64 [n, 3]."""
+    q = np.asarray(pc).astype(np.float64) / np.float64(voxel)
+    return np.round(q).astype(np.int64)
+
+
+def voxel_hashing(voxels: np.ndarray) -> np.ndarray:
+    """reference slam/common/pointcloud.py:13-23,40-51: 73856093 x + 19349669 y + 83492791 z in wrapping int64."""
+    v = voxels.astype(np.int64)
+    with np.errstate(over="ignore"):
+        return np.int64(73856093) * v[:, 0] + np.int64(19349669) * v[:, 1] + np.int64(83492791) * v[:, 2]
+
+
+def sample_from_hashes(pc: np.ndarray, hashes: np.ndarray):
+    """reference slam/common/pointcloud.py:170-179: np.unique(return_index) = first occurrence per distinct hash,
+    ordered by ascending int64 hash."""
+    _, idx = np.unique(hashes, return_index=True)
+    return pc[idx], idx
+
+
+def grid_sample(pc: np.ndarray, voxel: float):
+    """reference slam/common/pointcloud.py:182-195 and `GridSample.filter` slam/preprocessing.py:213-226."""
+    return sample_from_hashes(pc, voxel_hashing(voxelise(pc, voxel)))
+
+
+# ======================================================================================================================
+# a9 / a17  pose parametrisation (euler xyz, R = Rz Ry Rx), float32 like the reference's torch tensors
+# ======================================================================================================================
+def euler_to_mat(angles, dtype=F32) -> np.ndarray:
+    """reference slam/common/rotation.py:144-150 (`torch_euler_to_mat`): Rz(ez) @ Ry(ey) @ Rx(ex)."""
+    a = np.asarray(angles, dtype=dtype)
+    c, s = np.cos(a), np.sin(a)
+    one, zero = dtype(1), dtype(0)
+    rx = np.array([[one, zero, zero], [zero, c[0], -s[0]], [zero, s[0], c[0]]], dtype=dtype)
+    ry = np.array([[c[1], zero, s[1]], [zero, one, zero], [-s[1], zero, c[1]]], dtype=dtype)
+    rz = np.array([[c[2], -s[2], zero], [s[2], c[2], zero], [zero, zero, one]], dtype=dtype)
+    return (rz @ ry @ rx).astype(dtype)
+
+
+def build_pose_matrix(params, dtype=F32) -> np.ndarray:
+    """reference slam/common/pose.py:120-144: [tx,ty,tz,ex,ey,ez] -> 4x4."""
+    p = np.asarray(params, dtype=dtype).reshape(6)
+    t = np.eye(4, dtype=dtype)
+    t[:3, :3] = euler_to_mat(p[3:], dtype)
+    t[:3, 3] = p[:3]
+    return t
+
+
+def mat_to_euler(rot: np.ndarray, eps: float = 1.0e-6) -> np.ndarray:
+    """reference slam/common/rotation.py:253-270 (`torch_mat_to_euler`)."""
+    dtype = rot.dtype.type
+    sy = np.sqrt(rot[0, 0] * rot[0, 0] + rot[1, 0] * rot[1, 0])
+    if not sy < eps:
+        x = np.arctan2(rot[2, 1], rot[2, 2])
+        y = np.arctan2(-rot[2, 0], sy)
+        z = np.arctan2(rot[1, 0], rot[0, 0])
+    else:
+        x = np.arctan2(-rot[1, 2], rot[1, 1])
+        y = np.arctan2(-rot[2, 0], sy)
+        z = dtype(0)
+    return np.array([x, y, z], dtype=dtype)
+
+
+def from_pose_matrix(mat: np.ndarray) -> np.ndarray:
+    """reference slam/common/pose.py:188-207."""
+    return np.concatenate([mat[:3, 3], mat_to_euler(mat[:3, :3])]).astype(mat.dtype)
+
+
+def apply_transformation(points: np.ndarray, mat: np.ndarray) -> np.ndarray:
+    """reference slam/common/pose.py:169-186: p' = p @ R^T + t (float32)."""
+    return (points @ mat[:3, :3].T + mat[:3, 3][None, :]).astype(points.dtype)
+
+
+# ======================================================================================================================
+# a15  robust weighting schemes + one Gauss-Newton step
+# ======================================================================================================================
+def ls_weights(scheme: str, sigma: float, res: np.ndarray, tgt: Optional[np.ndarray] = None,
+               ref: Optional[np.ndarray] = None, eps: float = 1.0e-4) -> np.ndarray:
+    """reference slam/common/optimization.py:18-226: w = sqrt(cost(r)) / clamp(|r|, eps) (:45-50);
+    `least_square`/`default` short-circuit to w = 1 (:70-72)."""
+    res = res.astype(F32)
+    if scheme in ("default", "least_square"):
+        return np.ones((1,), dtype=F32)
+    s = F32(sigma)
+    if scheme == "huber":  # :87-97
+        a = np.abs(res)
+        sq = a < s
+        cost = sq * (res * res) + (~sq) * (F32(2) * s * a - s * s)
+    elif scheme == "exp":  # :110-117
+        cost = (res * res) * np.exp(-(res ** 2) / (s * s))
+    elif scheme == "neighborhood":  # :132-145
+        d = tgt.astype(F32) - ref.astype(F32)
+        nrm = np.sqrt((d * d).sum(axis=-1, dtype=F32))
+        cost = res * res * np.exp(-(nrm ** 2) / (s * s))
+    elif scheme == "geman_mcclure":  # :158-166
+        r2 = res ** 2
+        cost = s * r2 / (s + r2)
+    elif scheme == "square_geman_mcclure":  # :179-187
+        r2 = res ** 2
+        cost = r2 * (s / (s + r2)) ** 2
+    elif scheme == "cauchy":  # :200-208
+        cost = np.log(F32(1) + (res / s) ** 2)
+    else:
+        raise AssertionError(f"unknown scheme {scheme}")
+    clamped = np.clip(np.abs(res), F32(eps), None)
+    return (np.sqrt(cost.astype(F32)) / clamped).astype(F32)
+
+
+@dataclass
+class GNStep:
+    dx: np.ndarray  # [6] f32
+    loss: float  # sum (w r)^2
+    H: np.ndarray  # [6,6]
+    g: np.ndarray  # [6] = J^T (w r)
+    stopped: bool  # residual norm < 1e-7 early return
+
+
+def point_to_plane_rows(tgt: np.ndarray, ref: np.ndarray, normals: np.ndarray):
+    """reference slam/common/optimization.py:356-435 evaluated at x0 = 0 (alignment.py:100-113):
+    r_i = (p_i - q_i) . n_i (:427-431) ; J_i = [n_i, p_i x n_i] (:378-390 with dR/de_k at 0, rotation.py:166-184)."""
+    p = tgt.astype(F32)
+    n = normals.astype(F32)
+    res = ((p - ref.astype(F32)) * n).sum(axis=-1, dtype=F32)
+    jac = np.concatenate([n, np.cross(p, n).astype(F32)], axis=1)
+    return res, jac
+
+
+def gauss_newton_step(tgt: np.ndarray, ref: np.ndarray, normals: np.ndarray, scheme: str = "default",
+                      sigma: float = 0.5, accumulate=F32) -> GNStep:
+    """reference slam/common/optimization.py:296-344 with max_iters = 1 (alignment.py:77) from x0 = 0.
+
+    `accumulate` = float32 restates the reference arithmetic; float64 is the "exact" variant the HIP path is compared
+    with at tight tolerance (the device accumulates the normal equations in f64).
+    Raises RuntimeError("Invalid Jacobian in Gauss Newton minimization") when |det H| < 1e-7 (:334-336).
+    """
+    res, jac = point_to_plane_rows(tgt, ref, normals)
+    if np.sqrt((res.astype(np.float64) ** 2).sum()) < 1.0e-7:  # :323-327
+        return GNStep(np.zeros(6, F32), float((res * res).sum()), np.zeros((6, 6)), np.zeros(6), True)
+    w = ls_weights(scheme, sigma, res, tgt, ref)  # :328
+    res = (res * w).astype(F32)  # :329
+    jac = (jac * w.reshape(-1, 1)).astype(F32)  # :330
+    ja = jac.astype(accumulate)
+    ra = res.astype(accumulate)
+    H = ja.T @ ja  # :332-333
+    if abs(np.linalg.det(H)) < 1.0e-7:  # :334
+        raise RuntimeError("Invalid Jacobian in Gauss Newton minimization")
+    g = ja.T @ ra
+    dx = -(np.linalg.inv(H) @ g)  # :338
+    return GNStep(dx.astype(F32), float((ra * ra).sum()), H, g, False)
+
+
+# ======================================================================================================================
+# a10-a12  kd-tree local map
+# ======================================================================================================================
+def knn_normals(model: np.ndarray, tree: cKDTree, idx: np.ndarray, k: int = 10) -> np.ndarray:
+    """reference slam/odometry/local_map.py:397-422 for the map points `idx`: k+1 NN, drop the first (:405-407),
+    covariance centred on the query point (:411-413), normal = last right-singular vector (:414-416)."""
+    pts = model[idx]
+    _, nb = tree.query(pts.astype(np.float64), k=k + 1)
+    nb = nb[:, 1:]
+    centered = (model[nb.reshape(-1)].reshape(-1, k, 3) - pts.reshape(-1, 1, 3)).astype(F32)
+    covs = (centered[:, :, :, None] * centered[:, :, None, :]).mean(axis=1).astype(F32)
+    _, _, vh = np.linalg.svd(covs)
+    return vh[:, 2, :].astype(F32)
+
+
+class KdTreeLocalMapOracle:
+    """reference slam/odometry/local_map.py:254-427 (`KdTreeLocalMap`)."""
+
+    def __init__(self, local_map_size: int = 20, num_neighbors_normals: int = 10, workers: int = -1):
+        self.local_map_size = local_map_size
+        self.k = num_neighbors_normals
+        self.workers = workers
+        self.init()
+
+    def init(self):  # :279-288
+        self.local_map: Optional[np.ndarray] = None
+        self.num_elements: List[int] = []
+        self.model: Optional[np.ndarray] = None
+        self.normals: Optional[np.ndarray] = None
+        self.tree: Optional[cKDTree] = None
+
+    def set_map_pointcloud(self, pc: np.ndarray):  # :289-299
+        self.init()
+        self.local_map = np.asarray(pc, dtype=F32)
+        self.build_model()
+
+    def build_model(self):  # :365-369  (tree rebuilt and normal cache zeroed EVERY update)
+        self.model = self.local_map
+        self.normals = np.zeros((self.model.shape[0], 4), dtype=F32)
+        self.tree = cKDTree(self.model.astype(np.float64))
+
+    def update(self, rel_pose: np.ndarray, new_pc: Optional[np.ndarray] = None,
+               new_vertex_map: Optional[np.ndarray] = None):  # :302-362
+        numpy_pc = None
+        num = 0
+        if new_pc is not None:
+            numpy_pc = np.asarray(new_pc, dtype=F32).reshape(-1, 3)
+        elif new_vertex_map is not None:
+            pts = vertex_map_to_points(new_vertex_map)
+            nrm = np.sqrt((pts * pts).sum(axis=1, dtype=F32))
+            numpy_pc = pts[nrm > 0.01]  # :324
+        if numpy_pc is not None:
+            numpy_pc = numpy_pc[~np.isnan(numpy_pc).any(axis=1)]  # :327 remove_nan
+            num = numpy_pc.shape[0]
+        rel_pose = np.asarray(rel_pose, dtype=F32).reshape(4, 4)
+        if self.local_map is None:
+            self.local_map = numpy_pc
+            self.num_elements.append(num)
+        else:
+            inv = np.linalg.inv(rel_pose)  # :346 (float32 LAPACK)
+            moved = (np.einsum("ij,nj->ni", inv[:3, :3], self.local_map) + inv[:3, 3].reshape(1, 3)).astype(F32)
+            if numpy_pc is not None:
+                self.local_map = np.concatenate([moved, numpy_pc], axis=0)
+                self.num_elements.append(num)
+            else:
+                self.local_map = moved
+            if len(self.num_elements) > self.local_map_size:  # :356-360
+                first = self.num_elements.pop(0)
+                self.local_map = self.local_map[first:]
+        self.build_model()
+
+    def nearest_neighbor_search(self, pts: np.ndarray):  # :372-395
+        _, idx = self.tree.query(pts.astype(np.float64), workers=self.workers)
+        neighbors = self.model[idx]
+        normals = self.get_normals(idx)
+        return neighbors, normals, idx
+
+    def get_normals(self, idx: np.ndarray) -> np.ndarray:  # :397-422
+        todo = idx[self.normals[idx, 3] == 0.0]
+        if todo.shape[0] > 0:
+            todo = np.unique(todo)  # the reference recomputes duplicates; results are identical
+            self.normals[todo, :3] = knn_normals(self.model, self.tree, todo, self.k)
+            self.normals[todo, 3] = 1.0
+        return self.normals[idx, :3]
+
+
+# ======================================================================================================================
+# a7, a8, a17, a18  the frame-to-model ICP driver
+# ======================================================================================================================
+@dataclass
+class ICPOracleConfig:
+    """Mirrors ICPFrameToModelConfig (icp_odometry.py:29-64) + the sub-configs that matter numerically."""
+    max_num_alignments: int = 100
+    threshold_delta_pose: float = 1.0e-4
+    threshold_trans: float = 0.1
+    threshold_rot: float = 0.3
+    local_map_size: int = 20
+    num_neighbors_normals: int = 10
+    scheme: str = "default"  # ConfigStore default of alignment = plain least squares (alignment.py:77)
+    sigma: float = 0.5
+    height: int = 64
+    width: int = 1024
+    up_fov: float = 3.0
+    down_fov: float = -24.0
+    accumulate: type = F32
+
+
+@dataclass
+class FrameTrace:
+    dx: List[np.ndarray] = field(default_factory=list)
+    loss: List[float] = field(default_factory=list)
+    params: Optional[np.ndarray] = None
+
+
+class ICPFrameToModelOracle:
+    """reference slam/odometry/icp_odometry.py:72-381 (`ICPFrameToModel`) with the kd-tree local map."""
+
+    def __init__(self, config: ICPOracleConfig):
+        self.config = config
+        self.local_map = KdTreeLocalMapOracle(config.local_map_size, config.num_neighbors_normals)
+        self.init()
+
+    def init(self):  # :128-145
+        self.relative_poses: List[np.ndarray] = []
+        self.absolute_poses: List[np.ndarray] = []
+        self.local_map.init()
+        self._iter = 0
+        self._sample_pointcloud = False
+        self._delta = np.eye(4, dtype=F32)
+        self.traces: List[FrameTrace] = []
+
+    # a7 ---------------------------------------------------------------------------------------------------------------
+    def _read_input(self, data, is_numpy: bool):  # :319-358
+        c = self.config
+        if data.ndim == 2:
+            if is_numpy:
+                self._sample_pointcloud = True  # :330 sticky
+            pc = np.asarray(data, dtype=F32)
+            vmap = build_projection_map(pc, c.height, c.width, c.up_fov, c.down_fov)  # :333 / :349
+        else:
+            vmap = np.asarray(data, dtype=F32).reshape(3, c.height, c.width)
+            pc = vertex_map_to_points(vmap)
+            pc = pc[np.abs(pc).max(axis=1) > 0]  # :343-344 mask_not_null
+        nan_px = np.isnan(vmap).any(axis=0)
+        vmap = vmap.copy()
+        vmap[:, nan_px] = 0.0  # :356 modify_nan_pmap
+        pc = pc[~np.isnan(pc).any(axis=1)]  # :357 remove_nan
+        self._tgt_vmap, self._tgt_pc = vmap, pc
+
+    # a8 ---------------------------------------------------------------------------------------------------------------
+    def sample_points(self) -> np.ndarray:  # :301-308
+        if not self._sample_pointcloud:
+            pts = vertex_map_to_points(self._tgt_vmap)
+            nrm = np.sqrt((pts * pts).sum(axis=1, dtype=F32))
+            return pts[nrm > 0.0]
+        return self._tgt_pc
+
+    # a17 --------------------------------------------------------------------------------------------------------------
+    def register_new_frame(self, target: np.ndarray, init: np.ndarray):  # :248-299
+        c = self.config
+        pose = init.astype(F32)
+        params = np.zeros(6, dtype=F32)
+        trace = FrameTrace()
+        for _ in range(c.max_num_alignments):
+            p = apply_transformation(target, pose)  # :275
+            q, n, _ = self.local_map.nearest_neighbor_search(p)  # :278
+            step = gauss_newton_step(p, q, n, c.scheme, c.sigma, c.accumulate)  # :284-287
+            trace.dx.append(step.dx)
+            trace.loss.append(step.loss)
+            if np.sqrt((step.dx.astype(F32) ** 2).sum(dtype=F32)) < c.threshold_delta_pose:  # :292
+                break
+            delta = build_pose_matrix(step.dx)
+            params = from_pose_matrix((delta @ pose).astype(F32))  # :296
+            pose = build_pose_matrix(params)  # :297
+        trace.params = params
+        self.traces.append(trace)
+        return params, pose
+
+    # a18 --------------------------------------------------------------------------------------------------------------
+    def process_next_frame(self, data, init_rpose: Optional[np.ndarray] = None, is_numpy: bool = True):  # :157-246
+        """Returns the relative pose [4,4] f32 (None for frame 0, which writes nothing: :171-181)."""
+        self._read_input(data, is_numpy)
+        if self._iter == 0:
+            eye = np.eye(4, dtype=F32)
+            self.local_map.update(eye, new_vertex_map=self._tgt_vmap)  # :176
+            self.relative_poses.append(eye)
+            self.absolute_poses.append(np.eye(4))
+            self._iter += 1
+            return None
+        init = np.eye(4, dtype=F32) if init_rpose is None else np.asarray(init_rpose).astype(F32)  # :147-154
+        params, pose = self.register_new_frame(self.sample_points(), init)
+        self._update_map(pose)
+        self.relative_poses.append(pose)
+        self.absolute_poses.append(self.absolute_poses[-1] @ build_pose_matrix(params.astype(np.float64), np.float64))
+        self._iter += 1
+        return pose
+
+    def _update_map(self, new_rpose: np.ndarray):  # :360-380
+        c = self.config
+        new_delta = (self._delta @ new_rpose).astype(F32)
+        dp = from_pose_matrix(new_delta)
+        if np.linalg.norm(dp[:3]) > c.threshold_trans or np.linalg.norm(dp[3:]) * 180 / np.pi > c.threshold_rot:
+            self.local_map.update(new_rpose, new_pc=self._tgt_pc)
+            self._delta = np.eye(4, dtype=F32)
+        else:
+            self.local_map.update(new_rpose)
+            self._delta = new_delta
+
+    def get_relative_poses(self) -> np.ndarray:  # :310-314
+        return np.stack(self.relative_poses, axis=0)
+
+
+# ======================================================================================================================
+# a20  constant-velocity initialisation
+# ======================================================================================================================
+class ConstantVelocityOracle:
+    """reference slam/initialization.py:103-119: the initial guess is the last estimated relative pose."""
+
+    def __init__(self):
+        self.last = None
+
+    def next_initial_pose(self):
+        return self.last
+
+    def save_real_motion(self, pose):
+        self.last = pose
+
+
+# ======================================================================================================================
+# exact brute-force nearest neighbour (small cases; independent of cKDTree)
+# ======================================================================================================================
+def brute_force_nn(queries: np.ndarray, model: np.ndarray, chunk: int = 2048) -> Tuple[np.ndarray, np.ndarray]:
+    q = queries.astype(np.float64)
+    m = model.astype(np.float64)
+    idx = np.empty(q.shape[0], dtype=np.int64)
+    d2 = np.empty(q.shape[0], dtype=np.float64)
+    for s in range(0, q.shape[0], chunk):
+        d = ((q[s:s + chunk, None, :] - m[None, :, :]) ** 2).sum(axis=2)
+        idx[s:s + chunk] = d.argmin(axis=1)
+        d2[s:s + chunk] = d.min(axis=1)
+    return idx, d2
+
+
+def pose_error(a: np.ndarray, b: np.ndarray) -> Tuple[float, float]:
+    """(translation error in m, rotation angle of Ra^T Rb in rad) — the parity metric of BASELINE.json.
+
+    The angle is atan2(|vee(R - R^T)| / 2, (tr R - 1) / 2): well conditioned near zero (arccos of the trace is not)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    dt = float(np.linalg.norm(a[:3, 3] - b[:3, 3]))
+    r = a[:3, :3].T @ b[:3, :3]
+    v = 0.5 * np.array([r[2, 1] - r[1, 2], r[0, 2] - r[2, 0], r[1, 0] - r[0, 1]])
+    ang = float(np.arctan2(np.linalg.norm(v), (np.trace(r) - 1.0) / 2.0))
+    return dt, ang

@@ -1,0 +1,156 @@
+"""Seeded synthetic LiDAR scans: a spinning multi-beam sensor ray-cast inside a closed box room with interior boxes.
+
+This is the workload generator of SURVEY.md §8(d) / BASELINE.md §2 (the reference ships no data and the GPU box has no
+datasets): every ray hits a surface, so a scan has exactly H*W points, ring-major, float32, sensor frame.
+
+The beam elevations / azimuths are placed a quarter pixel inside the cells of the reference's spherical projector
+(`SphericalProjector(H, W, 3, up_fov, down_fov)`, reference slam/common/projection.py:11-73: row 0 <-> +up_fov,
+col = 0.5 * (-atan2(y, x) / pi + 1) * W) so the noiseless scan projects one point per pixel.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+__all__ = ["SceneConfig", "ray_directions", "pose_matrix", "trajectory", "render_scan", "make_sequence",
+           "make_fixed_map"]
+
+
+@dataclass
+class SceneConfig:
+    height: int = 64
+    width: int = 2048
+    up_fov: float = 3.0
+    down_fov: float = -24.0
+    noise_sigma: float = 0.01
+    seed: int = 1234
+    # closed room: [xmin, xmax, ymin, ymax, zmin, zmax] (world frame, sensor starts at the origin 1.7 m above the floor)
+    room: Tuple[float, ...] = (-20.0, 25.0, -15.0, 15.0, -1.7, 6.0)
+    # interior axis-aligned boxes so that all 6 DoF are constrained
+    boxes: List[Tuple[float, ...]] = field(default_factory=lambda: [
+        (6.0, 9.0, 4.0, 7.0, -1.7, 2.5),
+        (12.0, 14.0, -9.0, -5.0, -1.7, 4.0),
+        (-8.0, -5.0, 6.0, 10.0, -1.7, 1.5),
+        (-12.0, -9.5, -8.0, -4.0, -1.7, 3.0),
+        (2.0, 3.0, -6.0, -5.0, -1.7, 6.0),
+        (16.0, 19.0, 8.0, 11.0, -1.7, 2.0),
+        (-3.0, -2.0, 11.0, 12.0, -1.7, 6.0),
+        (19.0, 22.0, -3.0, 1.0, -1.7, 1.0),
+    ])
+    # trajectory: forward step per frame (m), yaw per frame (rad)
+    step: float = 0.4
+    yaw_rate: float = 0.01
+
+
+def ray_directions(cfg: SceneConfig) -> np.ndarray:
+    """Unit ray directions [H*W, 3] (float64), ring-major (row = beam, col = azimuth step)."""
+    h, w = cfg.height, cfg.width
+    fov = abs(cfg.up_fov) + abs(cfg.down_fov)
+    phi = np.deg2rad(cfg.up_fov - (np.arange(h) + 0.25) * fov / h)  # row i + 0.25
+    theta = ((np.arange(w) + 0.25) / w * 2.0 - 1.0) * np.pi  # col j + 0.25 ; theta = -atan2(y, x)
+    az = -theta
+    cp, sp = np.cos(phi)[:, None], np.sin(phi)[:, None]
+    d = np.stack([cp * np.cos(az)[None, :], cp * np.sin(az)[None, :], np.broadcast_to(sp, (h, w))], axis=-1)
+    return d.reshape(-1, 3)
+
+
+def _rot(ex: float, ey: float, ez: float) -> np.ndarray:
+    """R = Rz(ez) Ry(ey) Rx(ex) (the reference's euler 'xyz' convention, slam/common/rotation.py:144-150)."""
+    cx, sx, cy, sy, cz, sz = np.cos(ex), np.sin(ex), np.cos(ey), np.sin(ey), np.cos(ez), np.sin(ez)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def pose_matrix(params) -> np.ndarray:
+    """[tx, ty, tz, ex, ey, ez] -> 4x4 float64."""
+    t = np.eye(4)
+    t[:3, :3] = _rot(params[3], params[4], params[5])
+    t[:3, 3] = params[:3]
+    return t
+
+
+def trajectory(cfg: SceneConfig, num_frames: int) -> np.ndarray:
+    """Absolute sensor poses [F, 4, 4] float64 (world <- sensor): forward drive with slow yaw and small wobble."""
+    poses = np.zeros((num_frames, 4, 4))
+    x = y = 0.0
+    yaw = 0.0
+    for f in range(num_frames):
+        roll = 0.002 * np.sin(0.7 * f)
+        pitch = 0.002 * np.sin(0.4 * f + 1.0)
+        z = 0.02 * np.sin(0.5 * f)
+        poses[f] = pose_matrix(np.array([x, y, z, roll, pitch, yaw]))
+        x += cfg.step * np.cos(yaw)
+        y += cfg.step * np.sin(yaw)
+        yaw += cfg.yaw_rate
+    return poses
+
+
+def _ray_box_exit(o, d, box):
+    """Distance at which rays starting INSIDE the box leave it (slab method)."""
+    lo = np.array([box[0], box[2], box[4]])
+    hi = np.array([box[1], box[3], box[5]])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (lo - o) / d
+        t2 = (hi - o) / d
+    return np.min(np.maximum(t1, t2), axis=1)
+
+
+def _ray_box_entry(o, d, box):
+    """Distance at which rays starting OUTSIDE the box enter it (inf if missed)."""
+    lo = np.array([box[0], box[2], box[4]])
+    hi = np.array([box[1], box[3], box[5]])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (lo - o) / d
+        t2 = (hi - o) / d
+    tn = np.max(np.minimum(t1, t2), axis=1)
+    tf = np.min(np.maximum(t1, t2), axis=1)
+    hit = (tn <= tf) & (tn > 0.0)
+    return np.where(hit, tn, np.inf)
+
+
+def render_scan(cfg: SceneConfig, pose: np.ndarray, frame: int, dirs: Optional[np.ndarray] = None) -> np.ndarray:
+    """One scan [H*W, 3] float32 in the sensor frame taken from absolute pose `pose` (noise rng = seed + frame)."""
+    if dirs is None:
+        dirs = ray_directions(cfg)
+    o = pose[:3, 3]
+    dw = dirs @ pose[:3, :3].T
+    t = _ray_box_exit(o, dw, cfg.room)
+    for b in cfg.boxes:
+        t = np.minimum(t, _ray_box_entry(o, dw, b))
+    pts = dirs * t[:, None]
+    rng = np.random.default_rng(cfg.seed + frame)
+    pts = pts + rng.normal(0.0, cfg.noise_sigma, size=pts.shape)
+    return pts.astype(np.float32)
+
+
+def make_sequence(cfg: SceneConfig, num_frames: int):
+    """Returns (scans: list of [H*W,3] f32, absolute gt poses [F,4,4] f64)."""
+    dirs = ray_directions(cfg)
+    poses = trajectory(cfg, num_frames)
+    return [render_scan(cfg, poses[f], f, dirs) for f in range(num_frames)], poses
+
+
+def make_fixed_map(cfg: SceneConfig, scans, poses, ref_frame: int, num_points: int = 100_000, voxel: float = 0.25,
+                   seed: int = 7) -> np.ndarray:
+    """A fixed local map of exactly `num_points` points expressed in the frame of `poses[ref_frame]`.
+
+    Union of voxel-subsampled (one point per `voxel` cell, first occurrence) scans, randomly sub-selected with
+    rng(seed) — the C2 workload of SURVEY.md §8(d) (loaded through the `set_map_pointcloud` path,
+    reference slam/odometry/local_map.py:289-299).
+    """
+    inv_ref = np.linalg.inv(poses[ref_frame])
+    clouds = []
+    for s, p in zip(scans, poses):
+        rel = inv_ref @ p
+        pts = s.astype(np.float64) @ rel[:3, :3].T + rel[:3, 3]
+        keys = np.round(pts / voxel).astype(np.int64)
+        _, first = np.unique(keys, axis=0, return_index=True)
+        clouds.append(pts[np.sort(first)])
+    cloud = np.concatenate(clouds, axis=0)
+    rng = np.random.default_rng(seed)
+    if cloud.shape[0] < num_points:
+        raise ValueError(f"only {cloud.shape[0]} candidate map points (< {num_points}); add scans or shrink voxel")
+    sel = np.sort(rng.choice(cloud.shape[0], size=num_points, replace=False))
+    return cloud[sel].astype(np.float32)

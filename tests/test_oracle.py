@@ -1,0 +1,143 @@
+"""CPU: the oracle (oracle/icp_oracle.py) against the golden vectors produced by the reference's own code
+(oracle/make_golden.py) and against the reference's property tests."""
+import numpy as np
+import pytest
+
+import icp_oracle as O
+
+
+def test_projection_pixels_and_map(golden_components):
+    g = golden_components
+    h, w = (int(v) for v in g["proj_hw"])
+    up, down = (float(v) for v in g["proj_fov"])
+    rows, cols, _ = O.spherical_projection(g["proj_pc"], h, w, up, down)
+    # float pixel coordinates: same formula in f32; numpy vs torch libm differ by a few ulp
+    np.testing.assert_allclose(rows, g["proj_pixels"][:, 0], atol=2e-4)
+    np.testing.assert_allclose(cols, g["proj_pixels"][:, 1], atol=2e-3)
+    vmap = O.build_projection_map(g["proj_pc"], h, w, up, down)
+    mism = (np.abs(vmap - g["proj_vmap"]).max(axis=0) > 0).mean()
+    assert mism <= 2.0 / (h * w), f"{mism * h * w} pixels differ"
+
+
+def test_voxel_hash_grid_sample(golden_components):
+    g = golden_components
+    vox = O.voxelise(g["gs_pc"], float(g["gs_voxel"]))
+    assert vox.dtype == np.int64  # reference tests/test_pointcloud.py:14
+    np.testing.assert_array_equal(vox, g["gs_voxels"])
+    np.testing.assert_array_equal(O.voxel_hashing(vox), g["gs_hashes"])
+    np.testing.assert_array_equal(O.voxel_hashing(g["gs_big_voxels"]), g["gs_big_hashes"])
+    pts, idx = O.grid_sample(g["gs_pc"], float(g["gs_voxel"]))
+    np.testing.assert_array_equal(idx, g["gs_indices"])
+    np.testing.assert_array_equal(pts, g["gs_pc"][g["gs_indices"]])
+
+
+def test_voxel_property_like_reference_test():
+    """reference tests/test_pointcloud.py:7-25: points lie within sqrt(3) * voxel of their voxel mean."""
+    rng = np.random.default_rng(0)
+    pc = rng.normal(size=(20000, 3))
+    hashes = O.voxel_hashing(O.voxelise(pc, 0.1))
+    order = np.argsort(hashes, kind="stable")
+    hs, ps = hashes[order], pc[order]
+    starts = np.flatnonzero(np.r_[True, hs[1:] != hs[:-1]])
+    counts = np.diff(np.r_[starts, len(hs)])
+    means = np.add.reduceat(ps, starts, axis=0) / counts[:, None]
+    d = np.linalg.norm(ps - np.repeat(means, counts, axis=0), axis=1)
+    assert d.max() < 0.18
+
+
+def test_pose_roundtrip(golden_components):
+    g = golden_components
+    for p, m, b in zip(g["pose_params"], g["pose_mats"], g["pose_back"]):
+        mo = O.build_pose_matrix(p)
+        np.testing.assert_allclose(mo, m, atol=2e-7)
+        np.testing.assert_allclose(O.from_pose_matrix(m.astype(np.float32)), b, atol=2e-6)
+
+
+def test_nn_and_normals(golden_components):
+    g = golden_components
+    lm = O.KdTreeLocalMapOracle()
+    lm.set_map_pointcloud(g["nn_map"])
+    q, n, idx = lm.nearest_neighbor_search(g["nn_queries"])
+    np.testing.assert_array_equal(q, g["nn_points"])
+    dots = np.abs((n * g["nn_normals"]).sum(axis=1))
+    assert dots.min() > 1 - 1e-5
+    bi, _ = O.brute_force_nn(g["nn_queries"], g["nn_map"])
+    np.testing.assert_array_equal(bi, idx)
+
+
+@pytest.mark.parametrize("scheme", ["default", "least_square", "huber", "exp", "neighborhood", "geman_mcclure",
+                                    "square_geman_mcclure", "cauchy"])
+def test_gauss_newton_step(golden_components, scheme):
+    g = golden_components
+    sigma = float(g[f"gn_{scheme}_sigma"])
+    for acc, tol in ((np.float32, 2e-6), (np.float64, 2e-5)):
+        st = O.gauss_newton_step(g["nn_queries"], g["nn_points"], g["nn_normals"], scheme, sigma, accumulate=acc)
+        np.testing.assert_allclose(st.dx, g[f"gn_{scheme}_dx"], atol=tol, rtol=1e-4)
+        assert abs(st.loss - float(g[f"gn_{scheme}_loss"])) <= 1e-4 * abs(float(g[f"gn_{scheme}_loss"]))
+    np.testing.assert_allclose(O.build_pose_matrix(st.dx), g[f"gn_{scheme}_mat"], atol=2e-5)
+
+
+def test_gauss_newton_recovers_known_transform():
+    """reference tests/test_optimization.py:9-32 in its least-square form (the huber sigma=1e-4 form fails on the
+    reference itself: weights -> 0, |det H| < 1e-7)."""
+    rng = np.random.default_rng(3)
+    tgt = rng.normal(size=(1000, 3)) * 5
+    n = rng.normal(size=(1000, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    true = np.r_[rng.normal(size=3) * 1e-2, rng.normal(size=3) * 1e-3]
+    t = O.build_pose_matrix(true, np.float64)
+    ref = tgt @ t[:3, :3].T + t[:3, 3]
+    pose = np.eye(4)
+    for _ in range(10):
+        p = (tgt @ pose[:3, :3].T + pose[:3, 3])
+        res = ((p - ref) * n).sum(axis=1)
+        j = np.concatenate([n, np.cross(p, n)], axis=1)
+        dx = -np.linalg.solve(j.T @ j, j.T @ res)
+        pose = O.build_pose_matrix(O.from_pose_matrix(O.build_pose_matrix(dx, np.float64) @ pose), np.float64)
+    np.testing.assert_allclose(O.from_pose_matrix(pose), true, atol=1e-7)
+
+
+def test_invalid_jacobian_raises():
+    tgt = np.zeros((10, 3), np.float32)
+    tgt[:, 0] = np.arange(10)
+    n = np.tile(np.array([[0, 0, 1.0]], np.float32), (10, 1))
+    with pytest.raises(RuntimeError, match="Invalid Jacobian"):
+        O.gauss_newton_step(tgt, tgt + np.float32(0.1), n)
+
+
+def test_map_update(golden_components):
+    g = golden_components
+    lm = O.KdTreeLocalMapOracle(local_map_size=2)
+    c = g["mu_clouds"]
+    rel = g["mu_rel"]
+    lm.update(np.eye(4, dtype=np.float32), new_pc=c[0])
+    lm.update(rel, new_pc=c[1])
+    lm.update(rel)
+    lm.update(rel, new_pc=c[2])
+    lm.update(rel, new_pc=c[3])
+    np.testing.assert_array_equal(np.array(lm.num_elements), g["mu_counts"])
+    np.testing.assert_allclose(lm.local_map, g["mu_final"], atol=1e-5)
+
+
+@pytest.mark.parametrize("run", ["A_numpy_ls", "B_tensor_gm", "C_numpy_nbh_forced", "D_numpy_huber_forced"])
+def test_c1_sequence_matches_reference(golden_c1, c1_scans, run):
+    """BASELINE.json configs[0]: the oracle reproduces the reference's poses on the 10-scan C1 sequence."""
+    g = golden_c1
+    scans, _ = c1_scans
+    mode, scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
+    h, w = (int(v) for v in g["hw"])
+    cfg = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), scheme=scheme,
+                            sigma=float(sigma), height=h, width=w, local_map_size=20)
+    orc = O.ICPFrameToModelOracle(cfg)
+    cv = O.ConstantVelocityOracle()
+    for f, s in enumerate(scans):
+        pts, _ = O.grid_sample(s, 0.3)
+        assert pts.shape[0] == int(g[f"{run}_counts"][f])
+        pose = orc.process_next_frame(pts, cv.next_initial_pose(), is_numpy=(mode == "numpy"))
+        if pose is not None:
+            cv.save_real_motion(pose)
+            dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
+            assert dt < 2e-5 and dr < 2e-5, (f, dt, dr)
+            assert len(orc.traces[-1].dx) == int(g[f"{run}_iters"][f])
+    assert orc.local_map.local_map.shape[0] == int(g[f"{run}_map_size"])
+    np.testing.assert_allclose(np.stack(orc.absolute_poses), g[f"{run}_abs"], atol=1e-4)
