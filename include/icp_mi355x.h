@@ -1,0 +1,175 @@
+/*
+ * icp_mi355x.h — C ABI of the MI355X-native (gfx950, HIP) frame-to-model ICP odometry hot path.
+ *
+ * Drop-in boundary for pyLiDAR-SLAM's `ICPFrameToModel` and the inner plugin seams it is built from.
+ * Every entry point cites the reference interface it replaces (paths relative to the reference repo root).
+ * Plain pointers and sizes only: no torch / numpy types cross this boundary.  All matrices are row-major 4x4 float.
+ *
+ * Pointers tagged `mem` may live on the host (ICP_MEM_HOST: the library stages them through HBM) or on the device
+ * (ICP_MEM_DEVICE: e.g. `tensor.data_ptr()` of a torch-ROCm tensor; zero-copy).  All work is enqueued on the context's
+ * stream (`icp_set_stream`, default stream otherwise); entry points that return values to the host synchronise that
+ * stream before returning, the others are asynchronous.
+ *
+ * Threading: one context per odometry instance, calls on one context must be serialised by the caller (this is the
+ * reference's contract too: a single-threaded frame loop, slam/odometry/odometry_runner.py:170-182).
+ *
+ * Return value: ICP_OK (0) or a negative icp_status; `icp_last_error(ctx)` gives the message.
+ */
+#ifndef ICP_MI355X_H
+#define ICP_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icp_ctx icp_ctx;
+
+typedef enum {
+    ICP_OK = 0,
+    ICP_ERR_INVALID_ARGUMENT = -1, /* maps to the reference's AssertionError (slam/common/utils.py:30-38) */
+    ICP_ERR_HIP = -2,              /* HIP runtime failure (message in icp_last_error) */
+    ICP_ERR_INVALID_JACOBIAN = -3, /* RuntimeError("Invalid Jacobian in Gauss Newton minimization"),
+                                      slam/common/optimization.py:334-336 (|det H| < 1e-7) */
+    ICP_ERR_EMPTY_MAP = -4,        /* nearest-neighbour search against an empty local map */
+    ICP_ERR_NO_DEVICE = -5         /* no gfx950 device visible: the product path never falls back to the CPU */
+} icp_status;
+
+typedef enum { ICP_MEM_HOST = 0, ICP_MEM_DEVICE = 1 } icp_mem;
+
+/* Robust weighting schemes of slam/common/optimization.py:210-226 (`_LS_SCHEME`). */
+typedef enum {
+    ICP_SCHEME_LEAST_SQUARE = 0, /* "default" / "least_square" :66-72 */
+    ICP_SCHEME_HUBER = 1,        /* :76-97  */
+    ICP_SCHEME_EXP = 2,          /* :101-117 */
+    ICP_SCHEME_NEIGHBORHOOD = 3, /* :121-145 */
+    ICP_SCHEME_GEMAN_MCCLURE = 4,        /* :149-166 */
+    ICP_SCHEME_SQUARE_GEMAN_MCCLURE = 5, /* :170-187 */
+    ICP_SCHEME_CAUCHY = 6                /* :191-208 */
+} icp_scheme;
+
+/* Target-point masking of `ICPFrameToModel.sample_points` (slam/odometry/icp_odometry.py:301-308):
+ * rows containing a NaN are always skipped (remove_nan, :357); ICP_TARGETS_SKIP_NULL additionally skips zero-norm rows
+ * (the "non-null pixels of the vertex map" case, :303-305).  Skipped rows contribute nothing, exactly as if removed. */
+typedef enum { ICP_TARGETS_ALL = 0, ICP_TARGETS_SKIP_NULL = 1 } icp_target_mode;
+
+typedef struct {
+    /* SphericalProjector(height, width, 3, up_fov, down_fov), slam/common/projection.py:426-445 */
+    int32_t height;
+    int32_t width;
+    float up_fov;   /* degrees */
+    float down_fov; /* degrees */
+    /* ICPFrameToModelConfig, slam/odometry/icp_odometry.py:29-64 */
+    int32_t max_num_alignments;
+    float threshold_delta_pose;
+    /* GaussNewtonPointToPlaneConfig.gauss_newton_config {scheme, sigma}, slam/odometry/alignment.py:69-77 */
+    int32_t scheme; /* icp_scheme */
+    float sigma;
+    /* KdTreeLocalMapConfig, slam/odometry/local_map.py:243-251 */
+    int32_t local_map_size;
+    int32_t num_neighbors_normals;
+    /* MI355X-side knobs (no reference counterpart) */
+    float cell_size;   /* voxel-hash cell edge in metres (the exact search does not depend on it; speed does) */
+    int32_t max_rings; /* ring expansion limit before the exhaustive fallback (exactness is kept either way) */
+    int32_t device;    /* HIP device ordinal */
+    int32_t poll_every; /* host polls the device-side `done` flag every N iterations (0: never; implied by threshold <= 0) */
+} icp_config;
+
+typedef struct {
+    float pose[16];     /* relative pose new frame -> map frame, `new_pose_matrix` of register_new_frame :299 */
+    float params[6];    /* [tx,ty,tz,ex,ey,ez], `new_pose_params` :299 */
+    int32_t iterations; /* number of align() calls made (= len(losses) :289) */
+    int32_t converged;  /* 1 if stopped by ||dx|| < threshold_delta_pose (:292) or the residual-norm guard */
+    int32_t status;     /* icp_status of the Gauss-Newton loop */
+    int32_t num_targets; /* target rows that took part (after NaN / null masking) */
+    int64_t normals_computed; /* map normals estimated during this registration (lazy cache, local_map.py:397-422) */
+} icp_register_result;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------------- */
+void icp_default_config(icp_config* cfg);
+/* ICPFrameToModel.__init__ (slam/odometry/icp_odometry.py:77-121) */
+int icp_create(const icp_config* cfg, icp_ctx** out);
+void icp_destroy(icp_ctx* ctx);
+const char* icp_last_error(const icp_ctx* ctx);
+const char* icp_version(void);
+/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int icp_set_stream(icp_ctx* ctx, void* hip_stream);
+int icp_synchronize(icp_ctx* ctx);
+/* runtime re-configuration of the alignment (RIGID_ALIGNMENT.load, slam/odometry/alignment.py:200-208) */
+int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num_alignments,
+                      float threshold_delta_pose);
+
+/* ---- projection: Projector.build_projection_map (slam/common/projection.py:331-418) ------------------------------
+ * xyz [n,3] -> vertex map [3,H,W] planar (zeros where empty), nearest point wins each pixel.
+ * index_out (optional, [H*W] int32): winning point index per pixel, -1 where empty. */
+int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_out, int32_t* index_out, int out_mem);
+/* torch__spherical_projection (slam/common/projection.py:11-73): float pixel coordinates rows/cols [n] (diagnostics) */
+int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
+                       int out_mem);
+
+/* ---- voxel grid sampling: voxelise / voxel_hashing / sample_from_hashes (slam/common/pointcloud.py:13-79,170-195),
+ * GridSample.filter (slam/preprocessing.py:213-226) -----------------------------------------------------------------
+ * indices_out [>= n] int64: original index of the first point of every distinct voxel hash, ordered by ascending
+ * int64 hash; *count_out = number of samples; points_out (optional) [count,3] gathered samples. */
+int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
+                    float* points_out, int64_t* count_out, int out_mem);
+/* voxel coordinates [n,3] int64 and hashes [n] int64 (either output may be NULL) */
+int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
+                   int64_t* hashes_out, int out_mem);
+
+/* ---- local map: KdTreeLocalMap (slam/odometry/local_map.py:254-427) ---------------------------------------------- */
+int icp_map_init(icp_ctx* ctx);                                             /* init()               :279-288 */
+int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* set_map_pointcloud() :289-299 */
+/* update() :302-362 — move the map by inv(rel), append `new_xyz` (rows with NaN dropped; NULL / n = 0: pose-only
+ * update), evict the oldest cloud beyond local_map_size, rebuild the search structure and clear the normal cache.
+ * *inserted_out (optional) = number of rows appended. */
+int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
+                   int64_t* inserted_out);
+/* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */
+int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,
+                              int64_t* inserted_out);
+int64_t icp_map_size(const icp_ctx* ctx);
+int icp_map_num_clouds(const icp_ctx* ctx);
+int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem); /* current map [M,3] in insertion order */
+/* nearest_neighbor_search() :372-395 + __get_normals :397-422 — exact Euclidean 1-NN (no distance cap) and the
+ * lazily estimated normal of every hit.  Outputs [n,3], [n,3], [n] (any may be NULL). */
+int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* neighbor_points_out,
+                                float* neighbor_normals_out, int32_t* neighbor_index_out, int out_mem);
+
+/* ---- rigid alignment: GaussNewtonPointToPlaneAlignment.align (slam/odometry/alignment.py:91-127) on given
+ * correspondences; one Gauss-Newton step from x0 = 0 (slam/common/optimization.py:296-344).
+ * dx_out[6], pose_out[16] = build_pose_matrix(dx), loss_out = sum (w r)^2, normal_eq_out (optional) = 32 doubles:
+ * 21 upper-triangular JtJ, 6 Jtr, sum (w r)^2, sum r^2, row count, 2 pad. */
+int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
+                             int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
+                             double* normal_eq_out);
+
+/* ---- registration: ICPFrameToModel.register_new_frame (slam/odometry/icp_odometry.py:248-299) --------------------
+ * All iterations run on the device without host round trips.  loss_per_iter_out / dx_per_iter_out (optional) receive
+ * `iterations` entries ([.] double, [.,6] float). */
+int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
+                 icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);
+
+/* ---- multi-GPU seam: one ICP iteration split around the exchange of the packed normal equations -------------------
+ * begin -> { accumulate -> [all-reduce the 32 doubles at icp_normal_equations_ptr over RCCL] -> solve } x iters -> end.
+ * Every rank registers its own slice of the target points against a replicated map and applies the identical solve.*/
+int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]);
+int icp_iteration_accumulate(icp_ctx* ctx); /* search + normals + reduce into the 32-double device vector */
+int icp_iteration_solve(icp_ctx* ctx);      /* 6x6 solve + pose update from the (possibly all-reduced) vector */
+int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);
+void* icp_normal_equations_ptr(icp_ctx* ctx); /* device pointer, 32 doubles */
+/* use caller-owned device memory (e.g. a torch tensor RCCL can reduce in place) for the 32-double vector */
+int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
+
+/* ---- profiling hooks ---------------------------------------------------------------------------------------------
+ * Accumulated HIP-event time (ms) and launch count of the dominant kernel (the per-iteration nearest-neighbour
+ * search) since the last reset; measured on the context's stream. */
+int icp_profile_enable(icp_ctx* ctx, int enable);
+int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
+                     double* normals_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_MI355X_H */

@@ -1,0 +1,686 @@
+// C ABI of libicp_mi355x.so: context management, staging, and the orchestration of the kernels in the other
+// translation units.  Signatures and the reference interfaces they replace: include/icp_mi355x.h.
+#include <math.h>
+#include <string.h>
+
+#include "icp_internal.h"
+
+using namespace icp;
+
+namespace icp {
+
+hipError_t DeviceBuffer::reserve(size_t need, bool keep, hipStream_t stream) {
+    if (need <= bytes && ptr) return hipSuccess;
+    size_t cap = bytes ? bytes : 256;
+    while (cap < need) cap = cap + cap / 2 + 256;
+    void* np = nullptr;
+    hipError_t e = hipMalloc(&np, cap);
+    if (e != hipSuccess) return e;
+    if (ptr) {
+        if (keep && bytes) {
+            e = hipMemcpyAsync(np, ptr, bytes, hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+        // hipFree synchronises the device, so pending work on the old block has drained
+        (void)hipFree(ptr);
+    }
+    ptr = np;
+    bytes = cap;
+    return hipSuccess;
+}
+
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+int prof_begin(icp_ctx* ctx, int kind) {
+    Profile& p = ctx->prof;
+    if (!p.enabled) return -1;
+    const int ev = (int)p.pending.size();
+    if (ev >= (int)p.pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        p.pool.push_back({a, b});
+    }
+    (void)hipEventRecord(p.pool[ev].first, ctx->stream);
+    p.pending.push_back({kind, ev});
+    return ev;
+}
+
+void prof_end(icp_ctx* ctx, int token) {
+    if (token < 0) return;
+    (void)hipEventRecord(ctx->prof.pool[token].second, ctx->stream);
+}
+
+static void prof_collect(icp_ctx* ctx) {
+    Profile& p = ctx->prof;
+    for (auto& r : p.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.pool[r.ev].first, p.pool[r.ev].second) == hipSuccess) {
+            p.ms[r.kind] += ms;
+            p.launches[r.kind] += 1;
+        }
+    }
+    p.pending.clear();
+}
+
+// ---- small kernels owned by the API layer ---------------------------------------------------------------------------
+struct Pose16 {
+    float m[16];
+};
+
+__global__ void k_state_init(RegState* st, Pose16 init) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 16; ++k) st->pose[k] = init.m[k];
+    for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
+    st->iter = 0;
+    st->done = 0;
+    st->converged = 0;
+    st->status = 0;
+    st->n_targets = 0;
+    st->n_worklist = 0;
+    st->normals_computed = 0;
+}
+
+// moved = R^-1 x + t^-1 over the kept part of the map (local_map.py:346-348)
+__global__ void k_map_move(const float* __restrict__ in, long long m, Pose16 inv, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    const float* T = inv.m;
+    // np.einsum("ij,nj->ni", R, map) + t
+    out[3 * i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
+    out[3 * i + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
+    out[3 * i + 2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
+}
+
+__global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    bool ok = (x == x && y == y && z == z);
+    if (skip_null && x == 0.f && y == 0.f && z == 0.f) ok = false;
+    flags[i] = ok ? 1 : 0;
+}
+
+// planar [3,H*W] vertex map -> interleaved points + "norm > thr and not NaN" flags (local_map.py:320-327)
+__global__ void k_vmap_points(const float* __restrict__ vmap, int npix, float thr, float* __restrict__ pts,
+                              int* __restrict__ flags) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float x = vmap[p], y = vmap[npix + p], z = vmap[2 * npix + p];
+    pts[3 * p] = x;
+    pts[3 * p + 1] = y;
+    pts[3 * p + 2] = z;
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    flags[p] = (nrm > thr) ? 1 : 0;  // NaN compares false
+}
+
+}  // namespace icp
+
+// ---- helpers --------------------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+static int fail(icp_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+// returns a device pointer for `n_bytes` of caller data (staging a host buffer through `stage`)
+static int import_buffer(icp_ctx* ctx, const void* src, size_t n_bytes, int mem, DeviceBuffer& stage,
+                         const void** dev_out) {
+    if (n_bytes == 0) {
+        *dev_out = nullptr;
+        return ICP_OK;
+    }
+    if (!src) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "null input pointer");
+    if (mem == ICP_MEM_DEVICE) {
+        *dev_out = src;
+        return ICP_OK;
+    }
+    ICP_HIP(ctx, stage.reserve(n_bytes));
+    ICP_HIP(ctx, hipMemcpyAsync(stage.ptr, src, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_out = stage.ptr;
+    return ICP_OK;
+}
+
+// device scratch or the caller's device pointer, depending on where the output lives
+static int export_target(icp_ctx* ctx, void* dst, size_t n_bytes, int out_mem, DeviceBuffer& stage, void** dev_out) {
+    if (!dst || n_bytes == 0) {
+        *dev_out = nullptr;
+        return ICP_OK;
+    }
+    if (out_mem == ICP_MEM_DEVICE) {
+        *dev_out = dst;
+        return ICP_OK;
+    }
+    ICP_HIP(ctx, stage.reserve(n_bytes));
+    *dev_out = stage.ptr;
+    return ICP_OK;
+}
+
+static int export_finish(icp_ctx* ctx, void* dst, const void* dev, size_t n_bytes, int out_mem) {
+    if (!dst || n_bytes == 0 || out_mem == ICP_MEM_DEVICE) return ICP_OK;
+    ICP_HIP(ctx, hipMemcpyAsync(dst, dev, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return ICP_OK;
+}
+
+static bool invert4(const float* m, float* out) {
+    // general 4x4 inverse in f64 (np.linalg.inv(relative_pose), local_map.py:346)
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = m[4 * r + c];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
+        const double inv = 1.0 / a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+            }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = (float)a[r][4 + c];
+    return true;
+}
+
+static int ensure_state(icp_ctx* ctx) {
+    ICP_HIP(ctx, ctx->state.reserve(sizeof(RegState)));
+    const int cap = ctx->cfg.max_num_alignments > 1 ? ctx->cfg.max_num_alignments : 1;
+    if (cap > ctx->hist_cap) {
+        ICP_HIP(ctx, ctx->loss_hist.reserve((size_t)cap * sizeof(double)));
+        ICP_HIP(ctx, ctx->dx_hist.reserve((size_t)cap * 6 * sizeof(float)));
+        ctx->hist_cap = cap;
+    }
+    ICP_HIP(ctx, ctx->neq_own.reserve(NEQ * sizeof(double)));
+    if (!ctx->neq) ctx->neq = ctx->neq_own.as<double>();
+    ICP_HIP(ctx, ctx->counter.reserve(64));
+    return ICP_OK;
+}
+
+static int init_state(icp_ctx* ctx, const float* init_pose) {
+    Pose16 p;
+    if (init_pose) {
+        memcpy(p.m, init_pose, sizeof(p.m));
+    } else {
+        memset(p.m, 0, sizeof(p.m));
+        p.m[0] = p.m[5] = p.m[10] = p.m[15] = 1.f;
+    }
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// ---- lifecycle ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* icp_version(void) { return "icp_mi355x 0.1.0 (gfx950)"; }
+
+void icp_default_config(icp_config* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->height = 64;
+    cfg->width = 1024;
+    cfg->up_fov = 3.0f;
+    cfg->down_fov = -24.0f;
+    cfg->max_num_alignments = 100;       // icp_odometry.py:37
+    cfg->threshold_delta_pose = 1.0e-4f; // :48
+    cfg->scheme = ICP_SCHEME_LEAST_SQUARE;  // alignment.py:77 (ConfigStore default: plain least squares)
+    cfg->sigma = 0.5f;
+    cfg->local_map_size = 20;            // local_map.py:249
+    cfg->num_neighbors_normals = 10;     // :250
+    cfg->cell_size = 0.5f;
+    cfg->max_rings = 4;
+    cfg->device = 0;
+    cfg->poll_every = 4;
+}
+
+int icp_create(const icp_config* cfg, icp_ctx** out) {
+    if (!cfg || !out) return ICP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || cfg->device >= count) return ICP_ERR_NO_DEVICE;
+    if (cfg->height <= 0 || cfg->width <= 0 || !(cfg->cell_size > 0.f) || cfg->max_rings < 1 ||
+        cfg->num_neighbors_normals < 1 || cfg->num_neighbors_normals > 64 || cfg->local_map_size < 1 ||
+        cfg->max_num_alignments < 1)
+        return ICP_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(cfg->device) != hipSuccess) return ICP_ERR_HIP;
+    icp_ctx* ctx = new icp_ctx();
+    ctx->cfg = *cfg;
+    int rc = ensure_state(ctx);
+    if (rc == ICP_OK) rc = init_state(ctx, nullptr);
+    if (rc != ICP_OK) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return ICP_OK;
+}
+
+void icp_destroy(icp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    DeviceBuffer* bufs[] = {&ctx->map_xyz[0], &ctx->map_xyz[1], &ctx->table,   &ctx->sorted_pts, &ctx->normals,
+                            &ctx->nflag,      &ctx->slot_of,    &ctx->rank_of, &ctx->scan_tmp,   &ctx->worklist,
+                            &ctx->targets,    &ctx->nn_pos,     &ctx->partials, &ctx->state,     &ctx->loss_hist,
+                            &ctx->dx_hist,    &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
+                            &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
+                            &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter};
+    for (DeviceBuffer* b : bufs) b->release();
+    for (auto& e : ctx->prof.pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete ctx;
+}
+
+const char* icp_last_error(const icp_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ctx->stream = (hipStream_t)hip_stream;
+    return ICP_OK;
+}
+
+int icp_synchronize(icp_ctx* ctx) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num_alignments,
+                      float threshold_delta_pose) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    if (scheme < 0 || scheme > ICP_SCHEME_CAUCHY || max_num_alignments < 1)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "bad alignment parameters");
+    ctx->cfg.scheme = scheme;
+    ctx->cfg.sigma = sigma;
+    ctx->cfg.max_num_alignments = max_num_alignments;
+    ctx->cfg.threshold_delta_pose = threshold_delta_pose;
+    return ensure_state(ctx);
+}
+
+// ---- projection -----------------------------------------------------------------------------------------------------
+int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_out, int32_t* index_out, int out_mem) {
+    if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
+    const size_t npix = (size_t)ctx->cfg.height * ctx->cfg.width;
+    const void* in;
+    int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    void *vdev, *idev;
+    if ((rc = export_target(ctx, vmap_out, npix * 12, out_mem, ctx->stage_out, &vdev))) return rc;
+    if ((rc = export_target(ctx, index_out, npix * 4, out_mem, ctx->stage_out2, &idev))) return rc;
+    if ((rc = project_device(ctx, (const float*)in, n, (float*)vdev, (int32_t*)idev))) return rc;
+    if ((rc = export_finish(ctx, vmap_out, vdev, npix * 12, out_mem))) return rc;
+    if ((rc = export_finish(ctx, index_out, idev, npix * 4, out_mem))) return rc;
+    if (out_mem == ICP_MEM_HOST || mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
+                       int out_mem) {
+    if (!ctx || n < 0 || !rows_out || !cols_out) return ICP_ERR_INVALID_ARGUMENT;
+    const void* in;
+    int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    void *rdev, *cdev;
+    if ((rc = export_target(ctx, rows_out, (size_t)n * 4, out_mem, ctx->stage_out, &rdev))) return rc;
+    if ((rc = export_target(ctx, cols_out, (size_t)n * 4, out_mem, ctx->stage_out2, &cdev))) return rc;
+    if ((rc = project_pixels_device(ctx, (const float*)in, n, (float*)rdev, (float*)cdev))) return rc;
+    if ((rc = export_finish(ctx, rows_out, rdev, (size_t)n * 4, out_mem))) return rc;
+    if ((rc = export_finish(ctx, cols_out, cdev, (size_t)n * 4, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+// ---- grid sampling --------------------------------------------------------------------------------------------------
+int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
+                   int64_t* hashes_out, int out_mem) {
+    if (!ctx || n < 0 || !(voxel_size > 0)) return ICP_ERR_INVALID_ARGUMENT;
+    const void* in;
+    int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    void *vdev, *hdev;
+    if ((rc = export_target(ctx, voxels_out, (size_t)n * 24, out_mem, ctx->stage_out, &vdev))) return rc;
+    if ((rc = export_target(ctx, hashes_out, (size_t)n * 8, out_mem, ctx->stage_out2, &hdev))) return rc;
+    if ((rc = voxel_hash_device(ctx, (const float*)in, n, voxel_size, (long long*)vdev, (long long*)hdev))) return rc;
+    if ((rc = export_finish(ctx, voxels_out, vdev, (size_t)n * 24, out_mem))) return rc;
+    if ((rc = export_finish(ctx, hashes_out, hdev, (size_t)n * 8, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
+                    float* points_out, int64_t* count_out, int out_mem) {
+    if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in))) return rc;
+    void *idev, *pdev;
+    if ((rc = export_target(ctx, indices_out, (size_t)n * 8, out_mem, ctx->stage_out, &idev))) return rc;
+    if ((rc = export_target(ctx, points_out, (size_t)n * 12, out_mem, ctx->stage_out2, &pdev))) return rc;
+    int* count_dev = ctx->counter.as<int>();
+    if ((rc = grid_sample_device(ctx, (const float*)in, n, voxel_size, (long long*)idev, (float*)pdev, count_dev)))
+        return rc;
+    int count = 0;
+    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count_out = count;
+    if ((rc = export_finish(ctx, indices_out, idev, (size_t)count * 8, out_mem))) return rc;
+    if ((rc = export_finish(ctx, points_out, pdev, (size_t)count * 12, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+// ---- local map ------------------------------------------------------------------------------------------------------
+int icp_map_init(icp_ctx* ctx) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ctx->map_m = 0;
+    ctx->cloud_sizes.clear();
+    ctx->grid_valid = false;
+    return ICP_OK;
+}
+
+int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
+    if (!ctx || m < 0 || (m > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    icp_map_init(ctx);  // set_map_pointcloud() calls init(): `_local_map_num_elements` stays empty (local_map.py:294)
+    DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
+    ICP_HIP(ctx, dst.reserve((size_t)(m > 0 ? m : 1) * 12));
+    if (m > 0)
+        ICP_HIP(ctx, hipMemcpyAsync(dst.ptr, xyz, (size_t)m * 12,
+                                    mem == ICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                    ctx->stream));
+    ctx->map_m = m;
+    int rc = build_grid(ctx);
+    if (rc) return rc;
+    if (mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+// shared tail of the two update flavours: `new_dev` [n,3] device rows with flags, or nothing
+static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
+                           int64_t n, bool has_cloud, int64_t* inserted_out) {
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    int64_t inserted = 0;
+    if (ctx->map_m == 0 && ctx->cloud_sizes.empty() && !ctx->grid_valid) {
+        // first cloud: the map becomes the cloud, the pose is ignored (local_map.py:334-337)
+        DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
+        ICP_HIP(ctx, dst.reserve((size_t)(n > 0 ? n : 1) * 12));
+        int* count_dev = ctx->counter.as<int>();
+        if (has_cloud) {
+            if ((rc = compact_rows(ctx, new_dev, flags_dev, n, 3, dst.as<float>(), count_dev))) return rc;
+            int c = 0;
+            ICP_HIP(ctx, hipMemcpyAsync(&c, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            inserted = c;
+        }
+        ctx->map_m = inserted;
+        ctx->cloud_sizes.push_back(inserted);
+    } else {
+        float inv[16];
+        if (!invert4(rel_pose, inv)) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "singular relative pose");
+        // eviction is decided by the number of clouds only (local_map.py:356-360)
+        int64_t evict = 0;
+        const size_t clouds_after = ctx->cloud_sizes.size() + (has_cloud ? 1 : 0);
+        if ((int64_t)clouds_after > ctx->cfg.local_map_size && !ctx->cloud_sizes.empty()) evict = ctx->cloud_sizes[0];
+        if (evict > ctx->map_m) evict = ctx->map_m;
+        const int64_t keep = ctx->map_m - evict;
+        const int next = ctx->map_cur ^ 1;
+        DeviceBuffer& dst = ctx->map_xyz[next];
+        ICP_HIP(ctx, dst.reserve((size_t)(keep + (has_cloud ? n : 0) + 1) * 12));
+        const float* src = ctx->map_xyz[ctx->map_cur].as<float>() + 3 * evict;
+        Pose16 p;
+        memcpy(p.m, inv, sizeof(inv));
+        if (keep > 0)
+            hipLaunchKernelGGL(k_map_move, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, ctx->stream, src,
+                               (long long)keep, p, dst.as<float>());
+        if (has_cloud) {
+            int* count_dev = ctx->counter.as<int>();
+            if ((rc = compact_rows(ctx, new_dev, flags_dev, n, 3, dst.as<float>() + 3 * keep, count_dev))) return rc;
+            int c = 0;
+            ICP_HIP(ctx, hipMemcpyAsync(&c, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            inserted = c;
+            ctx->cloud_sizes.push_back(inserted);
+        }
+        if ((int64_t)ctx->cloud_sizes.size() > ctx->cfg.local_map_size) ctx->cloud_sizes.erase(ctx->cloud_sizes.begin());
+        ctx->map_cur = next;
+        ctx->map_m = keep + inserted;
+        ICP_HIP(ctx, hipGetLastError());
+    }
+    if (inserted_out) *inserted_out = inserted;
+    return build_grid(ctx);
+}
+
+int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
+                   int64_t* inserted_out) {
+    if (!ctx || !rel_pose || n < 0) return ICP_ERR_INVALID_ARGUMENT;
+    const bool has_cloud = new_xyz != nullptr;
+    const void* in = nullptr;
+    int rc;
+    if (has_cloud) {
+        if ((rc = import_buffer(ctx, new_xyz, (size_t)n * 12, mem, ctx->stage_in, &in))) return rc;
+        ICP_HIP(ctx, ctx->flags.reserve((size_t)(n > 0 ? n : 1) * 4));
+        if (n > 0)
+            hipLaunchKernelGGL(k_flag_not_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)in, (long long)n, row_mode == ICP_TARGETS_SKIP_NULL ? 1 : 0,
+                               ctx->flags.as<int>());
+    }
+    return map_update_impl(ctx, rel_pose, (const float*)in, ctx->flags.as<int>(), n, has_cloud, inserted_out);
+}
+
+int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,
+                              int64_t* inserted_out) {
+    if (!ctx || !rel_pose || !vmap) return ICP_ERR_INVALID_ARGUMENT;
+    const int npix = ctx->cfg.height * ctx->cfg.width;
+    const void* in;
+    int rc = import_buffer(ctx, vmap, (size_t)npix * 12, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    ICP_HIP(ctx, ctx->stage_out.reserve((size_t)npix * 12));
+    ICP_HIP(ctx, ctx->flags.reserve((size_t)npix * 4));
+    hipLaunchKernelGGL(k_vmap_points, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float*)in, npix, 0.01f,
+                       ctx->stage_out.as<float>(), ctx->flags.as<int>());
+    return map_update_impl(ctx, rel_pose, ctx->stage_out.as<float>(), ctx->flags.as<int>(), npix, true, inserted_out);
+}
+
+int64_t icp_map_size(const icp_ctx* ctx) { return ctx ? ctx->map_m : 0; }
+int icp_map_num_clouds(const icp_ctx* ctx) { return ctx ? (int)ctx->cloud_sizes.size() : 0; }
+
+int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem) {
+    if (!ctx || !xyz_out) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->map_m == 0) return ICP_OK;
+    ICP_HIP(ctx, hipMemcpyAsync(xyz_out, ctx->map_xyz[ctx->map_cur].ptr, (size_t)ctx->map_m * 12,
+                                out_mem == ICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* neighbor_points_out,
+                                float* neighbor_normals_out, int32_t* neighbor_index_out, int out_mem) {
+    if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->targets, &in))) return rc;
+    ctx->tgt_ptr = (const float*)in;
+    ctx->tgt_n = n;
+    ctx->tgt_mode = ICP_TARGETS_ALL;
+    ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
+    if ((rc = init_state(ctx, nullptr))) return rc;
+    if ((rc = launch_search_raw(ctx))) return rc;
+    if (neighbor_normals_out && (rc = launch_normals(ctx))) return rc;
+    void *pdev, *ndev, *idev;
+    DeviceBuffer& s3 = ctx->flags;  // third staging area
+    if ((rc = export_target(ctx, neighbor_points_out, (size_t)n * 12, out_mem, ctx->stage_out, &pdev))) return rc;
+    if ((rc = export_target(ctx, neighbor_normals_out, (size_t)n * 12, out_mem, ctx->stage_out2, &ndev))) return rc;
+    if ((rc = export_target(ctx, neighbor_index_out, (size_t)n * 4, out_mem, s3, &idev))) return rc;
+    if ((rc = launch_gather_neighbors(ctx, n, (float*)pdev, (float*)ndev, (int32_t*)idev))) return rc;
+    if ((rc = export_finish(ctx, neighbor_points_out, pdev, (size_t)n * 12, out_mem))) return rc;
+    if ((rc = export_finish(ctx, neighbor_normals_out, ndev, (size_t)n * 12, out_mem))) return rc;
+    if ((rc = export_finish(ctx, neighbor_index_out, idev, (size_t)n * 4, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+// ---- alignment on given correspondences -----------------------------------------------------------------------------
+int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
+                             int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
+                             double* normal_eq_out) {
+    if (!ctx || n <= 0 || !ref_points || !tgt_points || !ref_normals) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void *r, *t, *nr;
+    if ((rc = import_buffer(ctx, ref_points, (size_t)n * 12, mem, ctx->stage_in, &r))) return rc;
+    if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
+    if ((rc = import_buffer(ctx, ref_normals, (size_t)n * 12, mem, ctx->stage_out2, &nr))) return rc;
+    if ((rc = launch_align_given(ctx, (const float*)r, (const float*)t, (const float*)nr, n))) return rc;
+    char host[144];
+    double neq[NEQ];
+    ICP_HIP(ctx, hipMemcpyAsync(host, ctx->stage_out.ptr, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipMemcpyAsync(neq, ctx->neq, sizeof(neq), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const float* f = (const float*)host;
+    if (dx_out) memcpy(dx_out, f, 6 * sizeof(float));
+    if (pose_out) memcpy(pose_out, f + 6, 16 * sizeof(float));
+    if (loss_out) memcpy(loss_out, host + 128, sizeof(double));
+    if (normal_eq_out) memcpy(normal_eq_out, neq, sizeof(neq));
+    int status;
+    memcpy(&status, host + 136, sizeof(int));
+    if (status == ICP_ERR_INVALID_JACOBIAN)
+        return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
+    return status;
+}
+
+// ---- registration ---------------------------------------------------------------------------------------------------
+int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
+                       const float init_pose[16]) {
+    if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->targets, &in))) return rc;
+    ctx->tgt_ptr = (const float*)in;
+    ctx->tgt_n = n;
+    ctx->tgt_mode = target_mode;
+    ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
+    if ((rc = init_state(ctx, init_pose))) return rc;
+    ctx->in_registration = true;
+    return ICP_OK;
+}
+
+int icp_iteration_accumulate(icp_ctx* ctx) {
+    if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
+    int rc;
+    if ((rc = launch_search(ctx))) return rc;
+    if ((rc = launch_normals(ctx))) return rc;
+    return launch_reduce(ctx);
+}
+
+int icp_iteration_solve(icp_ctx* ctx) {
+    if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
+    return launch_solve(ctx);
+}
+
+int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    if (!ctx || !ctx->in_registration || !result) return ICP_ERR_INVALID_ARGUMENT;
+    ctx->in_registration = false;
+    RegState st;
+    ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(result->pose, st.pose, sizeof(st.pose));
+    memcpy(result->params, st.params, sizeof(st.params));
+    result->iterations = st.iter;
+    result->converged = st.converged;
+    result->status = st.status;
+    result->num_targets = st.n_targets;
+    result->normals_computed = st.normals_computed;
+    const int k = st.iter < ctx->hist_cap ? st.iter : ctx->hist_cap;
+    if (k > 0 && loss_per_iter_out)
+        ICP_HIP(ctx, hipMemcpy(loss_per_iter_out, ctx->loss_hist.ptr, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
+    if (k > 0 && dx_per_iter_out)
+        ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist.ptr, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    if (ctx->prof.enabled) prof_collect(ctx);
+    if (st.status == ICP_ERR_INVALID_JACOBIAN)
+        return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
+    return st.status;
+}
+
+int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
+                 icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    if (!ctx || !result) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
+    if (rc) return rc;
+    const int iters = ctx->cfg.max_num_alignments;
+    // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
+    const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = icp_iteration_accumulate(ctx)) || (rc = icp_iteration_solve(ctx))) {
+            ctx->in_registration = false;
+            return rc;
+        }
+        if (poll > 0 && (it + 1) % poll == 0 && it + 1 < iters) {
+            int done = 0;
+            ICP_HIP(ctx, hipMemcpyAsync(&done, &reg_state(ctx)->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (done) break;
+        }
+    }
+    return icp_register_end(ctx, result, loss_per_iter_out, dx_per_iter_out);
+}
+
+void* icp_normal_equations_ptr(icp_ctx* ctx) {
+    if (!ctx) return nullptr;
+    if (ensure_state(ctx) != ICP_OK) return nullptr;
+    return ctx->neq;
+}
+
+int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    ctx->neq = device_ptr ? (double*)device_ptr : ctx->neq_own.as<double>();
+    return ICP_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------------------
+int icp_profile_enable(icp_ctx* ctx, int enable) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ctx->prof.enabled = enable != 0;
+    ctx->prof.pending.clear();
+    for (int k = 0; k < 3; ++k) {
+        ctx->prof.ms[k] = 0;
+        ctx->prof.launches[k] = 0;
+    }
+    return ICP_OK;
+}
+
+int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
+                     double* normals_ms_out) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (search_ms_out) *search_ms_out = ctx->prof.ms[0];
+    if (search_launches_out) *search_launches_out = ctx->prof.launches[0];
+    if (reduce_ms_out) *reduce_ms_out = ctx->prof.ms[1];
+    if (normals_ms_out) *normals_ms_out = ctx->prof.ms[2];
+    return ICP_OK;
+}
+
+}  // extern "C"

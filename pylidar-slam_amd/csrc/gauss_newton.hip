@@ -1,0 +1,409 @@
+// Point-to-plane residual / Jacobian rows, robust weights and the 6x6 normal-equation reduction + solve.
+//
+// Replaces one `GaussNewtonPointToPlaneAlignment.align` call (slam/odometry/alignment.py:91-127), i.e.
+// `PointToPlaneCost.get_residual_fun / get_residual_jac_fun` (slam/common/optimization.py:356-435) evaluated at
+// x0 = 0 and `GaussNewton.compute` with max_iters = 1 (:296-344), plus the pose update of
+// `ICPFrameToModel.register_new_frame` (slam/odometry/icp_odometry.py:289-297).
+//
+// The reference materialises J [N,6] and forms J^T J in f32; here every row is built in f32 exactly as there
+// (r = (p - q).n, J = [n, p x n], w = sqrt(cost)/clamp(|r|,1e-4)), but the 21 + 6 + 3 sums are accumulated in f64:
+// wave64 shuffle reduction -> LDS across the 4 waves of a block -> one partial row per block -> fixed-order final sum
+// (bit-reproducible run to run).  No MFMA: this is a gather + reduce, not a dense contraction.
+#include "icp_internal.h"
+
+namespace icp {
+
+static constexpr int RED_THREADS = 256;
+
+__device__ inline float robust_weight(int scheme, float sigma, float r, float dist2_pq) {
+    // slam/common/optimization.py:45-50 with the per-scheme cost(); least_square short-circuits to 1 (:70-72)
+    if (scheme == ICP_SCHEME_LEAST_SQUARE) return 1.0f;
+    const float a = fabsf(r);
+    float cost;
+    switch (scheme) {
+        case ICP_SCHEME_HUBER:  // :87-97
+            cost = a < sigma ? r * r : (2.0f * sigma * a - sigma * sigma);
+            break;
+        case ICP_SCHEME_EXP:  // :110-117
+            cost = (r * r) * expf(-(r * r) / (sigma * sigma));
+            break;
+        case ICP_SCHEME_NEIGHBORHOOD: {  // :132-145  exp(-||p - q||^2 / sigma^2), norm taken then squared
+            const float nrm = sqrtf(dist2_pq);
+            cost = r * r * expf(-(nrm * nrm) / (sigma * sigma));
+            break;
+        }
+        case ICP_SCHEME_GEMAN_MCCLURE: {  // :158-166
+            const float r2 = r * r;
+            cost = sigma * r2 / (sigma + r2);
+            break;
+        }
+        case ICP_SCHEME_SQUARE_GEMAN_MCCLURE: {  // :179-187
+            const float r2 = r * r;
+            const float q = sigma / (sigma + r2);
+            cost = r2 * (q * q);
+            break;
+        }
+        case ICP_SCHEME_CAUCHY: {  // :200-208
+            const float q = r / sigma;
+            cost = logf(1.0f + q * q);
+            break;
+        }
+        default:
+            cost = r * r;
+    }
+    return sqrtf(cost) / fmaxf(a, 1.0e-4f);
+}
+
+struct RowAcc {
+    double v[NEQ_USED];
+    __device__ inline void zero() {
+#pragma unroll
+        for (int k = 0; k < NEQ_USED; ++k) v[k] = 0.0;
+    }
+    // one correspondence: p (transformed target), q (map point), n (map normal)
+    __device__ inline void add(float px, float py, float pz, float qx, float qy, float qz, float nx, float ny, float nz,
+                               int scheme, float sigma) {
+        const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+        // r = ((p - q) * n).sum(-1)   (optimization.py:427-431)
+        const float r = __fadd_rn(__fadd_rn(__fmul_rn(dx, nx), __fmul_rn(dy, ny)), __fmul_rn(dz, nz));
+        // J = [n, p x n]              (optimization.py:378-390 at x0 = 0)
+        float J[6];
+        J[0] = nx;
+        J[1] = ny;
+        J[2] = nz;
+        J[3] = __fsub_rn(__fmul_rn(py, nz), __fmul_rn(pz, ny));
+        J[4] = __fsub_rn(__fmul_rn(pz, nx), __fmul_rn(px, nz));
+        J[5] = __fsub_rn(__fmul_rn(px, ny), __fmul_rn(py, nx));
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const float w = robust_weight(scheme, sigma, r, d2);
+        const float rw = __fmul_rn(r, w);  // res *= weights (:329)
+        double Jw[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jw[a] = (double)__fmul_rn(J[a], w);  // J *= weights (:330)
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) v[k++] += Jw[a] * Jw[b];  // H = J^T J (:332-333), upper triangle
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[21 + a] += Jw[a] * (double)rw;  // J^T r
+        v[27] += (double)__fmul_rn(rw, rw);                            // loss = sum (w r)^2
+        v[28] += (double)__fmul_rn(r, r);                              // ||r||^2 for the 1e-7 guard (:323)
+        v[29] += 1.0;
+    }
+};
+
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+__device__ inline void block_store_partial(RowAcc& acc, double* __restrict__ partial_row) {
+    __shared__ double lds[RED_THREADS / 64][NEQ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NEQ_USED; ++k) {
+        const double s = wave_sum(acc.v[k]);
+        if (lane == 0) lds[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NEQ) {
+        double s = 0.0;
+        if (threadIdx.x < NEQ_USED) {
+#pragma unroll
+            for (int w = 0; w < RED_THREADS / 64; ++w) s += lds[w][threadIdx.x];
+        }
+        partial_row[threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K3: rows from the search result
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void k_reduce(const float4* __restrict__ map_pts,
+                                                        const float4* __restrict__ normals,
+                                                        const float* __restrict__ tgt, const int* __restrict__ nn_pos,
+                                                        int n, const RegState* __restrict__ st, AlignParams ap,
+                                                        double* __restrict__ partials) {
+    if (st->done) return;
+    RowAcc acc;
+    acc.zero();
+    const float* T = st->pose;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int s = nn_pos[i];
+        if (s < 0) continue;
+        const float x = tgt[3 * i + 0], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+        const float px = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
+        const float py = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
+        const float pz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
+        const float4 q = map_pts[s];
+        const float4 nn = normals[s];
+        acc.add(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma);
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// rows from caller-supplied correspondences (RigidAlignment.align seam)
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_given(const float* __restrict__ ref,
+                                                              const float* __restrict__ tgt,
+                                                              const float* __restrict__ nrm, int n, AlignParams ap,
+                                                              double* __restrict__ partials) {
+    RowAcc acc;
+    acc.zero();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        acc.add(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], ref[3 * i], ref[3 * i + 1], ref[3 * i + 2], nrm[3 * i],
+                nrm[3 * i + 1], nrm[3 * i + 2], ap.scheme, ap.sigma);
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// fixed-order sum of the per-block partial rows -> neq[NEQ]
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int nblocks,
+                                                      const RegState* __restrict__ st, int check_done,
+                                                      double* __restrict__ neq) {
+    if (check_done && st->done) return;
+    __shared__ double lds[8][NEQ];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 groups x 32 columns
+    double s = 0.0;
+    for (int b = grp; b < nblocks; b += 8) s += partials[(size_t)b * NEQ + col];
+    lds[grp][col] = s;
+    __syncthreads();
+    if (threadIdx.x < NEQ) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += lds[g][threadIdx.x];
+        neq[threadIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K4: solve + pose update (one thread)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline void euler_to_mat_f32(float ex, float ey, float ez, float* R) {
+    // torch_euler_to_mat: Rz(ez) @ Ry(ey) @ Rx(ex)   (slam/common/rotation.py:144-150), float32
+    const float cx = cosf(ex), sx = sinf(ex), cy = cosf(ey), sy = sinf(ey), cz = cosf(ez), sz = sinf(ez);
+    // Ry Rx
+    const float a00 = cy, a01 = sy * sx, a02 = sy * cx;
+    const float a10 = 0.f, a11 = cx, a12 = -sx;
+    const float a20 = -sy, a21 = cy * sx, a22 = cy * cx;
+    R[0] = cz * a00 - sz * a10;
+    R[1] = cz * a01 - sz * a11;
+    R[2] = cz * a02 - sz * a12;
+    R[3] = sz * a00 + cz * a10;
+    R[4] = sz * a01 + cz * a11;
+    R[5] = sz * a02 + cz * a12;
+    R[6] = a20;
+    R[7] = a21;
+    R[8] = a22;
+}
+
+__device__ inline void build_pose_f32(const float* p, float* T) {  // slam/common/pose.py:120-144
+    float R[9];
+    euler_to_mat_f32(p[3], p[4], p[5], R);
+    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = p[0];
+    T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = p[1];
+    T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+__device__ inline void from_pose_f32(const float* T, float* p) {  // pose.py:188-207, rotation.py:253-270
+    const float r00 = T[0], r10 = T[4], r20 = T[8], r21 = T[9], r22 = T[10], r11 = T[5], r12 = T[6];
+    const float sy = sqrtf(r00 * r00 + r10 * r10);
+    p[0] = T[3];
+    p[1] = T[7];
+    p[2] = T[11];
+    if (!(sy < 1.0e-6f)) {
+        p[3] = atan2f(r21, r22);
+        p[4] = atan2f(-r20, sy);
+        p[5] = atan2f(r10, r00);
+    } else {
+        p[3] = atan2f(-r12, r11);
+        p[4] = atan2f(-r20, sy);
+        p[5] = 0.f;
+    }
+}
+
+// LU with partial pivoting in f64: det and solve H x = b (6x6)
+__device__ inline double solve6(double A[6][6], double* b, double* x) {
+    double det = 1.0;
+    int perm_sign = 1;
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 6; ++r)
+            if (fabs(A[r][c]) > best) {
+                best = fabs(A[r][c]);
+                piv = r;
+            }
+        if (best == 0.0) return 0.0;
+        if (piv != c) {
+            for (int k = 0; k < 6; ++k) {
+                const double t = A[c][k];
+                A[c][k] = A[piv][k];
+                A[piv][k] = t;
+            }
+            const double t = b[c];
+            b[c] = b[piv];
+            b[piv] = t;
+            perm_sign = -perm_sign;
+        }
+        det *= A[c][c];
+        const double inv = 1.0 / A[c][c];
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = A[r][c] * inv;
+            if (f == 0.0) continue;
+            for (int k = c; k < 6; ++k) A[r][k] -= f * A[c][k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = 5; r >= 0; --r) {
+        double s = b[r];
+        for (int k = r + 1; k < 6; ++k) s -= A[r][k] * x[k];
+        x[r] = s / A[r][r];
+    }
+    return det * (double)perm_sign;
+}
+
+// Solves one Gauss-Newton step from the packed normal equations.  Returns status; dx (f32) and loss are written.
+__device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double* loss, int* stopped) {
+    *stopped = 0;
+    const double r2 = neq[28];
+    if (sqrt(r2) < 1.0e-7) {  // optimization.py:323-327: return x unchanged, loss = res * res (unweighted)
+        for (int a = 0; a < 6; ++a) dx[a] = 0.f;
+        *loss = r2;
+        *stopped = 1;
+        return ICP_OK;
+    }
+    double H[6][6], g[6], x[6];
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            H[a][b] = neq[k];
+            H[b][a] = neq[k];
+            ++k;
+        }
+    for (int a = 0; a < 6; ++a) g[a] = neq[21 + a];
+    const double det = solve6(H, g, x);
+    *loss = neq[27];
+    if (!(fabs(det) >= 1.0e-7)) {  // optimization.py:334-336 (also catches NaN)
+        for (int a = 0; a < 6; ++a) dx[a] = 0.f;
+        return ICP_ERR_INVALID_JACOBIAN;
+    }
+    for (int a = 0; a < 6; ++a) dx[a] = (float)(-x[a]);  // dx = -H^-1 J^T r (:338)
+    return ICP_OK;
+}
+
+__global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
+                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->done) return;
+    const int it = st->iter;
+    st->n_worklist = 0;
+    st->n_targets = (int)neq[29];
+    float dx[6];
+    double loss;
+    int stopped;
+    const int status = gauss_newton_from_neq(neq, dx, &loss, &stopped);
+    if (it < hist_cap) {
+        loss_hist[it] = loss;
+        for (int a = 0; a < 6; ++a) dx_hist[6 * it + a] = dx[a];
+    }
+    st->iter = it + 1;
+    if (status != ICP_OK) {
+        st->status = status;
+        st->done = 1;
+        return;
+    }
+    // if delta_pose.norm() < threshold: break     (icp_odometry.py:292) — also taken by the residual guard (dx = 0)
+    float nrm2 = 0.f;
+    for (int a = 0; a < 6; ++a) nrm2 += dx[a] * dx[a];
+    if (sqrtf(nrm2) < ap.threshold_delta_pose || stopped) {
+        st->done = 1;
+        st->converged = 1;
+        return;
+    }
+    // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
+    float D[16], P[16];
+    build_pose_f32(dx, D);
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float s = 0.f;
+            for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * st->pose[4 * k2 + c];
+            P[4 * r + c] = s;
+        }
+    float prm[6];
+    from_pose_f32(P, prm);
+    for (int a = 0; a < 6; ++a) st->params[a] = prm[a];
+    build_pose_f32(prm, st->pose);
+    if (st->iter >= ap.max_iters) st->done = 1;
+}
+
+// align() on given correspondences: writes dx[6], pose[16] (f32) and loss into `out` (device, 6 + 16 floats; loss double)
+__global__ void k_solve_given(const double* __restrict__ neq, float* __restrict__ out_f, double* __restrict__ out_loss,
+                              int* __restrict__ out_status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float dx[6];
+    double loss;
+    int stopped;
+    *out_status = gauss_newton_from_neq(neq, dx, &loss, &stopped);
+    for (int a = 0; a < 6; ++a) out_f[a] = dx[a];
+    build_pose_f32(dx, out_f + 6);
+    *out_loss = loss;
+}
+
+static AlignParams align_params(const icp_ctx* ctx) {
+    AlignParams ap;
+    ap.scheme = ctx->cfg.scheme;
+    ap.sigma = ctx->cfg.sigma;
+    ap.threshold_delta_pose = ctx->cfg.threshold_delta_pose;
+    ap.max_iters = ctx->cfg.max_num_alignments;
+    return ap;
+}
+
+static int reduce_grid(int64_t n) {
+    int blocks = (int)((n + RED_THREADS - 1) / RED_THREADS);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    return blocks;
+}
+
+int launch_reduce(icp_ctx* ctx) {
+    const int n = (int)ctx->tgt_n;
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    const int tok = prof_begin(ctx, 1);
+    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
+                       ctx->normals.as<float4>(), ctx->tgt_ptr, ctx->nn_pos.as<int>(), n, reg_state(ctx),
+                       align_params(ctx), ctx->partials.as<double>());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), 1, ctx->neq);
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int launch_solve(icp_ctx* ctx) {
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), ctx->neq, align_params(ctx),
+                       ctx->loss_hist.as<double>(), ctx->dx_hist.as<float>(), ctx->hist_cap);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// out layout in ctx->stage_out: [0..21] floats (dx, pose), then at byte 128 the loss (double), at byte 136 status (int)
+int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n) {
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    ICP_HIP(ctx, ctx->stage_out.reserve(256));
+    hipLaunchKernelGGL(k_reduce_given, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, nrm, (int)n,
+                       align_params(ctx), ctx->partials.as<double>());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), 0, ctx->neq);
+    char* out = ctx->stage_out.as<char>();
+    hipLaunchKernelGGL(k_solve_given, dim3(1), dim3(64), 0, ctx->stream, ctx->neq, (float*)out, (double*)(out + 128),
+                       (int*)(out + 136));
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+}  // namespace icp

@@ -1,0 +1,113 @@
+// Voxel-grid subsampling: one point per voxel hash.
+//
+// Replaces the reference's numba kernels `voxelise` / `voxel_hashing` (slam/common/pointcloud.py:13-79) and the
+// `np.unique(hashes, return_index=True)` of `sample_from_hashes` (:170-179) used by `GridSample.filter`
+// (slam/preprocessing.py:213-226): the sample of a voxel is its FIRST point in input order, and the samples come out
+// ordered by ascending signed int64 hash (hash collisions merge voxels, exactly as in the reference).
+//
+//   voxel  = int64(round_half_even(double(p) / voxel_size))      numba promotes f32 / f64 to f64
+//   hash   = 73856093 x + 19349669 y + 83492791 z                wrapping int64
+//   sort (hash, index) by hash — stable LSD radix sort, so equal hashes keep ascending index — keep run heads.
+// The sort is rocPRIM's device radix sort (a library primitive); everything else is hand-written.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "icp_internal.h"
+
+namespace icp {
+
+__device__ inline long long voxel_coord(float v, double voxel) {
+    // int(np.round_(p / voxel)); rint = round-half-even
+    return (long long)rint((double)v / voxel);
+}
+
+__global__ void k_voxel_hash(const float* __restrict__ xyz, int n, double voxel, long long* __restrict__ voxels,
+                             long long* __restrict__ hashes, unsigned long long* __restrict__ sort_keys,
+                             int* __restrict__ sort_vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long vx = voxel_coord(xyz[3 * i], voxel), vy = voxel_coord(xyz[3 * i + 1], voxel),
+                    vz = voxel_coord(xyz[3 * i + 2], voxel);
+    // wrapping arithmetic: do it unsigned
+    const unsigned long long h = 73856093ull * (unsigned long long)vx + 19349669ull * (unsigned long long)vy +
+                                 83492791ull * (unsigned long long)vz;
+    if (voxels) {
+        voxels[3 * i] = vx;
+        voxels[3 * i + 1] = vy;
+        voxels[3 * i + 2] = vz;
+    }
+    if (hashes) hashes[i] = (long long)h;
+    if (sort_keys) {
+        sort_keys[i] = h ^ 0x8000000000000000ull;  // signed order under an unsigned sort
+        sort_vals[i] = i;
+    }
+}
+
+__global__ void k_run_heads(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ void k_emit_samples(const float* __restrict__ xyz, const int* __restrict__ vals,
+                               const int* __restrict__ flags, const int* __restrict__ offs, int n,
+                               long long* __restrict__ indices, float* __restrict__ points) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const int o = offs[i];
+    const int src = vals[i];
+    if (indices) indices[o] = src;
+    if (points) {
+        points[3 * o] = xyz[3 * src];
+        points[3 * o + 1] = xyz[3 * src + 1];
+        points[3 * o + 2] = xyz[3 * src + 2];
+    }
+}
+
+int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
+                      long long* hashes_dev) {
+    if (n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_voxel_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
+                       voxel, voxels_dev, hashes_dev, (unsigned long long*)nullptr, (int*)nullptr);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                       float* points_dev, int* count_dev) {
+    if (n <= 0) {
+        ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
+        return ICP_OK;
+    }
+    ICP_HIP(ctx, ctx->keys_a.reserve((size_t)n * 8));
+    ICP_HIP(ctx, ctx->keys_b.reserve((size_t)n * 8));
+    ICP_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->vals_b.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->scan_a.reserve((size_t)n * 4));
+    unsigned long long* ka = ctx->keys_a.as<unsigned long long>();
+    unsigned long long* kb = ctx->keys_b.as<unsigned long long>();
+    int* va = ctx->vals_a.as<int>();
+    int* vb = ctx->vals_b.as<int>();
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_voxel_hash, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, (long long*)nullptr,
+                       (long long*)nullptr, ka, va);
+    size_t tmp_bytes = 0;
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64, ctx->stream));
+    ICP_HIP(ctx, ctx->sort_tmp.reserve(tmp_bytes));
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64,
+                                           ctx->stream));
+    int* flags = ctx->flags.as<int>();
+    int* offs = ctx->scan_a.as<int>();
+    hipLaunchKernelGGL(k_run_heads, dim3(nb), dim3(256), 0, ctx->stream, kb, (int)n, flags);
+    int rc = exclusive_scan_i32(ctx, flags, offs, n, count_dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_emit_samples, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, vb, flags, offs, (int)n,
+                       indices_dev, points_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+}  // namespace icp

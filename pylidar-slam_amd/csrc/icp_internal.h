@@ -1,0 +1,189 @@
+// Internal declarations shared by the HIP translation units of libicp_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "icp_mi355x.h"
+
+namespace icp {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Voxel-hash grid over the local map (the search structure that replaces the reference's pykdtree KDTree,
+// slam/odometry/local_map.py:365-369).  Open addressing, 16-byte entries so one dwordx4 load resolves a probe.
+// ---------------------------------------------------------------------------------------------------------------------
+struct alignas(16) GridEntry {
+    unsigned long long key;  // packed cell coordinates, GRID_EMPTY if free
+    int start;               // first point of the cell in the cell-sorted point array
+    int count;               // number of points of the cell
+};
+static constexpr unsigned long long GRID_EMPTY = ~0ull;
+static constexpr int CELL_OFFSET = 1 << 20;  // cells are in [-2^20, 2^20)
+
+struct GridView {
+    const GridEntry* table;
+    unsigned int mask;   // table size - 1 (power of two)
+    float h;             // cell edge
+    float inv_h;
+    const float4* pts;   // cell-sorted map points: (x, y, z, bits(original index))
+    int m;               // number of map points
+};
+
+__host__ __device__ inline unsigned long long pack_cell(int cx, int cy, int cz) {
+    return ((unsigned long long)((unsigned)(cx + CELL_OFFSET) & 0x1FFFFFu)) |
+           ((unsigned long long)((unsigned)(cy + CELL_OFFSET) & 0x1FFFFFu) << 21) |
+           ((unsigned long long)((unsigned)(cz + CELL_OFFSET) & 0x1FFFFFu) << 42);
+}
+
+__host__ __device__ inline unsigned int hash_cell(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+__device__ inline int cell_coord(float v, float inv_h) {
+    float c = floorf(v * inv_h);
+    c = fminf(fmaxf(c, (float)(-CELL_OFFSET + 8)), (float)(CELL_OFFSET - 8));
+    return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-resident registration state (one per context): the whole Gauss-Newton loop reads / writes this, the host only
+// copies it back once per frame.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int NEQ = 32;          // packed normal equations: 21 H + 6 g + loss + r2 + count + 2 pad
+static constexpr int NEQ_USED = 30;
+
+struct RegState {
+    float pose[16];
+    float params[6];
+    int iter;        // align() calls made so far
+    int done;        // 1: loop finished (converged / guard / error); later launches are no-ops
+    int converged;
+    int status;      // icp_status
+    int n_targets;   // valid target rows (from the last reduction)
+    int n_worklist;  // map points queued for normal estimation in the current iteration
+    long long normals_computed;
+};
+
+struct AlignParams {
+    int scheme;
+    float sigma;
+    float threshold_delta_pose;
+    int max_iters;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-side context
+// ---------------------------------------------------------------------------------------------------------------------
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need, bool keep = false, hipStream_t stream = nullptr);
+    void release();
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+struct Profile {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    struct Rec { int kind; int ev; };
+    std::vector<Rec> pending;
+    double ms[3] = {0, 0, 0};
+    long long launches[3] = {0, 0, 0};
+};
+
+}  // namespace icp
+
+struct icp_ctx {
+    icp_config cfg;
+    hipStream_t stream = nullptr;
+    std::string error;
+    // ---- local map
+    int64_t map_m = 0;                 // number of map points
+    std::vector<int64_t> cloud_sizes;  // `_local_map_num_elements`
+    int map_cur = 0;                   // which of map_xyz[2] is current
+    icp::DeviceBuffer map_xyz[2];      // [M,3] float, insertion order
+    // ---- hash grid
+    icp::DeviceBuffer table;           // GridEntry[T]
+    unsigned int table_size = 0;
+    icp::DeviceBuffer sorted_pts;      // float4[M]
+    icp::DeviceBuffer normals;         // float4[M] (by cell-sorted position)
+    icp::DeviceBuffer nflag;           // int[M]: 0 none, 2 queued, 1 ready
+    icp::DeviceBuffer slot_of, rank_of;  // int[M] temporaries of the build
+    icp::DeviceBuffer scan_tmp;
+    icp::DeviceBuffer worklist;        // int[M]
+    bool grid_valid = false;
+    // ---- registration
+    icp::DeviceBuffer targets;         // staged copy of host targets
+    const float* tgt_ptr = nullptr;    // device pointer of the current targets
+    int64_t tgt_n = 0;
+    int tgt_mode = 0;
+    icp::DeviceBuffer nn_pos;          // int[N]
+    icp::DeviceBuffer partials;        // double[blocks][NEQ]
+    icp::DeviceBuffer state;           // RegState + histories
+    icp::DeviceBuffer loss_hist;       // double[max_iters]
+    icp::DeviceBuffer dx_hist;         // float[max_iters][6]
+    icp::DeviceBuffer neq_own;         // double[NEQ]
+    double* neq = nullptr;             // active normal-equation vector (own or caller supplied)
+    int hist_cap = 0;
+    int reduce_blocks = 0;
+    bool in_registration = false;
+    // ---- scratch for projection / sampling / io
+    icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
+        vals_b, counter;
+    icp::Profile prof;
+};
+
+namespace icp {
+
+#define ICP_HIP(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return ICP_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+// ---- hash_grid.hip
+int build_grid(icp_ctx* ctx);
+// exclusive scan of n ints (in place allowed); total written to *total_dev (device int) if non-null
+int exclusive_scan_i32(icp_ctx* ctx, const int* in, int* out, int64_t n, int* total_dev);
+// ordered compaction: copies rows (row_floats floats each) whose flag != 0; count to *count_dev
+int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int row_floats, float* out,
+                 int* count_dev);
+
+// ---- search.hip
+int launch_search_raw(icp_ctx* ctx);  // 1-NN without the pose transform (LocalMap seam)
+int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, queues missing normals
+int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
+int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
+
+// ---- gauss_newton.hip
+int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
+int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
+int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n);
+
+// ---- projection.hip
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev);
+int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
+
+// ---- grid_sample.hip
+int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
+                      long long* hashes_dev);
+int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                       float* points_dev, int* count_dev);
+
+// ---- profiling helpers (api.hip)
+int prof_begin(icp_ctx* ctx, int kind);
+void prof_end(icp_ctx* ctx, int token);
+
+inline RegState* reg_state(icp_ctx* ctx) { return ctx->state.as<RegState>(); }
+
+}  // namespace icp

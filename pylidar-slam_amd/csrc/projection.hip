@@ -1,0 +1,122 @@
+// Spherical range-image projection with a z-buffer.
+//
+// Replaces `torch__spherical_projection` (slam/common/projection.py:11-73) and `Projector.build_projection_map`
+// (:331-418).  The reference sorts all points by descending range and scatters them so that the last (= nearest) write
+// wins each pixel (:404-415) — deterministic only single-threaded.  Here every point does one 64-bit atomicMin on
+// (range bits << 32 | ~index) per pixel, then a resolve pass gathers the winner: nearest point wins, equal ranges go to
+// the highest point index (the outcome of a stable descending sort + last-write-wins).
+#include "icp_internal.h"
+
+namespace icp {
+
+struct ProjParams {
+    int height, width;
+    float fov_down_abs;  // |down_fov| in rad
+    float fov;           // |down| + |up| in rad
+};
+
+// float pixel coordinates, float32 operations in the reference's order (:52-73)
+__device__ inline void spherical_pixel(float x, float y, float z, const ProjParams& pp, float& row, float& col,
+                                       float& range) {
+    const float r_raw = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    range = r_raw;
+    if (r_raw == 0.0f) {  // mask_0: row = col = -1 (:55-57,:73)
+        row = -1.0f;
+        col = -1.0f;
+        return;
+    }
+    const float theta = -atan2f(y, x);                                            // :64
+    const float phi = asinf(z / r_raw);                                           // :65
+    const float pc = 0.5f * (theta / 3.14159265358979323846f + 1.0f);             // :67
+    const float pr = 1.0f - (phi + pp.fov_down_abs) / pp.fov;                     // :68
+    col = pc * (float)pp.width;                                                   // :70
+    row = pr * (float)pp.height;                                                  // :71
+}
+
+__global__ void k_zbuf_clear(unsigned long long* __restrict__ zbuf, int npix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npix) zbuf[i] = ~0ull;
+}
+
+__global__ void k_project(const float* __restrict__ xyz, int n, ProjParams pp, unsigned long long* __restrict__ zbuf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    float row, col, r;
+    spherical_pixel(x, y, z, pp, row, col, r);
+    const float prow = rintf(row), pcol = rintf(col);  // torch.round = half-to-even (:395-396)
+    // invalid outside the image (:398-401); NaN fails every comparison; r must be > 0 (:409)
+    if (!(prow >= 0.0f && prow <= (float)(pp.height - 1) && pcol >= 0.0f && pcol <= (float)(pp.width - 1))) return;
+    if (!(r > 0.0f)) return;
+    const int pix = (int)prow * pp.width + (int)pcol;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned long long)(~(unsigned)i);
+    atomicMin(&zbuf[pix], key);
+}
+
+__global__ void k_project_resolve(const float* __restrict__ xyz, const unsigned long long* __restrict__ zbuf, int npix,
+                                  float* __restrict__ vmap, int* __restrict__ index) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const unsigned long long k = zbuf[p];
+    float x = 0.f, y = 0.f, z = 0.f;
+    int idx = -1;
+    if (k != ~0ull) {
+        idx = (int)(~(unsigned)(k & 0xffffffffull));
+        x = xyz[3 * idx];
+        y = xyz[3 * idx + 1];
+        z = xyz[3 * idx + 2];
+    }
+    if (vmap) {
+        vmap[p] = x;
+        vmap[npix + p] = y;
+        vmap[2 * npix + p] = z;
+    }
+    if (index) index[p] = idx;
+}
+
+__global__ void k_project_pixels(const float* __restrict__ xyz, int n, ProjParams pp, float* __restrict__ rows,
+                                 float* __restrict__ cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float row, col, r;
+    spherical_pixel(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], pp, row, col, r);
+    rows[i] = row;
+    cols[i] = col;
+}
+
+static ProjParams proj_params(const icp_ctx* ctx) {
+    ProjParams pp;
+    pp.height = ctx->cfg.height;
+    pp.width = ctx->cfg.width;
+    const double up = (double)ctx->cfg.up_fov / 180.0 * 3.14159265358979323846;
+    const double down = (double)ctx->cfg.down_fov / 180.0 * 3.14159265358979323846;
+    const double a_down = down < 0 ? -down : down, a_up = up < 0 ? -up : up;
+    pp.fov_down_abs = (float)a_down;
+    pp.fov = (float)(a_down + a_up);
+    return pp;
+}
+
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev) {
+    const int npix = ctx->cfg.height * ctx->cfg.width;
+    ICP_HIP(ctx, ctx->zbuf.reserve((size_t)npix * sizeof(unsigned long long)));
+    unsigned long long* zb = ctx->zbuf.as<unsigned long long>();
+    const ProjParams pp = proj_params(ctx);
+    hipLaunchKernelGGL(k_zbuf_clear, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, zb, npix);
+    if (n > 0)
+        hipLaunchKernelGGL(k_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n, pp,
+                           zb);
+    hipLaunchKernelGGL(k_project_resolve, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, xyz_dev, zb, npix,
+                       vmap_dev, index_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev) {
+    if (n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_project_pixels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
+                       proj_params(ctx), rows_dev, cols_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+}  // namespace icp

@@ -1,0 +1,304 @@
+"""`IcpContext`: the Python handle on one `icp_ctx` of libicp_mi355x.so.
+
+Accepts numpy arrays (host memory, staged by the library) and torch-ROCm tensors (device memory, zero-copy through
+`tensor.data_ptr()`); returns numpy arrays or torch tensors accordingly.  torch is used for device memory and streams
+only — every computation happens in the HIP kernels behind the C ABI.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (IcpConfig, IcpLibraryError, IcpRegisterResult, MEM_DEVICE, MEM_HOST, SCHEMES, STATUS_MESSAGES,
+                   TARGETS_ALL, TARGETS_SKIP_NULL)
+
+Array = Union[np.ndarray, torch.Tensor]
+
+
+class InvalidJacobianError(RuntimeError):
+    """RuntimeError("Invalid Jacobian in Gauss Newton minimization") of slam/common/optimization.py:336."""
+
+
+@dataclass
+class RegisterResult:
+    pose: np.ndarray  # [4,4] f32
+    params: np.ndarray  # [6] f32
+    iterations: int
+    converged: bool
+    num_targets: int
+    normals_computed: int
+    losses: np.ndarray  # [iterations] f64
+    dx: np.ndarray  # [iterations, 6] f32
+
+
+def _ptr_mem(a: Optional[Array]) -> Tuple[Optional[int], int, object]:
+    """(pointer, mem kind, keep-alive object) of an [.., 3]-float32 contiguous array / tensor."""
+    if a is None:
+        return None, MEM_HOST, None
+    if isinstance(a, torch.Tensor):
+        t = a
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        if t.is_cuda:
+            return t.data_ptr(), MEM_DEVICE, t
+        n = t.numpy()
+        return n.ctypes.data, MEM_HOST, n
+    n = np.ascontiguousarray(a, dtype=np.float32)
+    return n.ctypes.data, MEM_HOST, n
+
+
+def _pose16(m) -> "C.Array":
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(4, 4))
+    return (C.c_float * 16)(*a.reshape(-1).tolist())
+
+
+class IcpContext:
+    def __init__(self, height: int = 64, width: int = 1024, up_fov: float = 3.0, down_fov: float = -24.0,
+                 max_num_alignments: int = 100, threshold_delta_pose: float = 1.0e-4, scheme: str = "default",
+                 sigma: float = 0.5, local_map_size: int = 20, num_neighbors_normals: int = 10,
+                 cell_size: float = 0.5, max_rings: int = 4, device: int = 0, poll_every: int = 4):
+        self._lib = _lib.load_library()
+        cfg = IcpConfig()
+        self._lib.icp_default_config(C.byref(cfg))
+        if scheme not in SCHEMES:
+            raise AssertionError(f"unknown weighting scheme {scheme}")
+        cfg.height, cfg.width, cfg.up_fov, cfg.down_fov = int(height), int(width), float(up_fov), float(down_fov)
+        cfg.max_num_alignments, cfg.threshold_delta_pose = int(max_num_alignments), float(threshold_delta_pose)
+        cfg.scheme, cfg.sigma = SCHEMES[scheme], float(sigma)
+        cfg.local_map_size, cfg.num_neighbors_normals = int(local_map_size), int(num_neighbors_normals)
+        cfg.cell_size, cfg.max_rings, cfg.device, cfg.poll_every = float(cell_size), int(max_rings), int(device), \
+            int(poll_every)
+        self.config = cfg
+        self.device = torch.device("cuda", int(device))
+        handle = C.c_void_p()
+        rc = self._lib.icp_create(C.byref(cfg), C.byref(handle))
+        if rc != 0:
+            raise IcpLibraryError(f"icp_create failed: {STATUS_MESSAGES.get(rc, rc)}")
+        self._h = handle
+        self._neq_tensor: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        msg = self._lib.icp_last_error(self._h).decode() or STATUS_MESSAGES.get(rc, str(rc))
+        if rc == _lib.ICP_ERR_INVALID_JACOBIAN:
+            raise InvalidJacobianError("Invalid Jacobian in Gauss Newton minimization")
+        if rc == _lib.ICP_ERR_INVALID_ARGUMENT:
+            raise AssertionError(msg)
+        raise RuntimeError(f"libicp_mi355x: {msg} ({rc})")
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current HIP stream of this device."""
+        self._check(self._lib.icp_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self):
+        self._check(self._lib.icp_synchronize(self._h))
+
+    def set_alignment(self, scheme: str, sigma: float, max_num_alignments: int, threshold_delta_pose: float):
+        self._check(self._lib.icp_set_alignment(self._h, SCHEMES[scheme], float(sigma), int(max_num_alignments),
+                                                float(threshold_delta_pose)))
+        self.config.scheme, self.config.sigma = SCHEMES[scheme], float(sigma)
+        self.config.max_num_alignments = int(max_num_alignments)
+        self.config.threshold_delta_pose = float(threshold_delta_pose)
+
+    # ---- projection --------------------------------------------------------------------------------------------------
+    def project(self, points: Array, with_index: bool = False, out: Optional[torch.Tensor] = None):
+        """Vertex map [3, H, W] (same kind as the input: numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0]) if keep is not None else 0
+        h, w = self.config.height, self.config.width
+        if mem == MEM_DEVICE:
+            vmap = out if out is not None else torch.empty((3, h, w), dtype=torch.float32, device=keep.device)
+            idx = torch.empty((h, w), dtype=torch.int32, device=keep.device) if with_index else None
+            self._check(self._lib.icp_project(self._h, p, n, mem, vmap.data_ptr(),
+                                              idx.data_ptr() if idx is not None else None, MEM_DEVICE))
+        else:
+            vmap = np.empty((3, h, w), dtype=np.float32)
+            idx = np.empty((h, w), dtype=np.int32) if with_index else None
+            self._check(self._lib.icp_project(self._h, p, n, mem, vmap.ctypes.data,
+                                              idx.ctypes.data if idx is not None else None, MEM_HOST))
+        return (vmap, idx) if with_index else vmap
+
+    def project_pixels(self, points: np.ndarray):
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        rows, cols = np.empty(n, np.float32), np.empty(n, np.float32)
+        self._check(self._lib.icp_project_pixels(self._h, p, n, mem, rows.ctypes.data, cols.ctypes.data, MEM_HOST))
+        return rows, cols
+
+    # ---- grid sampling -----------------------------------------------------------------------------------------------
+    def voxel_hash(self, points: np.ndarray, voxel_size: float):
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        vox, hashes = np.empty((n, 3), np.int64), np.empty(n, np.int64)
+        self._check(self._lib.icp_voxel_hash(self._h, p, n, mem, float(voxel_size), vox.ctypes.data,
+                                             hashes.ctypes.data, MEM_HOST))
+        return vox, hashes
+
+    def grid_sample(self, points: Array, voxel_size: float):
+        """(sample points [V,3], indices [V] int64), ordered by ascending voxel hash."""
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        count = C.c_int64(0)
+        if mem == MEM_DEVICE:
+            idx = torch.empty(max(n, 1), dtype=torch.int64, device=keep.device)
+            pts = torch.empty((max(n, 1), 3), dtype=torch.float32, device=keep.device)
+            self._check(self._lib.icp_grid_sample(self._h, p, n, mem, float(voxel_size), idx.data_ptr(),
+                                                  pts.data_ptr(), C.byref(count), MEM_DEVICE))
+            return pts[:count.value], idx[:count.value]
+        idx = np.empty(max(n, 1), np.int64)
+        pts = np.empty((max(n, 1), 3), np.float32)
+        self._check(self._lib.icp_grid_sample(self._h, p, n, mem, float(voxel_size), idx.ctypes.data,
+                                              pts.ctypes.data, C.byref(count), MEM_HOST))
+        return pts[:count.value].copy(), idx[:count.value].copy()
+
+    # ---- local map ---------------------------------------------------------------------------------------------------
+    def map_init(self):
+        self._check(self._lib.icp_map_init(self._h))
+
+    def map_set(self, points: Array):
+        p, mem, keep = _ptr_mem(points)
+        self._check(self._lib.icp_map_set(self._h, p, int(keep.shape[0]), mem))
+
+    def map_update(self, rel_pose, new_points: Optional[Array] = None, skip_null: bool = False) -> int:
+        p, mem, keep = _ptr_mem(new_points)
+        n = int(keep.shape[0]) if keep is not None else 0
+        if keep is not None and n == 0:
+            # an empty cloud still counts as a cloud in the reference's bookkeeping; give the library a valid pointer
+            keep = np.zeros((1, 3), np.float32)
+            p = keep.ctypes.data
+            mem = MEM_HOST
+        ins = C.c_int64(0)
+        self._check(self._lib.icp_map_update(self._h, _pose16(rel_pose), p, n, mem,
+                                             TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, C.byref(ins)))
+        return int(ins.value)
+
+    def map_update_vertex_map(self, rel_pose, vmap: Array) -> int:
+        p, mem, keep = _ptr_mem(vmap)
+        ins = C.c_int64(0)
+        self._check(self._lib.icp_map_update_vertex_map(self._h, _pose16(rel_pose), p, mem, C.byref(ins)))
+        return int(ins.value)
+
+    def map_size(self) -> int:
+        return int(self._lib.icp_map_size(self._h))
+
+    def map_num_clouds(self) -> int:
+        return int(self._lib.icp_map_num_clouds(self._h))
+
+    def map_points(self) -> np.ndarray:
+        out = np.empty((self.map_size(), 3), np.float32)
+        if out.shape[0]:
+            self._check(self._lib.icp_map_get(self._h, out.ctypes.data, MEM_HOST))
+        return out
+
+    def nearest_neighbor_search(self, points: Array, with_normals: bool = True, with_index: bool = False):
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        if mem == MEM_DEVICE:
+            nb = torch.empty((n, 3), dtype=torch.float32, device=keep.device)
+            nm = torch.empty((n, 3), dtype=torch.float32, device=keep.device) if with_normals else None
+            ix = torch.empty(n, dtype=torch.int32, device=keep.device) if with_index else None
+            self._check(self._lib.icp_nearest_neighbor_search(
+                self._h, p, n, mem, nb.data_ptr(), nm.data_ptr() if nm is not None else None,
+                ix.data_ptr() if ix is not None else None, MEM_DEVICE))
+        else:
+            nb = np.empty((n, 3), np.float32)
+            nm = np.empty((n, 3), np.float32) if with_normals else None
+            ix = np.empty(n, np.int32) if with_index else None
+            self._check(self._lib.icp_nearest_neighbor_search(
+                self._h, p, n, mem, nb.ctypes.data, nm.ctypes.data if nm is not None else None,
+                ix.ctypes.data if ix is not None else None, MEM_HOST))
+        return nb, nm, ix
+
+    # ---- alignment ---------------------------------------------------------------------------------------------------
+    def align_point_to_plane(self, ref_points: Array, tgt_points: Array, ref_normals: Array):
+        """One Gauss-Newton point-to-plane step: (pose [4,4], dx [6], loss, normal equations [32] f64)."""
+        r, mem_r, kr = _ptr_mem(ref_points)
+        t, mem_t, kt = _ptr_mem(tgt_points)
+        nn, mem_n, kn = _ptr_mem(ref_normals)
+        if not (mem_r == mem_t == mem_n):
+            raise AssertionError("ref / tgt / normals must live in the same memory space")
+        n = int(kr.shape[0])
+        if not (kt.shape[0] == n and kn.shape[0] == n):
+            raise AssertionError("ref / tgt / normals must have the same number of rows")
+        dx = (C.c_float * 6)()
+        pose = (C.c_float * 16)()
+        loss = C.c_double(0)
+        neq = (C.c_double * 32)()
+        self._check(self._lib.icp_align_point_to_plane(self._h, r, t, nn, n, mem_r, dx, pose, C.byref(loss), neq))
+        return (np.array(pose, np.float32).reshape(4, 4), np.array(dx, np.float32), float(loss.value),
+                np.array(neq, np.float64))
+
+    # ---- registration ------------------------------------------------------------------------------------------------
+    def _result(self, res: IcpRegisterResult, losses, dxs) -> RegisterResult:
+        k = int(res.iterations)
+        return RegisterResult(np.array(res.pose, np.float32).reshape(4, 4), np.array(res.params, np.float32), k,
+                              bool(res.converged), int(res.num_targets), int(res.normals_computed),
+                              np.array(losses[:k], np.float64), np.array(dxs, np.float32).reshape(-1, 6)[:k])
+
+    def register(self, points: Array, init_pose=None, skip_null: bool = False) -> RegisterResult:
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        cap = max(1, int(self.config.max_num_alignments))
+        losses = (C.c_double * cap)()
+        dxs = (C.c_float * (6 * cap))()
+        res = IcpRegisterResult()
+        init = _pose16(init_pose if init_pose is not None else np.eye(4))
+        self._check(self._lib.icp_register(self._h, p, n, mem, TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init,
+                                           C.byref(res), losses, dxs))
+        return self._result(res, losses, dxs)
+
+    # ---- multi-GPU seam ----------------------------------------------------------------------------------------------
+    def normal_equations_tensor(self) -> torch.Tensor:
+        """A torch-owned [32] f64 device vector installed as the context's normal-equation buffer, so that
+        `torch.distributed.all_reduce` (RCCL) can sum it in place between accumulate() and solve()."""
+        if self._neq_tensor is None:
+            self._neq_tensor = torch.zeros(32, dtype=torch.float64, device=self.device)
+            self._check(self._lib.icp_set_normal_equations_buffer(self._h, self._neq_tensor.data_ptr()))
+        return self._neq_tensor
+
+    def register_begin(self, points: Array, init_pose=None, skip_null: bool = False):
+        p, mem, keep = _ptr_mem(points)
+        self._keep_targets = keep
+        init = _pose16(init_pose if init_pose is not None else np.eye(4))
+        self._check(self._lib.icp_register_begin(self._h, p, int(keep.shape[0]), mem,
+                                                 TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init))
+
+    def iteration_accumulate(self):
+        self._check(self._lib.icp_iteration_accumulate(self._h))
+
+    def iteration_solve(self):
+        self._check(self._lib.icp_iteration_solve(self._h))
+
+    def register_end(self) -> RegisterResult:
+        cap = max(1, int(self.config.max_num_alignments))
+        losses = (C.c_double * cap)()
+        dxs = (C.c_float * (6 * cap))()
+        res = IcpRegisterResult()
+        self._check(self._lib.icp_register_end(self._h, C.byref(res), losses, dxs))
+        self._keep_targets = None
+        return self._result(res, losses, dxs)
+
+    # ---- profiling ---------------------------------------------------------------------------------------------------
+    def profile_enable(self, enable: bool = True):
+        self._check(self._lib.icp_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        s, n, r, m = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._check(self._lib.icp_profile_read(self._h, C.byref(s), C.byref(n), C.byref(r), C.byref(m)))
+        return {"search_ms": s.value, "search_launches": int(n.value), "reduce_ms": r.value, "normals_ms": m.value}

@@ -1,0 +1,467 @@
+"""Host-side mirror of the reference's ICP odometry plugin surface, running on the MI355X through libicp_mi355x.so.
+
+Same names, argument meaning and error behaviour as the reference classes they stand in for:
+
+  reference (paths relative to the reference repo)                      here
+  -------------------------------------------------------------------   -----------------------------------
+  OdometryAlgorithm                slam/odometry/odometry.py:21-81      OdometryAlgorithm
+  ICPFrameToModelConfig            slam/odometry/icp_odometry.py:29-64  MI355XICPConfig
+  ICPFrameToModel                  slam/odometry/icp_odometry.py:72-381 MI355XICPFrameToModel
+  KdTreeLocalMap                   slam/odometry/local_map.py:254-427   HashGridLocalMap
+  GaussNewtonPointToPlaneAlignment slam/odometry/alignment.py:80-127    PointToPlaneAlignment
+  SphericalProjector               slam/common/projection.py:426-508    SphericalProjector
+  GridSample / grid_sample         slam/preprocessing.py:207-226        GridSample / grid_sample
+  ConstantVelocityInitialization   slam/initialization.py:103-119       ConstantVelocityInitialization
+
+All array arithmetic over points happens in HIP kernels; this file only orchestrates (O(1) pose algebra per frame).
+There is no CPU fallback: constructing any of these without the library / a GPU raises.
+"""
+import time
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .engine import IcpContext, InvalidJacobianError, RegisterResult  # noqa: F401
+
+__all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap",
+           "PointToPlaneAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
+           "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
+
+
+def assert_debug(condition: bool, message: str = ""):
+    """reference slam/common/utils.py:30-38."""
+    if not condition:
+        raise AssertionError(message)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# O(1) pose algebra on the host (euler xyz, R = Rz Ry Rx: slam/common/rotation.py:144-150,253-270; pose.py:120-207)
+# ----------------------------------------------------------------------------------------------------------------------
+def build_pose_matrix(params, dtype=np.float32) -> np.ndarray:
+    p = np.asarray(params, dtype=dtype).reshape(6)
+    cx, cy, cz = np.cos(p[3:])
+    sx, sy, sz = np.sin(p[3:])
+    t = np.eye(4, dtype=dtype)
+    t[0, :3] = (cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx)
+    t[1, :3] = (sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx)
+    t[2, :3] = (-sy, cy * sx, cy * cx)
+    t[:3, 3] = p[:3]
+    return t
+
+
+def from_pose_matrix(mat: np.ndarray, eps: float = 1.0e-6) -> np.ndarray:
+    m = np.asarray(mat)
+    sy = np.sqrt(m[0, 0] * m[0, 0] + m[1, 0] * m[1, 0])
+    if not sy < eps:
+        e = (np.arctan2(m[2, 1], m[2, 2]), np.arctan2(-m[2, 0], sy), np.arctan2(m[1, 0], m[0, 0]))
+    else:
+        e = (np.arctan2(-m[1, 2], m[1, 1]), np.arctan2(-m[2, 0], sy), 0.0)
+    return np.array([m[0, 3], m[1, 3], m[2, 3], *e], dtype=m.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class OdometryAlgorithm(ABC):
+    """The plugin ABC of slam/odometry/odometry.py:21-81 (restated so the package is importable without the
+    reference; `register.py` also registers the MI355X odometry in the reference's own ODOMETRY enum)."""
+
+    def __init__(self, config, **kwargs):
+        self.config = config
+        self.elapsed: list = []
+
+    @abstractmethod
+    def init(self):
+        self.elapsed = []
+
+    def process_next_frame(self, data_dict: dict):
+        beginning = time.time()
+        self.do_process_next_frame(data_dict)
+        self.elapsed.append(time.time() - beginning)
+
+    @abstractmethod
+    def do_process_next_frame(self, data_dict: dict):
+        raise NotImplementedError("")
+
+    def get_relative_poses(self) -> np.ndarray:
+        raise NotImplementedError("")
+
+    def get_elapsed(self) -> float:
+        return sum(self.elapsed)
+
+    @staticmethod
+    def pointcloud_key() -> str:
+        return "odometry_pc"
+
+    @staticmethod
+    def relative_pose_key() -> str:
+        return "odometry_pose"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class SphericalProjector:
+    """Parameters of slam/common/projection.py:426-445; `build_projection_map` (:331-418) runs on the GPU."""
+    height: int = 64
+    width: int = 1024
+    num_channels: int = 3
+    up_fov: float = 3.0
+    down_fov: float = -24.0
+    _ctx: Optional[IcpContext] = field(default=None, repr=False, compare=False)
+
+    def _context(self) -> IcpContext:
+        if self._ctx is None:
+            self._ctx = IcpContext(height=self.height, width=self.width, up_fov=self.up_fov, down_fov=self.down_fov)
+        return self._ctx
+
+    def build_projection_map(self, pointcloud, **kwargs):
+        """[1, N, 3] (or [N, 3]) -> [1, 3, H, W]; torch cuda tensors stay on the device."""
+        pts = pointcloud[0] if pointcloud.ndim == 3 else pointcloud
+        vmap = self._context().project(pts)
+        return vmap[None] if isinstance(vmap, np.ndarray) else vmap.unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def grid_sample(pointcloud: np.ndarray, voxel_size: float, ctx: Optional[IcpContext] = None):
+    """slam/common/pointcloud.py:182-195: (sample points, indices of the sampled points)."""
+    ctx = ctx or _shared_context()
+    pts, idx = ctx.grid_sample(pointcloud, voxel_size)
+    if isinstance(pointcloud, np.ndarray) and pointcloud.dtype != np.float32:
+        pts = pointcloud[idx]  # keep the caller's dtype, like `pointcloud[unique_indices]`
+    return pts, idx
+
+
+_SHARED: Optional[IcpContext] = None
+
+
+def _shared_context() -> IcpContext:
+    global _SHARED
+    if _SHARED is None:
+        _SHARED = IcpContext()
+    return _SHARED
+
+
+@dataclass
+class GridSampleConfig:
+    """slam/preprocessing.py:196-204."""
+    filter_name: str = "grid_sample"
+    voxel_size: float = 0.3
+    pointcloud_key: str = "numpy_pc"
+    output_indices_key: str = "sample_indices"
+    output_sample_key: str = "sample_points"
+
+
+class GridSample:
+    """slam/preprocessing.py:207-226 (`Filter.filter(data_dict)` seam)."""
+
+    def __init__(self, config: GridSampleConfig, ctx: Optional[IcpContext] = None, **kwargs):
+        self.config = config
+        self._ctx = ctx
+
+    def filter(self, data_dict: dict):
+        pc = data_dict[self.config.pointcloud_key]
+        assert_debug(isinstance(pc, np.ndarray), "Cannot Distort a non numpy frame")
+        assert_debug(pc.ndim == 2 and pc.shape[1] == 3, f"expected [N, 3], got {pc.shape}")
+        sample, indices = grid_sample(pc, self.config.voxel_size, self._ctx)
+        data_dict[self.config.output_sample_key] = sample
+        data_dict[self.config.output_indices_key] = indices
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class ConstantVelocityInitialization:
+    """slam/initialization.py:103-119: the initial guess is the last registered relative pose."""
+
+    def __init__(self, *args, **kwargs):
+        self.initial_estimate = None
+
+    def init(self):
+        self.initial_estimate = np.eye(4)
+
+    @staticmethod
+    def initial_pose_key():
+        return "init_rpose"
+
+    def next_initial_pose(self, **kwargs):
+        return self.initial_estimate
+
+    def next_frame(self, data_dict: dict, **kwargs):
+        data_dict[self.initial_pose_key()] = self.next_initial_pose()
+
+    def save_real_motion(self, relative_pose: np.ndarray, data_dict: Optional[dict] = None):
+        self.initial_estimate = relative_pose
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class NeighborhoodResult:
+    """LocalMap.NeighborhoodResult, slam/odometry/local_map.py:34-38."""
+    neighbor_points: Any = None
+    neighbor_normals: Any = None
+    new_target_points: Any = None
+
+
+class HashGridLocalMap:
+    """Drop-in for `KdTreeLocalMap` (slam/odometry/local_map.py:254-427): a sliding window of the last
+    `local_map_size` clouds, rebuilt (voxel-hash grid instead of a kd-tree) and with its lazy normal cache cleared on
+    every update; exact 1-NN with no distance cap."""
+
+    def __init__(self, ctx: IcpContext, **kwargs):
+        self.ctx = ctx
+        self._last_count = 0
+
+    def init(self):  # :279-288
+        self.ctx.map_init()
+        self._last_count = 0
+
+    def set_map_pointcloud(self, pointcloud: np.ndarray, normals: Optional[np.ndarray] = None):  # :289-299
+        assert_debug(isinstance(pointcloud, np.ndarray) and pointcloud.ndim == 2 and pointcloud.shape[1] == 3)
+        assert_debug(normals is None, "externally supplied normals are not supported (the reference's own branch "
+                                      "stores [M,3] where its cache expects [M,4], local_map.py:297-299,368,399)")
+        self.ctx.map_set(pointcloud)
+
+    def update(self, relative_pose, new_pc_data=None, new_vertex_map=None, **kwargs):  # :302-362
+        if isinstance(relative_pose, torch.Tensor):
+            assert_debug(tuple(relative_pose.shape) == (1, 4, 4))
+            relative_pose = relative_pose[0].cpu().numpy()
+        rel = np.asarray(relative_pose, dtype=np.float32)
+        assert_debug(rel.shape == (4, 4))
+        if new_pc_data is not None:
+            pc = new_pc_data.reshape(-1, 3)
+            self._last_count = self.ctx.map_update(rel, pc, skip_null=bool(kwargs.get("skip_null", False)))
+        elif new_vertex_map is not None:
+            vm = new_vertex_map
+            assert_debug(vm.ndim == 4 and vm.shape[0] == 1 and vm.shape[1] == 3)
+            self._last_count = self.ctx.map_update_vertex_map(rel, vm[0])
+        else:
+            self.ctx.map_update(rel, None)
+
+    def nearest_neighbor_search(self, target_points, with_normals: bool = True, with_new_target_points: bool = True,
+                                **kwargs) -> NeighborhoodResult:  # :372-395
+        is_torch = isinstance(target_points, torch.Tensor)
+        assert_debug(target_points.ndim == 2 and target_points.shape[1] == 3)
+        nb, nm, _ = self.ctx.nearest_neighbor_search(target_points, with_normals=with_normals)
+        res = NeighborhoodResult()
+        if is_torch:
+            res.neighbor_points = (nb if isinstance(nb, torch.Tensor) else torch.from_numpy(nb)).unsqueeze(0)
+            if with_normals:
+                res.neighbor_normals = (nm if isinstance(nm, torch.Tensor) else torch.from_numpy(nm)).unsqueeze(0)
+            if with_new_target_points:
+                res.new_target_points = target_points.reshape(1, -1, 3)
+        else:
+            res.neighbor_points = nb
+            res.neighbor_normals = nm if with_normals else None
+            res.new_target_points = target_points if with_new_target_points else None
+        return res
+
+    def get_last_frame(self) -> torch.Tensor:  # :424-427
+        pts = self.ctx.map_points()
+        return torch.from_numpy(pts[pts.shape[0] - self._last_count:])
+
+
+class PointToPlaneAlignment:
+    """Drop-in for `GaussNewtonPointToPlaneAlignment.align` (slam/odometry/alignment.py:91-127): one Gauss-Newton
+    point-to-plane step from x0 = 0 on given correspondences; returns (pose [1,4,4], params [1,6], loss)."""
+
+    def __init__(self, ctx: IcpContext, **kwargs):
+        self.ctx = ctx
+
+    def align(self, ref_points, tgt_points, ref_normals=None, **kwargs):
+        assert_debug(ref_normals is not None,
+                     "The argument 'ref_normals' is required for a point to plane alignemnt")
+        is_torch = isinstance(ref_points, torch.Tensor)
+        r = ref_points.reshape(-1, 3)
+        t = tgt_points.reshape(-1, 3)
+        n = ref_normals.reshape(-1, 3)
+        pose, dx, loss, _ = self.ctx.align_point_to_plane(r, t, n)
+        if is_torch:
+            return torch.from_numpy(pose).unsqueeze(0), torch.from_numpy(dx).unsqueeze(0), loss
+        return pose[None], dx[None], loss
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MI355XICPConfig:
+    """Mirrors `ICPFrameToModelConfig` (slam/odometry/icp_odometry.py:29-64) with the sub-configs flattened:
+    `local_map` = KdTreeLocalMapConfig (local_map.py:243-251), `alignment` = GaussNewtonPointToPlaneConfig
+    (alignment.py:69-77)."""
+    algorithm: str = "icp_F2M_mi355x"
+    device: str = "cuda:0"
+    pose: str = "euler"
+    max_num_alignments: int = 100
+    threshold_delta_pose: float = 1.0e-4
+    threshold_trans: float = 0.1
+    threshold_rot: float = 0.3
+    sigma: float = 0.1  # dead field in the reference too (icp_odometry.py:51)
+    data_key: str = "vertex_map"
+    local_map: Dict[str, Any] = field(default_factory=lambda: dict(type="kdtree_local_map", local_map_size=20,
+                                                                   num_neighbors_normals=10))
+    alignment: Dict[str, Any] = field(default_factory=lambda: dict(
+        mode="point_to_plane_gauss_newton", gauss_newton_config=dict(max_iters=1)))
+    initialization: Any = None
+    viz_debug: bool = False
+    # MI355X-side knobs
+    cell_size: float = 0.5
+    max_rings: int = 4
+
+
+def _get(obj, key, default=None):
+    if obj is None:
+        return default
+    if isinstance(obj, dict):
+        return obj.get(key, default)
+    return getattr(obj, key, default)
+
+
+class MI355XICPFrameToModel(OdometryAlgorithm):
+    """Drop-in for `ICPFrameToModel` (slam/odometry/icp_odometry.py:72-381) with the kd-tree local map and the
+    Gauss-Newton point-to-plane alignment, every per-point stage on the MI355X."""
+
+    def __init__(self, config: MI355XICPConfig, projector=None, pose=None, device=None, **kwargs):
+        if not isinstance(config, MI355XICPConfig):
+            known = {f for f in MI355XICPConfig.__dataclass_fields__}
+            config = MI355XICPConfig(**{k: v for k, v in dict(config).items() if k in known})
+        super().__init__(config)
+        assert_debug(projector is not None)
+        self.projector = projector
+        lm = config.local_map
+        assert_debug(_get(lm, "type", "kdtree_local_map") == "kdtree_local_map",
+                     "only the kd-tree local map semantics are implemented on the MI355X path")
+        gn = _get(config.alignment, "gauss_newton_config", {}) or {}
+        assert_debug(_get(config.alignment, "mode", "point_to_plane_gauss_newton") == "point_to_plane_gauss_newton",
+                     "only the point-to-plane Gauss-Newton alignment is implemented on the MI355X path")
+        dev_index = 0
+        if device is not None and getattr(device, "index", None) is not None:
+            dev_index = device.index
+        self.ctx = IcpContext(
+            height=int(projector.height), width=int(projector.width), up_fov=float(projector.up_fov),
+            down_fov=float(projector.down_fov), max_num_alignments=int(config.max_num_alignments),
+            threshold_delta_pose=float(config.threshold_delta_pose), scheme=str(_get(gn, "scheme", "default")),
+            sigma=float(_get(gn, "sigma", 0.5)), local_map_size=int(_get(lm, "local_map_size", 20)),
+            num_neighbors_normals=int(_get(lm, "num_neighbors_normals", 10)), cell_size=float(config.cell_size),
+            max_rings=int(config.max_rings), device=dev_index)
+        self.device = self.ctx.device
+        self.local_map = HashGridLocalMap(self.ctx)
+        self.rigid_alignment = PointToPlaneAlignment(self.ctx)
+        self.gn_max_iters = config.max_num_alignments
+        self._sample_pointcloud = False
+        self.relative_poses: List[np.ndarray] = []
+        self.absolute_poses: List[np.ndarray] = []
+        self.last_result: Optional[RegisterResult] = None
+        self._iter = 0
+        self._tgt_vmap = None
+        self._tgt_pc = None
+        self._delta_since_map_update = np.eye(4, dtype=np.float32)
+        self._register_threshold_trans = config.threshold_trans
+        self._register_threshold_rot = config.threshold_rot
+
+    def init(self):  # :128-145
+        super().init()
+        self.relative_poses = []
+        self.absolute_poses = []
+        self.local_map.init()
+        self._iter = 0
+        self._delta_since_map_update = np.eye(4, dtype=np.float32)
+
+    @staticmethod
+    def _initial_pose(data_dict: dict) -> np.ndarray:  # :147-154
+        rpose = data_dict.get("init_rpose", None)
+        if rpose is None:
+            return np.eye(4, dtype=np.float32)
+        return np.asarray(rpose).astype(np.float32).reshape(4, 4)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _read_input(self, data_dict: dict):  # :319-358
+        key = self.config.data_key
+        assert_debug(key in data_dict, f"Could not find the key `{key}` in the input dictionary.\n"
+                                       f"With keys : {data_dict.keys()}). Set the parameter "
+                                       f"`slam.odometry.data_key` to the desired key")
+        data = data_dict[key]
+        self._tgt_vmap = None
+        self._tgt_pc = None
+        if isinstance(data, np.ndarray):
+            assert_debug(data.ndim == 2 and data.shape[1] == 3, f"expected [N, 3], got {data.shape}")
+            self._sample_pointcloud = True  # sticky (:330)
+            pc = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(self.device)
+            vmap = self.ctx.project(pc)
+        elif isinstance(data, torch.Tensor):
+            if data.ndim in (3, 4):
+                vmap = data.to(self.device, torch.float32)
+                if data.ndim == 4:
+                    assert_debug(data.shape[0] == 1, "Unexpected batched data format.")
+                    vmap = vmap[0]
+                assert_debug(vmap.shape[0] == 3)
+                vmap = vmap.contiguous()
+                # all H*W pixels; null / NaN pixels are masked inside the kernels (mask_not_null :343-344)
+                pc = vmap.permute(1, 2, 0).reshape(-1, 3).contiguous()
+            else:
+                assert_debug(data.ndim == 2)
+                pc = data.to(self.device, torch.float32).contiguous()
+                vmap = self.ctx.project(pc)
+        else:
+            raise RuntimeError(f"Could not interpret the data: {data} as a pointcloud tensor")
+        # modify_nan_pmap (:356): a projected map never holds a NaN (NaN rows fail the pixel-validity test); a
+        # caller-supplied vertex map keeps its NaN pixels, which every kernel masks exactly like null pixels
+        self._tgt_vmap = vmap
+        self._tgt_pc = pc
+        self._pc_is_pixels = isinstance(data, torch.Tensor) and data.ndim in (3, 4)
+
+    def sample_points(self):  # :301-308 — returns (device rows, skip_null)
+        if not self._sample_pointcloud:
+            h, w = self._tgt_vmap.shape[-2:]
+            return self._tgt_vmap.permute(1, 2, 0).reshape(h * w, 3).contiguous(), True
+        return self._tgt_pc, self._pc_is_pixels
+
+    def register_new_frame(self, target_points, initial_estimate=None, skip_null: bool = False, **kwargs):  # :248-299
+        res = self.ctx.register(target_points, initial_estimate, skip_null=skip_null)
+        self.last_result = res
+        return res.params, res.pose, res.losses
+
+    def do_process_next_frame(self, data_dict: dict):  # :157-246
+        self.ctx.use_torch_stream()
+        self._read_input(data_dict)
+        if self._iter == 0:
+            eye = np.eye(4, dtype=np.float32)
+            self.local_map.update(eye, new_vertex_map=self._tgt_vmap.unsqueeze(0))  # :176
+            self.relative_poses.append(eye[None])
+            self.absolute_poses.append(np.eye(4, dtype=np.float64))
+            self._iter += 1
+            return
+        initial_estimate = self._initial_pose(data_dict)
+        targets, skip_null = self.sample_points()
+        params, pose, _ = self.register_new_frame(targets, initial_estimate, skip_null=skip_null)
+        self.__update_map(pose)
+        self.relative_poses.append(pose[None].copy())
+        self.absolute_poses.append(self.absolute_poses[-1].dot(build_pose_matrix(params.astype(np.float64),
+                                                                                 np.float64)))  # :200-202
+        if "distorted" in data_dict:
+            tgt_np_pc = data_dict["distorted"]
+        else:
+            tgt_np_pc = self._valid_rows(self._tgt_pc)
+        data_dict[self.pointcloud_key()] = tgt_np_pc  # :243
+        data_dict[self.relative_pose_key()] = pose.reshape(4, 4).copy()  # :244
+        self._iter += 1
+
+    def _valid_rows(self, pc: torch.Tensor) -> np.ndarray:
+        a = pc.cpu().numpy().reshape(-1, 3)
+        keep = ~np.isnan(a).any(axis=1)
+        if self._pc_is_pixels:
+            keep &= np.abs(a).max(axis=1) > 0
+        return a if keep.all() else a[keep]
+
+    def __update_map(self, new_rpose: np.ndarray):  # :360-380
+        new_delta = (self._delta_since_map_update @ new_rpose).astype(np.float32)
+        dp = from_pose_matrix(new_delta)
+        if np.linalg.norm(dp[:3]) > self._register_threshold_trans or \
+                np.linalg.norm(dp[3:]) * 180 / np.pi > self._register_threshold_rot:
+            # vertex-map input: `_tgt_pc` = the non-null pixels (:342-344) -> null rows are dropped inside the library
+            self.local_map.update(new_rpose, new_pc_data=self._tgt_pc, skip_null=self._pc_is_pixels)
+            self._delta_since_map_update = np.eye(4, dtype=np.float32)
+        else:
+            self.local_map.update(new_rpose)
+            self._delta_since_map_update = new_delta
+
+    def get_relative_poses(self) -> Optional[np.ndarray]:  # :310-314
+        if len(self.relative_poses) == 0:
+            return None
+        return np.concatenate(self.relative_poses, axis=0)

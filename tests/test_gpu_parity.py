@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP path (through the C ABI of libicp_mi355x.so) against the CPU oracle on the same seeded
+inputs and against the golden vectors produced by the reference's own code (tests/golden, oracle/make_golden.py).
+
+Tolerances (BASELINE.json north_star): poses within 1e-4 m / 1e-4 rad per frame; index / integer work bit-exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists for the product path)")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def O():
+    import icp_oracle
+    return icp_oracle
+
+
+def _ctx(**kw):
+    from pylidar_slam_amd.engine import IcpContext
+    return IcpContext(**kw)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_library_loaded_is_in_tree(torch_cuda):
+    from pylidar_slam_amd import _lib
+    lib = _lib.load_library()
+    assert lib.icp_version().decode().startswith("icp_mi355x")
+    with open("/proc/self/maps") as f:
+        assert any("pylidar_slam_amd/_lib/libicp_mi355x.so" in line for line in f)
+
+
+def test_projection(torch_cuda, O, golden_components):
+    g = golden_components
+    h, w = (int(v) for v in g["proj_hw"])
+    up, down = (float(v) for v in g["proj_fov"])
+    ctx = _ctx(height=h, width=w, up_fov=up, down_fov=down)
+    rows, cols = ctx.project_pixels(g["proj_pc"])
+    np.testing.assert_allclose(rows, g["proj_pixels"][:, 0], atol=2e-4)
+    np.testing.assert_allclose(cols, g["proj_pixels"][:, 1], atol=2e-3)
+    vmap, idx = ctx.project(g["proj_pc"], with_index=True)
+    # vs the reference's own vertex map: identical except where 1-ulp libm differences flip a half-pixel rounding
+    mism_ref = (np.abs(vmap - g["proj_vmap"]).max(axis=0) > 0).sum()
+    assert mism_ref <= 2, mism_ref
+    ovmap, oidx = O.build_projection_map(g["proj_pc"], h, w, up, down, return_index=True)
+    assert (idx != oidx).sum() <= 2
+    # device-resident variant gives the same bits
+    t = torch_cuda.from_numpy(g["proj_pc"]).cuda()
+    dv = ctx.project(t)
+    assert dv.is_cuda and np.array_equal(dv.cpu().numpy(), vmap)
+
+
+def test_projection_edge_cases(torch_cuda, O):
+    ctx = _ctx(height=8, width=16)
+    # empty cloud -> all-zero map
+    v, i = ctx.project(np.zeros((0, 3), np.float32), with_index=True)
+    assert v.shape == (3, 8, 16) and not v.any() and (i == -1).all()
+    # zeros, NaN rows and duplicates: never selected / highest index wins the tie
+    pc = np.array([[0, 0, 0], [np.nan, 1, 1], [5, 0.1, -0.5], [5, 0.1, -0.5], [10, 0.2, -1.0]], np.float32)
+    v, i = ctx.project(pc, with_index=True)
+    ov, oi = O.build_projection_map(pc, 8, 16, 3.0, -24.0, return_index=True)
+    np.testing.assert_array_equal(i, oi)
+    assert 3 in i and 2 not in i and 0 not in i and 1 not in i
+    np.testing.assert_array_equal(v, ov)
+
+
+def test_voxel_hash_and_grid_sample(torch_cuda, O, golden_components):
+    g = golden_components
+    ctx = _ctx()
+    vox, hashes = ctx.voxel_hash(g["gs_pc"], float(g["gs_voxel"]))
+    np.testing.assert_array_equal(vox, g["gs_voxels"])  # bit exact vs the reference's numba body
+    np.testing.assert_array_equal(hashes, g["gs_hashes"])
+    pts, idx = ctx.grid_sample(g["gs_pc"], float(g["gs_voxel"]))
+    np.testing.assert_array_equal(idx, g["gs_indices"])
+    np.testing.assert_array_equal(pts, g["gs_pc"][g["gs_indices"]])
+    # device-resident
+    dp, di = ctx.grid_sample(torch_cuda.from_numpy(g["gs_pc"]).cuda(), float(g["gs_voxel"]))
+    np.testing.assert_array_equal(di.cpu().numpy(), g["gs_indices"])
+    # ragged / degenerate inputs
+    p0, i0 = ctx.grid_sample(np.zeros((0, 3), np.float32), 0.3)
+    assert p0.shape == (0, 3) and i0.shape == (0,)
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (100, 1))
+    p1, i1 = ctx.grid_sample(same, 0.3)
+    np.testing.assert_array_equal(i1, [0])
+    # large coordinates: int64 wrap-around identical to numpy
+    rng = np.random.default_rng(5)
+    big = (rng.normal(size=(5000, 3)) * 1e6).astype(np.float32)
+    _, hb = ctx.voxel_hash(big, 1e-3)
+    np.testing.assert_array_equal(hb, O.voxel_hashing(O.voxelise(big, 1e-3)))
+    _, ib = ctx.grid_sample(big, 1e-3)
+    np.testing.assert_array_equal(ib, O.grid_sample(big, 1e-3)[1])
+
+
+def test_nearest_neighbor_and_normals(torch_cuda, O, golden_components):
+    g = golden_components
+    ctx = _ctx(cell_size=0.5)
+    ctx.map_set(g["nn_map"])
+    nb, nm, ix = ctx.nearest_neighbor_search(g["nn_queries"], with_index=True)
+    bi, _ = O.brute_force_nn(g["nn_queries"], g["nn_map"])
+    np.testing.assert_array_equal(ix, bi)  # index-exact
+    np.testing.assert_array_equal(nb, g["nn_points"])  # = the reference's neighbours
+    dots = np.abs((nm * g["nn_normals"]).sum(axis=1))
+    assert dots.min() > 1 - 1e-5, dots.min()
+    np.testing.assert_allclose(np.linalg.norm(nm, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("cell,rings", [(0.25, 1), (0.5, 4), (2.0, 2), (8.0, 1)])
+def test_nearest_neighbor_exact_for_far_and_sparse_queries(torch_cuda, O, cell, rings):
+    """No distance cap (local_map.py:385): queries far from the map go through ring expansion and the exhaustive
+    fallback and must still return the exact nearest neighbour."""
+    rng = np.random.default_rng(11)
+    model = (rng.normal(size=(3000, 3)) * np.array([8.0, 8.0, 1.0])).astype(np.float32)
+    q = np.concatenate([rng.normal(size=(500, 3)) * 10, rng.normal(size=(100, 3)) * 200 + 300,
+                        model[:50] + 1e-3], axis=0).astype(np.float32)
+    ctx = _ctx(cell_size=cell, max_rings=rings)
+    ctx.map_set(model)
+    _, _, ix = ctx.nearest_neighbor_search(q, with_normals=False, with_index=True)
+    bi, bd2 = O.brute_force_nn(q, model)
+    d2 = ((q.astype(np.float64) - model[ix].astype(np.float64)) ** 2).sum(axis=1)
+    # same point, or an exact-distance tie within f32 rounding of the squared distance
+    same = ix == bi
+    assert same.mean() > 0.995
+    np.testing.assert_allclose(d2[~same], bd2[~same], rtol=2e-6)
+
+
+def test_tiny_maps_and_duplicates(torch_cuda, O):
+    ctx = _ctx()
+    model = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float32)  # < k+1 points, duplicate
+    ctx.map_set(model)
+    q = np.array([[0.9, 0.1, 0.0], [0.1, 0.1, 0.8]], np.float32)
+    nb, nm, ix = ctx.nearest_neighbor_search(q, with_index=True)
+    np.testing.assert_array_equal(ix, [1, 3])  # ties -> lowest index
+    assert np.isfinite(nm).all()
+    ctx2 = _ctx()
+    with pytest.raises(RuntimeError):
+        ctx2.nearest_neighbor_search(q)  # empty map
+
+
+@pytest.mark.parametrize("scheme", ["default", "least_square", "huber", "exp", "neighborhood", "geman_mcclure",
+                                    "square_geman_mcclure", "cauchy"])
+def test_gauss_newton_step(torch_cuda, O, golden_components, scheme):
+    g = golden_components
+    sigma = float(g[f"gn_{scheme}_sigma"])
+    ctx = _ctx(scheme=scheme, sigma=sigma)
+    pose, dx, loss, neq = ctx.align_point_to_plane(g["nn_points"], g["nn_queries"], g["nn_normals"])
+    # vs the reference's own align(): its f32 normal equations carry ~1e-5 relative noise
+    np.testing.assert_allclose(dx, g[f"gn_{scheme}_dx"], atol=2e-5, rtol=1e-4)
+    assert abs(loss - float(g[f"gn_{scheme}_loss"])) <= 1e-4 * abs(float(g[f"gn_{scheme}_loss"]))
+    np.testing.assert_allclose(pose, g[f"gn_{scheme}_mat"], atol=2e-5)
+    # vs the oracle with f64 accumulation: the same f32 rows, exact sums
+    st = O.gauss_newton_step(g["nn_queries"], g["nn_points"], g["nn_normals"], scheme, sigma, accumulate=np.float64)
+    np.testing.assert_allclose(dx, st.dx, atol=2e-7, rtol=2e-5)
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = neq[:21]
+    H = H + np.triu(H, 1).T
+    np.testing.assert_allclose(H, st.H, rtol=1e-5, atol=1e-6 * np.abs(st.H).max())
+    np.testing.assert_allclose(neq[21:27], st.g, rtol=1e-4, atol=1e-6 * np.abs(st.g).max())
+    assert neq[29] == g["nn_points"].shape[0]
+    # run-to-run bit reproducibility of the reduction
+    _, dx2, loss2, neq2 = ctx.align_point_to_plane(g["nn_points"], g["nn_queries"], g["nn_normals"])
+    assert np.array_equal(neq, neq2) and np.array_equal(dx, dx2)
+
+
+def test_invalid_jacobian_raises_runtime_error(torch_cuda):
+    """optimization.py:334-336: |det H| < 1e-7 -> RuntimeError("Invalid Jacobian in Gauss Newton minimization")."""
+    ctx = _ctx()
+    tgt = np.zeros((10, 3), np.float32)
+    tgt[:, 0] = np.arange(10)
+    n = np.tile(np.array([[0, 0, 1.0]], np.float32), (10, 1))
+    with pytest.raises(RuntimeError, match="Invalid Jacobian"):
+        ctx.align_point_to_plane(tgt + np.float32(0.1), tgt, n)
+
+
+def test_map_update(torch_cuda, O, golden_components):
+    g = golden_components
+    ctx = _ctx(local_map_size=2)
+    c, rel = g["mu_clouds"], g["mu_rel"]
+    ctx.map_init()
+    assert ctx.map_update(np.eye(4), c[0]) == c[0].shape[0]
+    ctx.map_update(rel, c[1])
+    ctx.map_update(rel, None)
+    ctx.map_update(rel, c[2])
+    withnan = c[3].copy()
+    ctx.map_update(rel, withnan)
+    assert ctx.map_num_clouds() == len(g["mu_counts"])
+    assert ctx.map_size() == int(g["mu_counts"].sum())
+    np.testing.assert_allclose(ctx.map_points(), g["mu_final"], atol=1e-5)
+    # NaN rows are dropped on insert (remove_nan, local_map.py:327)
+    withnan[::7, 1] = np.nan
+    assert ctx.map_update(rel, withnan) == int((~np.isnan(withnan).any(axis=1)).sum())
+
+
+@pytest.mark.parametrize("run", ["A_numpy_ls", "B_tensor_gm", "C_numpy_nbh_forced", "D_numpy_huber_forced"])
+def test_c1_sequence_matches_reference_and_oracle(torch_cuda, O, golden_c1, c1_scans, run):
+    """BASELINE.json configs[0]: 10 synthetic 64x1024 scans, grid_sample preprocessing, CV init — the MI355X odometry
+    behind the reference's plugin surface reproduces the reference CPU poses frame by frame."""
+    from pylidar_slam_amd.odometry import (ConstantVelocityInitialization, GridSample, GridSampleConfig,
+                                           MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector)
+    g = golden_c1
+    scans, _ = c1_scans
+    mode, scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
+    h, w = (int(v) for v in g["hw"])
+    cfg = MI355XICPConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr),
+                          data_key="sample_points" if mode == "numpy" else "input_data",
+                          alignment=dict(mode="point_to_plane_gauss_newton",
+                                         gauss_newton_config=dict(max_iters=1, scheme=scheme, sigma=float(sigma))))
+    odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(h, w), device=torch_cuda.device("cuda:0"))
+    odo.init()
+    init = ConstantVelocityInitialization()
+    init.init()
+    gs = GridSample(GridSampleConfig(voxel_size=0.3, pointcloud_key="numpy_pc"), ctx=odo.ctx)
+    worst = (0.0, 0.0)
+    for f, s in enumerate(scans):
+        d = {"numpy_pc": s}
+        init.next_frame(d)
+        gs.filter(d)
+        assert d["sample_points"].shape[0] == int(g[f"{run}_counts"][f])
+        if mode == "tensor":
+            d["input_data"] = torch_cuda.from_numpy(d["sample_points"])
+        odo.process_next_frame(d)
+        if f == 0:
+            assert "odometry_pose" not in d  # frame 0 writes nothing (icp_odometry.py:171-181)
+            continue
+        init.save_real_motion(d["odometry_pose"], d)
+        dt, dr = O.pose_error(d["odometry_pose"], g[f"{run}_rel"][f])
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        assert dt < 1e-4 and dr < 1e-4, (run, f, dt, dr)
+        assert d["odometry_pose"].dtype == np.float32 and d["odometry_pose"].shape == (4, 4)
+        if float(thr) == 0.0:
+            assert odo.last_result.iterations == int(g[f"{run}_iters"][f])
+    assert odo.ctx.map_size() == int(g[f"{run}_map_size"])
+    rel = odo.get_relative_poses()
+    assert rel.shape == (len(scans), 4, 4) and np.array_equal(rel[0], np.eye(4, dtype=np.float32))
+    np.testing.assert_allclose(np.stack(odo.absolute_poses), g[f"{run}_abs"], atol=5e-4)
+    print(f"{run}: worst per-frame error vs reference {worst[0]:.2e} m / {worst[1]:.2e} rad")
+
+
+def test_register_masks_nan_and_null_rows(torch_cuda, O, golden_components):
+    g = golden_components
+    ctx = _ctx(max_num_alignments=6, threshold_delta_pose=0.0)
+    ctx.map_set(g["nn_map"])
+    q = g["nn_queries"]
+    base = ctx.register(q)
+    dirty = np.concatenate([q[:100], np.full((7, 3), np.nan, np.float32), q[100:], np.zeros((5, 3), np.float32)])
+    r1 = ctx.register(dirty, skip_null=True)
+    assert r1.num_targets == q.shape[0] == base.num_targets
+    np.testing.assert_allclose(r1.pose, base.pose, atol=1e-6)
+    np.testing.assert_allclose(r1.losses, base.losses, rtol=1e-9)
+    empty = ctx.register(np.full((4, 3), np.nan, np.float32))
+    assert empty.num_targets == 0 and empty.converged and np.array_equal(empty.pose, np.eye(4, dtype=np.float32))
+
+
+def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
+    """The multi-GPU seam (accumulate -> [all-reduce] -> solve) with world size 1 reproduces icp_register bit for bit,
+    and two half-slices summed by hand give the same normal equations as the whole scan."""
+    g = golden_components
+    ctx = _ctx(max_num_alignments=5, threshold_delta_pose=0.0)
+    ctx.map_set(g["nn_map"])
+    q = g["nn_queries"]
+    fused = ctx.register(q)
+    neq = ctx.normal_equations_tensor()
+    ctx.register_begin(q)
+    for _ in range(5):
+        ctx.iteration_accumulate()
+        ctx.iteration_solve()
+    split = ctx.register_end()
+    assert np.array_equal(split.pose, fused.pose) and np.array_equal(split.losses, fused.losses)
+    # slices
+    ctx.register_begin(q)
+    ctx.iteration_accumulate()
+    whole = neq.clone()
+    ctx.register_end()
+    parts = []
+    for sl in (q[:1000], q[1000:]):
+        ctx.register_begin(sl)
+        ctx.iteration_accumulate()
+        parts.append(neq.clone())
+        ctx.register_end()
+    np.testing.assert_allclose((parts[0] + parts[1]).cpu().numpy(), whole.cpu().numpy(), rtol=1e-12)
+
+
+def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
+    """BASELINE.json configs[1]: 64x2048 scan (131072 points) vs a 100k-point map, 20 forced iterations, for the three
+    schemes of BASELINE.md; pose within 1e-4 m / 1e-4 rad of the oracle, plus exactness of the search on a sample."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=64, width=2048)
+    scans, poses = make_sequence(cfg, 6)
+    model = make_fixed_map(cfg, scans[:5], poses[:5], ref_frame=4, num_points=100_000)
+    scan = scans[5]
+    ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0)
+    ctx.map_set(model)
+    dscan = torch_cuda.from_numpy(scan).cuda()
+    # search exactness on a sample of the full-size problem
+    sample = scan[::61]
+    _, _, ix = ctx.nearest_neighbor_search(sample, with_normals=False, with_index=True)
+    bi, bd2 = O.brute_force_nn(sample, model)
+    d2 = ((sample.astype(np.float64) - model[ix].astype(np.float64)) ** 2).sum(axis=1)
+    assert (ix == bi).mean() > 0.999
+    np.testing.assert_allclose(d2, bd2, rtol=2e-6, atol=1e-12)
+    for scheme, sigma in (("least_square", 0.5), ("geman_mcclure", 0.3), ("neighborhood", 0.2)):
+        ctx.set_alignment(scheme, sigma, 20, 0.0)
+        ctx.map_set(model)  # clears the normal cache, like every map update
+        res = ctx.register(dscan)
+        assert res.iterations == 20 and res.num_targets == scan.shape[0]
+        lm = O.KdTreeLocalMapOracle()
+        lm.set_map_pointcloud(model)
+        oc = O.ICPOracleConfig(max_num_alignments=20, threshold_delta_pose=0.0, scheme=scheme, sigma=sigma,
+                               height=64, width=2048, accumulate=np.float64)
+        orc = O.ICPFrameToModelOracle(oc)
+        orc.local_map = lm
+        _, opose = orc.register_new_frame(scan, np.eye(4, dtype=np.float32))
+        dt, dr = O.pose_error(res.pose, opose)
+        print(f"C2 {scheme}: |dt| = {dt:.2e} m |dr| = {dr:.2e} rad, loss {res.losses[-1]:.4f} vs "
+              f"{orc.traces[-1].loss[-1]:.4f}, normals computed {res.normals_computed}")
+        assert dt < 1e-4 and dr < 1e-4, (scheme, dt, dr)
+        np.testing.assert_allclose(res.losses[-1], orc.traces[-1].loss[-1], rtol=1e-3)
