@@ -164,7 +164,8 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
 
 /* ---- profiling hooks ---------------------------------------------------------------------------------------------
  * Accumulated HIP-event time (ms) and launch count of the dominant kernel (the per-iteration nearest-neighbour
- * search) since the last reset; measured on the context's stream. */
+ * search) since the last reset; measured on the context's stream.  `enable` is a bit mask: 1 = search kernel,
+ * 2 = reduction, 4 = normal estimation (0 disables). */
 int icp_profile_enable(icp_ctx* ctx, int enable);
 int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
                      double* normals_ms_out);

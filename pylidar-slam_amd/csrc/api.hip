@@ -37,7 +37,7 @@ void DeviceBuffer::release() {
 
 int prof_begin(icp_ctx* ctx, int kind) {
     Profile& p = ctx->prof;
-    if (!p.enabled) return -1;
+    if (!p.enabled || !((p.mask >> kind) & 1)) return -1;
     const int ev = (int)p.pending.size();
     if (ev >= (int)p.pool.size()) {
         hipEvent_t a, b;
@@ -663,6 +663,7 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
 int icp_profile_enable(icp_ctx* ctx, int enable) {
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ctx->prof.enabled = enable != 0;
+    ctx->prof.mask = enable;
     ctx->prof.pending.clear();
     for (int k = 0; k < 3; ++k) {
         ctx->prof.ms[k] = 0;

@@ -91,6 +91,7 @@ struct DeviceBuffer {
 
 struct Profile {
     bool enabled = false;
+    int mask = 0;  // bit0 search, bit1 reduce, bit2 normals
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     struct Rec { int kind; int ev; };
     std::vector<Rec> pending;

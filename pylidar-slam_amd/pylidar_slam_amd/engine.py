@@ -295,8 +295,9 @@ class IcpContext:
         return self._result(res, losses, dxs)
 
     # ---- profiling ---------------------------------------------------------------------------------------------------
-    def profile_enable(self, enable: bool = True):
-        self._check(self._lib.icp_profile_enable(self._h, 1 if enable else 0))
+    def profile_enable(self, mask: int = 1):
+        """bit mask of the kernels timed with HIP events: 1 search, 2 reduction, 4 normals (0 = off)."""
+        self._check(self._lib.icp_profile_enable(self._h, int(mask)))
 
     def profile_read(self):
         s, n, r, m = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)

@@ -291,9 +291,9 @@ def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
     schemes of BASELINE.md; pose within 1e-4 m / 1e-4 rad of the oracle, plus exactness of the search on a sample."""
     from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
     cfg = SceneConfig(height=64, width=2048)
-    scans, poses = make_sequence(cfg, 6)
-    model = make_fixed_map(cfg, scans[:5], poses[:5], ref_frame=4, num_points=100_000)
-    scan = scans[5]
+    scans, poses = make_sequence(cfg, 9)
+    model = make_fixed_map(cfg, scans[:8], poses[:8], ref_frame=7, num_points=100_000)
+    scan = scans[8]
     ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0)
     ctx.map_set(model)
     dscan = torch_cuda.from_numpy(scan).cuda()
