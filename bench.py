@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--sigma", type=float, default=0.3)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--cell-size", type=float, default=0.5)
+    ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
     return ap.parse_args()

@@ -240,7 +240,7 @@ void icp_default_config(icp_config* cfg) {
     cfg->sigma = 0.5f;
     cfg->local_map_size = 20;            // local_map.py:249
     cfg->num_neighbors_normals = 10;     // :250
-    cfg->cell_size = 0.5f;
+    cfg->cell_size = 0.0f;  // <= 0: auto-tuned from the measured map occupancy
     cfg->max_rings = 4;
     cfg->device = 0;
     cfg->poll_every = 4;
@@ -251,13 +251,14 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || cfg->device >= count) return ICP_ERR_NO_DEVICE;
-    if (cfg->height <= 0 || cfg->width <= 0 || !(cfg->cell_size > 0.f) || cfg->max_rings < 1 ||
+    if (cfg->height <= 0 || cfg->width <= 0 || cfg->max_rings < 1 ||
         cfg->num_neighbors_normals < 1 || cfg->num_neighbors_normals > 64 || cfg->local_map_size < 1 ||
         cfg->max_num_alignments < 1)
         return ICP_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(cfg->device) != hipSuccess) return ICP_ERR_HIP;
     icp_ctx* ctx = new icp_ctx();
     ctx->cfg = *cfg;
+    ctx->cell_h = cfg->cell_size > 0.f ? cfg->cell_size : 0.5f;
     int rc = ensure_state(ctx);
     if (rc == ICP_OK) rc = init_state(ctx, nullptr);
     if (rc != ICP_OK) {
@@ -276,7 +277,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->targets,    &ctx->nn_pos,     &ctx->partials, &ctx->state,     &ctx->loss_hist,
                             &ctx->dx_hist,    &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
                             &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
-                            &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter};
+                            &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
+                            &ctx->grid_stats};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
@@ -581,6 +583,9 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
     if ((rc = init_state(ctx, init_pose))) return rc;
+    // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
+    // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
+    if (!ctx->normals_ready && ctx->map_m <= 2 * n && (rc = launch_normals_all(ctx))) return rc;
     ctx->in_registration = true;
     return ICP_OK;
 }
@@ -602,8 +607,18 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     if (!ctx || !ctx->in_registration || !result) return ICP_ERR_INVALID_ARGUMENT;
     ctx->in_registration = false;
     RegState st;
+    int stats[4] = {0, 0, 0, 0};
     ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->stats_pending)
+        ICP_HIP(ctx, hipMemcpyAsync(stats, ctx->grid_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stats_pending) {
+        ctx->occupied_cells = stats[0];
+        ctx->stats_m = ctx->stats_m_pending;
+        ctx->stats_pending = false;
+    }
+    st.normals_computed += ctx->normals_eager_count;
+    ctx->normals_eager_count = 0;
     memcpy(result->pose, st.pose, sizeof(st.pose));
     memcpy(result->params, st.params, sizeof(st.params));
     result->iterations = st.iter;
@@ -631,7 +646,7 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
     // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
     const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
     for (int it = 0; it < iters; ++it) {
-        if ((rc = icp_iteration_accumulate(ctx)) || (rc = icp_iteration_solve(ctx))) {
+        if ((rc = launch_search(ctx)) || (rc = launch_normals(ctx)) || (rc = launch_reduce_solve(ctx))) {
             ctx->in_registration = false;
             return rc;
         }

@@ -158,23 +158,35 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_given(const float* __res
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
 
-// fixed-order sum of the per-block partial rows -> neq[NEQ]
-__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int nblocks,
-                                                      const RegState* __restrict__ st, int check_done,
-                                                      double* __restrict__ neq) {
-    if (check_done && st->done) return;
-    __shared__ double lds[8][NEQ];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 groups x 32 columns
-    double s = 0.0;
-    for (int b = grp; b < nblocks; b += 8) s += partials[(size_t)b * NEQ + col];
-    lds[grp][col] = s;
+// fixed-order sum of the per-block partial rows -> out[NEQ] (1024 threads: 32 row groups x 32 columns; the order of
+// the additions depends only on the launch geometry, never on timing)
+__device__ inline void sum_partials_block(const double* __restrict__ partials, int nblocks, double* out /* LDS or global */) {
+    __shared__ double lds[32][NEQ];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = grp;
+    for (; b + 96 < nblocks; b += 128) {  // four independent loads in flight
+        s0 += partials[(size_t)b * NEQ + col];
+        s1 += partials[(size_t)(b + 32) * NEQ + col];
+        s2 += partials[(size_t)(b + 64) * NEQ + col];
+        s3 += partials[(size_t)(b + 96) * NEQ + col];
+    }
+    for (; b < nblocks; b += 32) s0 += partials[(size_t)b * NEQ + col];
+    lds[grp][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < NEQ) {
         double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) t += lds[g][threadIdx.x];
-        neq[threadIdx.x] = t;
+        for (int g = 0; g < 32; ++g) t += lds[g][threadIdx.x];
+        out[threadIdx.x] = t;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partials, int nblocks,
+                                                       const RegState* __restrict__ st, int check_done,
+                                                       double* __restrict__ neq) {
+    if (check_done && st->done) return;
+    sum_partials_block(partials, nblocks, neq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -224,45 +236,53 @@ __device__ inline void from_pose_f32(const float* T, float* p) {  // pose.py:188
     }
 }
 
-// LU with partial pivoting in f64: det and solve H x = b (6x6)
+// Cholesky H = L L^T in f64 with fully unrolled static indexing (everything stays in registers): returns det(H)
+// (0 if a pivot is not positive: H = J^T J is PSD, so that only happens for a numerically singular system) and solves
+// H x = b.
 __device__ inline double solve6(double A[6][6], double* b, double* x) {
+    double L[6][6];
     double det = 1.0;
-    int perm_sign = 1;
-    for (int c = 0; c < 6; ++c) {
-        int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 6; ++r)
-            if (fabs(A[r][c]) > best) {
-                best = fabs(A[r][c]);
-                piv = r;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) ok = false;
+        const double ljj = sqrt(d);
+        L[j][j] = ljj;
+        det *= d;
+        const double inv = 1.0 / ljj;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = A[i][j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) v -= L[i][k] * L[j][k];
+                L[i][j] = v * inv;
             }
-        if (best == 0.0) return 0.0;
-        if (piv != c) {
-            for (int k = 0; k < 6; ++k) {
-                const double t = A[c][k];
-                A[c][k] = A[piv][k];
-                A[piv][k] = t;
-            }
-            const double t = b[c];
-            b[c] = b[piv];
-            b[piv] = t;
-            perm_sign = -perm_sign;
-        }
-        det *= A[c][c];
-        const double inv = 1.0 / A[c][c];
-        for (int r = c + 1; r < 6; ++r) {
-            const double f = A[r][c] * inv;
-            if (f == 0.0) continue;
-            for (int k = c; k < 6; ++k) A[r][k] -= f * A[c][k];
-            b[r] -= f * b[c];
         }
     }
-    for (int r = 5; r >= 0; --r) {
-        double s = b[r];
-        for (int k = r + 1; k < 6; ++k) s -= A[r][k] * x[k];
-        x[r] = s / A[r][r];
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) v -= L[i][k] * y[k];
+        y[i] = v / L[i][i];
     }
-    return det * (double)perm_sign;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) v -= L[k][i] * x[k];
+        x[i] = v / L[i][i];
+    }
+    return ok ? det : 0.0;
 }
 
 // Solves one Gauss-Newton step from the packed normal equations.  Returns status; dx (f32) and loss are written.
@@ -277,12 +297,15 @@ __device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double
     }
     double H[6][6], g[6], x[6];
     int k = 0;
+#pragma unroll
     for (int a = 0; a < 6; ++a)
+#pragma unroll
         for (int b = a; b < 6; ++b) {
             H[a][b] = neq[k];
             H[b][a] = neq[k];
             ++k;
         }
+#pragma unroll
     for (int a = 0; a < 6; ++a) g[a] = neq[21 + a];
     const double det = solve6(H, g, x);
     *loss = neq[27];
@@ -294,10 +317,8 @@ __device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double
     return ICP_OK;
 }
 
-__global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
-                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->done) return;
+__device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
+                                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
     const int it = st->iter;
     st->n_worklist = 0;
     st->n_targets = (int)neq[29];
@@ -339,6 +360,26 @@ __global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ ne
     if (st->iter >= ap.max_iters) st->done = 1;
 }
 
+__global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
+                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->done) return;
+    solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap);
+}
+
+// single-GPU path: final sum of the partial rows + solve + pose update in one launch
+__global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks,
+                                                    RegState* __restrict__ st, AlignParams ap,
+                                                    double* __restrict__ neq, double* __restrict__ loss_hist,
+                                                    float* __restrict__ dx_hist, int hist_cap) {
+    if (st->done) return;
+    __shared__ double total[NEQ];
+    sum_partials_block(partials, nblocks, total);
+    __syncthreads();
+    if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
+    if (threadIdx.x == 0) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap);
+}
+
 // align() on given correspondences: writes dx[6], pose[16] (f32) and loss into `out` (device, 6 + 16 floats; loss double)
 __global__ void k_solve_given(const double* __restrict__ neq, float* __restrict__ out_f, double* __restrict__ out_loss,
                               int* __restrict__ out_status) {
@@ -364,7 +405,7 @@ static AlignParams align_params(const icp_ctx* ctx) {
 static int reduce_grid(int64_t n) {
     int blocks = (int)((n + RED_THREADS - 1) / RED_THREADS);
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;  // one block per CU: 256 partial rows to sum
     return blocks;
 }
 
@@ -376,8 +417,24 @@ int launch_reduce(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->normals.as<float4>(), ctx->tgt_ptr, ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        align_params(ctx), ctx->partials.as<double>());
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 1, ctx->neq);
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int launch_reduce_solve(icp_ctx* ctx) {
+    const int n = (int)ctx->tgt_n;
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    const int tok = prof_begin(ctx, 1);
+    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
+                       ctx->normals.as<float4>(), ctx->tgt_ptr, ctx->nn_pos.as<int>(), n, reg_state(ctx),
+                       align_params(ctx), ctx->partials.as<double>());
+    hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
+                       ctx->dx_hist.as<float>(), ctx->hist_cap);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -397,7 +454,7 @@ int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const f
     ICP_HIP(ctx, ctx->stage_out.reserve(256));
     hipLaunchKernelGGL(k_reduce_given, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, nrm, (int)n,
                        align_params(ctx), ctx->partials.as<double>());
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 0, ctx->neq);
     char* out = ctx->stage_out.as<char>();
     hipLaunchKernelGGL(k_solve_given, dim3(1), dim3(64), 0, ctx->stream, ctx->neq, (float*)out, (double*)(out + 128),

@@ -7,6 +7,8 @@
 //   3. scatter: point -> start[slot] + rank, stored as float4 (x, y, z, bits(original index))
 // The rank order inside a cell is not deterministic, but every consumer breaks distance ties on the ORIGINAL index,
 // so search results are.
+#include <math.h>
+
 #include "icp_internal.h"
 
 namespace icp {
@@ -167,7 +169,8 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size) {
 }
 
 __global__ void k_grid_insert(const float* __restrict__ xyz, int m, float inv_h, GridEntry* __restrict__ table,
-                              unsigned int mask, int* __restrict__ slot_of, int* __restrict__ rank_of) {
+                              unsigned int mask, int* __restrict__ slot_of, int* __restrict__ rank_of,
+                              int* __restrict__ stats) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -175,6 +178,7 @@ __global__ void k_grid_insert(const float* __restrict__ xyz, int m, float inv_h,
     unsigned int slot = hash_cell(key) & mask;
     while (true) {
         unsigned long long old = atomicCAS(&table[slot].key, GRID_EMPTY, key);
+        if (old == GRID_EMPTY) atomicAdd(&stats[0], 1);  // occupied cells (feeds the cell-size auto-tuning)
         if (old == GRID_EMPTY || old == key) break;
         slot = (slot + 1) & mask;
     }
@@ -230,11 +234,27 @@ int build_grid(icp_ctx* ctx) {
     ctx->table_size = tsize;
     GridEntry* table = ctx->table.as<GridEntry>();
     const float* xyz = ctx->map_xyz[ctx->map_cur].as<float>();
-    const float inv_h = 1.0f / ctx->cfg.cell_size;
+    // cell edge: fixed by the configuration, or auto-tuned towards ~6 map points per occupied cell from the occupancy
+    // measured on the previous build (surface-like scaling: points per cell ~ h^2)
+    if (ctx->cfg.cell_size > 0.f) {
+        ctx->cell_h = ctx->cfg.cell_size;
+    } else if (ctx->occupied_cells > 0 && ctx->stats_m > 0) {
+        const double mean = (double)ctx->stats_m / (double)ctx->occupied_cells;
+        double f = sqrt(6.0 / mean);
+        if (f < 0.5) f = 0.5;
+        if (f > 2.0) f = 2.0;
+        if (f < 0.85 || f > 1.18) ctx->cell_h = (float)fmin(fmax(ctx->cell_h * f, 0.05), 8.0);
+    }
+    const float inv_h = 1.0f / ctx->cell_h;
+    ICP_HIP(ctx, ctx->grid_stats.reserve(16));
+    ICP_HIP(ctx, hipMemsetAsync(ctx->grid_stats.ptr, 0, 16, ctx->stream));
+    ctx->normals_ready = false;
+    ctx->stats_pending = true;
+    ctx->stats_m_pending = m;
     const unsigned tb = (tsize + 255) / 256, mb = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_grid_clear, dim3(tb), dim3(256), 0, ctx->stream, table, tsize);
     hipLaunchKernelGGL(k_grid_insert, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, table, tsize - 1,
-                       ctx->slot_of.as<int>(), ctx->rank_of.as<int>());
+                       ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->grid_stats.as<int>());
     int* counts = ctx->scan_b.as<int>();
     hipLaunchKernelGGL(k_grid_counts, dim3(tb), dim3(256), 0, ctx->stream, table, tsize, counts);
     int rc = exclusive_scan_i32(ctx, counts, counts, tsize, nullptr);

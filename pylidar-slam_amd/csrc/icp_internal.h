@@ -120,6 +120,14 @@ struct icp_ctx {
     icp::DeviceBuffer scan_tmp;
     icp::DeviceBuffer worklist;        // int[M]
     bool grid_valid = false;
+    bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
+    int64_t normals_eager_count = 0;
+    float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
+    icp::DeviceBuffer grid_stats;      // int[4]: occupied cells of the last build
+    int occupied_cells = 0;
+    int64_t stats_m = 0;               // map size the occupancy figure belongs to
+    bool stats_pending = false;
+    int64_t stats_m_pending = 0;
     // ---- registration
     icp::DeviceBuffer targets;         // staged copy of host targets
     const float* tgt_ptr = nullptr;    // device pointer of the current targets
@@ -164,11 +172,13 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 int launch_search_raw(icp_ctx* ctx);  // 1-NN without the pose transform (LocalMap seam)
 int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, queues missing normals
 int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
+int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager mode)
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
 
 // ---- gauss_newton.hip
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
+int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n);
 
 // ---- projection.hip

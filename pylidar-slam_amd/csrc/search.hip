@@ -42,17 +42,28 @@ __device__ inline float axis_gap(int o, float f, float h) {
     return o < 0 ? f + (float)(-o - 1) * h : (h - f) + (float)(o - 1) * h;
 }
 
+__device__ inline void consider(const float4 q, int pos, float px, float py, float pz, Best& b) {
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const int idx = __float_as_int(q.w);
+    if (better(d2, idx, b.d2, b.idx)) {
+        b.d2 = d2;
+        b.idx = idx;
+        b.pos = pos;
+    }
+}
+
+// candidates are fetched four at a time (independent 16-byte loads in flight together); the tail re-reads the last
+// point of the cell, which cannot change the (d2, index) minimum
 __device__ inline void scan_cell_1nn(const GridView& g, int start, int count, float px, float py, float pz, Best& b) {
-    for (int k = 0; k < count; ++k) {
-        const float4 q = g.pts[start + k];
-        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        const int idx = __float_as_int(q.w);
-        if (better(d2, idx, b.d2, b.idx)) {
-            b.d2 = d2;
-            b.idx = idx;
-            b.pos = start + k;
-        }
+    const int last = start + count - 1;
+    for (int k = start; k <= last; k += 4) {
+        const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+        const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+        consider(q0, k, px, py, pz, b);
+        consider(q1, k1, px, py, pz, b);
+        consider(q2, k2, px, py, pz, b);
+        consider(q3, k3, px, py, pz, b);
     }
 }
 
@@ -122,7 +133,7 @@ __device__ inline void transform_point(const float* __restrict__ T, float x, flo
 __global__ __launch_bounds__(256) void k_search(GridView g, const float* __restrict__ tgt, int n, int mode,
                                                 int transform, RegState* __restrict__ st, int max_rings,
                                                 int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                int* __restrict__ worklist) {
+                                                int* __restrict__ worklist, int queue_normals) {
     if (st->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void k_search(GridView g, const float* __restr
     if (transform) transform_point(st->pose, x, y, z, px, py, pz);
     const Best b = nearest_in_grid(g, px, py, pz, max_rings);
     nn_pos[i] = b.pos;
-    if (b.pos >= 0 && nflag[b.pos] == 0) {
+    if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
         if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
     }
 }
@@ -237,77 +248,91 @@ __device__ inline void smallest_eigenvector(double a00, double a01, double a02, 
 }
 
 template <int KN>
+__device__ inline void estimate_normal(const GridView& g, int s, int max_rings, float4* __restrict__ normals,
+                                       int* __restrict__ nflag) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    TopK<KN> t;
+    t.init();
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float h = g.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    int start, count;
+    if (grid_lookup(g, cx, cy, cz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+    bool exact = false;
+    for (int r = 1; r <= max_rings && !exact; ++r) {
+        for (int oz = -r; oz <= r; ++oz) {
+            const float gz = axis_gap(oz, fz, h);
+            const float gz2 = gz * gz;
+            if (gz2 > t.d2[KN - 1]) continue;
+            const int az = oz < 0 ? -oz : oz;
+            for (int oy = -r; oy <= r; ++oy) {
+                const float gy = axis_gap(oy, fy, h);
+                const float gyz2 = fmaf(gy, gy, gz2);
+                if (gyz2 > t.d2[KN - 1]) continue;
+                const int ay = oy < 0 ? -oy : oy;
+                const int step = ((az == r) || (ay == r)) ? 1 : 2 * r;
+                for (int ox = -r; ox <= r; ox += step) {
+                    const float gx = axis_gap(ox, fx, h);
+                    if (fmaf(gx, gx, gyz2) > t.d2[KN - 1]) continue;
+                    if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
+                        scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+                }
+            }
+        }
+        const float bound = (float)r * h + edge;
+        exact = t.d2[KN - 1] <= bound * bound * 0.999999f;
+    }
+    if (!exact) {
+        t.init();
+        scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
+    }
+    // covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32
+    float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    int used = 0;
+#pragma unroll
+    for (int k = 1; k < KN; ++k) {
+        if (t.pos[k] < 0) continue;  // map smaller than k + 1 points
+        const float4 q = g.pts[t.pos[k]];
+        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+        c00 += dx * dx;
+        c01 += dx * dy;
+        c02 += dx * dz;
+        c11 += dy * dy;
+        c12 += dy * dz;
+        c22 += dz * dz;
+        ++used;
+    }
+    const float invk = used > 0 ? 1.0f / (float)used : 0.f;
+    float nx, ny, nz;
+    smallest_eigenvector((double)(c00 * invk), (double)(c01 * invk), (double)(c02 * invk), (double)(c11 * invk),
+                         (double)(c12 * invk), (double)(c22 * invk), nx, ny, nz);
+    normals[s] = make_float4(nx, ny, nz, 1.f);
+    nflag[s] = 1;
+}
+
+// lazy: the map points queued by the search of this iteration
+template <int KN>
 __global__ __launch_bounds__(128) void k_normals(GridView g, RegState* __restrict__ st,
                                                  const int* __restrict__ worklist, int max_rings,
                                                  float4* __restrict__ normals, int* __restrict__ nflag) {
     if (st->done) return;
     const int nw = st->n_worklist;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x) {
-        const int s = worklist[w];
-        const float4 P = g.pts[s];
-        const float px = P.x, py = P.y, pz = P.z;
-        TopK<KN> t;
-        t.init();
-        const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
-        const float h = g.h;
-        const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
-        const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
-        const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
-        const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-        int start, count;
-        if (grid_lookup(g, cx, cy, cz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
-        bool exact = false;
-        for (int r = 1; r <= max_rings && !exact; ++r) {
-            for (int oz = -r; oz <= r; ++oz) {
-                const float gz = axis_gap(oz, fz, h);
-                const float gz2 = gz * gz;
-                if (gz2 > t.d2[KN - 1]) continue;
-                const int az = oz < 0 ? -oz : oz;
-                for (int oy = -r; oy <= r; ++oy) {
-                    const float gy = axis_gap(oy, fy, h);
-                    const float gyz2 = fmaf(gy, gy, gz2);
-                    if (gyz2 > t.d2[KN - 1]) continue;
-                    const int ay = oy < 0 ? -oy : oy;
-                    const int step = ((az == r) || (ay == r)) ? 1 : 2 * r;
-                    for (int ox = -r; ox <= r; ox += step) {
-                        const float gx = axis_gap(ox, fx, h);
-                        if (fmaf(gx, gx, gyz2) > t.d2[KN - 1]) continue;
-                        if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
-                            scan_cell_knn<KN>(g, start, count, px, py, pz, t);
-                    }
-                }
-            }
-            const float bound = (float)r * h + edge;
-            exact = t.d2[KN - 1] <= bound * bound * 0.999999f;
-        }
-        if (!exact) {
-            t.init();
-            scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
-        }
-        // covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32
-        float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-        int used = 0;
-#pragma unroll
-        for (int k = 1; k < KN; ++k) {
-            if (t.pos[k] < 0) continue;  // map smaller than k + 1 points
-            const float4 q = g.pts[t.pos[k]];
-            const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-            c00 += dx * dx;
-            c01 += dx * dy;
-            c02 += dx * dz;
-            c11 += dy * dy;
-            c12 += dy * dz;
-            c22 += dz * dz;
-            ++used;
-        }
-        const float invk = used > 0 ? 1.0f / (float)used : 0.f;
-        float nx, ny, nz;
-        smallest_eigenvector((double)(c00 * invk), (double)(c01 * invk), (double)(c02 * invk), (double)(c11 * invk),
-                             (double)(c12 * invk), (double)(c22 * invk), nx, ny, nz);
-        normals[s] = make_float4(nx, ny, nz, 1.f);
-        nflag[s] = 1;
-    }
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x)
+        estimate_normal<KN>(g, worklist[w], max_rings, normals, nflag);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
+}
+
+// eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values
+// are the same either way: a normal depends on the map only)
+template <int KN>
+__global__ __launch_bounds__(128) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
+                                                     int* __restrict__ nflag) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < g.m) estimate_normal<KN>(g, s, max_rings, normals, nflag);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -400,8 +425,8 @@ static GridView make_view(icp_ctx* ctx) {
     GridView g;
     g.table = ctx->table.as<GridEntry>();
     g.mask = ctx->table_size - 1;
-    g.h = ctx->cfg.cell_size;
-    g.inv_h = 1.0f / ctx->cfg.cell_size;
+    g.h = ctx->cell_h;
+    g.inv_h = 1.0f / ctx->cell_h;
     g.pts = ctx->sorted_pts.as<float4>();
     g.m = (int)ctx->map_m;
     return g;
@@ -413,13 +438,38 @@ int launch_search(icp_ctx* ctx) {
     const int tok = prof_begin(ctx, 0);
     hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt_ptr, n,
                        ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                       ctx->nflag.as<int>(), ctx->worklist.as<int>());
+                       ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
+// eager estimation of every map normal (only for the k with a register-resident top-k list)
+int launch_normals_all(icp_ctx* ctx) {
+    const int kn = ctx->cfg.num_neighbors_normals + 1;
+    if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
+    if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
+    const int blocks = (int)((ctx->map_m + 127) / 128);
+    GridView g = make_view(ctx);
+    const int tok = prof_begin(ctx, 2);
+    if (kn == 11)
+        hipLaunchKernelGGL(k_normals_all<11>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
+    else if (kn == 6)
+        hipLaunchKernelGGL(k_normals_all<6>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
+    else
+        hipLaunchKernelGGL(k_normals_all<21>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    ctx->normals_ready = true;
+    ctx->normals_eager_count += ctx->map_m;
+    return ICP_OK;
+}
+
 int launch_normals(icp_ctx* ctx) {
+    if (ctx->normals_ready) return ICP_OK;
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     // the worklist length lives on the device: launch a fixed grid and stride over it
     int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
@@ -455,7 +505,7 @@ int launch_search_raw(icp_ctx* ctx) {
     if (n <= 0) return ICP_OK;
     hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt_ptr, n,
                        ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                       ctx->nflag.as<int>(), ctx->worklist.as<int>());
+                       ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -301,7 +301,7 @@ class MI355XICPConfig:
     initialization: Any = None
     viz_debug: bool = False
     # MI355X-side knobs
-    cell_size: float = 0.5
+    cell_size: float = 0.0  # <= 0: auto-tuned
     max_rings: int = 4
 
 
