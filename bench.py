@@ -71,14 +71,11 @@ def step_replica(ctx, scan_dev, vmap_out):
     return res
 
 
-def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, neq, iters, dist):
+def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, iters):
+    from pylidar_slam_amd.distributed import sharded_register
     ctx.project(full_scan_dev, out=vmap_out)
-    ctx.register_begin(scan_slice_dev)
-    for _ in range(iters):
-        ctx.iteration_accumulate()
-        dist.all_reduce(neq)  # RCCL, 256 B, in place on the library's normal-equation vector
-        ctx.iteration_solve()
-    res = ctx.register_end()
+    # per iteration: accumulate -> all-reduce (RCCL, 256 B, in place on the library's vector) -> identical solve
+    res = sharded_register(ctx, scan_slice_dev, None, iters)
     ctx.map_update(res.pose, None)
     return res
 
@@ -131,15 +128,16 @@ def main():
     ctx.map_set(torch.from_numpy(model).to(dev))
     neq = ctx.normal_equations_tensor() if sharded else None
     if sharded:
-        per = (n_pts + world - 1) // world
-        slices = [s[rank * per:min(n_pts, (rank + 1) * per)].contiguous() for s in scans_dev]
+        from pylidar_slam_amd.distributed import shard_bounds
+        b, e = shard_bounds(n_pts, world, rank)
+        slices = [s[b:e].contiguous() for s in scans_dev]
 
     def run(k, first_frame):
         res = None
         for i in range(k):
             f = order[(first_frame + i) % len(order)]
             if sharded:
-                res = step_sharded(ctx, slices[f], scans_dev[f], vmap, neq, args.iters, dist)
+                res = step_sharded(ctx, slices[f], scans_dev[f], vmap, args.iters)
             else:
                 res = step_replica(ctx, scans_dev[f], vmap)
         return res
