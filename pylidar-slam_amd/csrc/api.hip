@@ -1,6 +1,7 @@
 // C ABI of libicp_mi355x.so: context management, staging, and the orchestration of the kernels in the other
 // translation units.  Signatures and the reference interfaces they replace: include/icp_mi355x.h.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "icp_internal.h"
@@ -241,7 +242,7 @@ void icp_default_config(icp_config* cfg) {
     cfg->local_map_size = 20;            // local_map.py:249
     cfg->num_neighbors_normals = 10;     // :250
     cfg->cell_size = 0.0f;  // <= 0: auto-tuned from the measured map occupancy
-    cfg->max_rings = 4;
+    cfg->max_rings = 3;  // fine rings; beyond that the coarse level (4x cells, 6 rings) takes over
     cfg->device = 0;
     cfg->poll_every = 4;
 }
@@ -259,6 +260,9 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
     icp_ctx* ctx = new icp_ctx();
     ctx->cfg = *cfg;
     ctx->cell_h = cfg->cell_size > 0.f ? cfg->cell_size : 0.5f;
+    if (const char* v = getenv("ICP_SEARCH_VARIANT")) ctx->search_variant = atoi(v);
+    if (const char* v = getenv("ICP_SORT_TARGETS")) ctx->sort_targets = atoi(v);
+    if (const char* v = getenv("ICP_TARGET_OCCUPANCY")) ctx->target_occupancy = atof(v) > 0.1 ? atof(v) : 4.0;
     int rc = ensure_state(ctx);
     if (rc == ICP_OK) rc = init_state(ctx, nullptr);
     if (rc != ICP_OK) {
@@ -278,7 +282,9 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->dx_hist,    &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
                             &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
-                            &ctx->grid_stats};
+                            &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
+                            &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->ctable,
+                            &ctx->csorted,    &ctx->pos_of_orig};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
@@ -524,6 +530,7 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     ctx->tgt_n = n;
     ctx->tgt_mode = ICP_TARGETS_ALL;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, nullptr, 0))) return rc;
     if ((rc = init_state(ctx, nullptr))) return rc;
     if ((rc = launch_search_raw(ctx))) return rc;
     if (neighbor_normals_out && (rc = launch_normals(ctx))) return rc;
@@ -582,6 +589,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, init_pose, ctx->sort_targets))) return rc;
     if ((rc = init_state(ctx, init_pose))) return rc;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)

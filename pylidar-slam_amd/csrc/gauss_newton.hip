@@ -123,7 +123,7 @@ __device__ inline void block_store_partial(RowAcc& acc, double* __restrict__ par
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RED_THREADS) void k_reduce(const float4* __restrict__ map_pts,
                                                         const float4* __restrict__ normals,
-                                                        const float* __restrict__ tgt, const int* __restrict__ nn_pos,
+                                                        const float4* __restrict__ tgt, const int* __restrict__ nn_pos,
                                                         int n, const RegState* __restrict__ st, AlignParams ap,
                                                         double* __restrict__ partials) {
     if (st->done) return;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(const float4* __restrict
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int s = nn_pos[i];
         if (s < 0) continue;
-        const float x = tgt[3 * i + 0], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
+        const float4 t4 = tgt[i];
+        const float x = t4.x, y = t4.y, z = t4.z;
         const float px = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
         const float py = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
         const float pz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
@@ -415,7 +416,7 @@ int launch_reduce(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     const int tok = prof_begin(ctx, 1);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
-                       ctx->normals.as<float4>(), ctx->tgt_ptr, ctx->nn_pos.as<int>(), n, reg_state(ctx),
+                       ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 1, ctx->neq);
@@ -430,7 +431,7 @@ int launch_reduce_solve(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     const int tok = prof_begin(ctx, 1);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
-                       ctx->normals.as<float4>(), ctx->tgt_ptr, ctx->nn_pos.as<int>(), n, reg_state(ctx),
+                       ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),

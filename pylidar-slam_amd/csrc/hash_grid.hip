@@ -186,26 +186,87 @@ __global__ void k_grid_insert(const float* __restrict__ xyz, int m, float inv_h,
     rank_of[i] = atomicAdd(&table[slot].count, 1);
 }
 
-__global__ void k_grid_counts(const GridEntry* __restrict__ table, unsigned int size, int* __restrict__ counts) {
+__global__ void k_grid_counts(const GridEntry* __restrict__ table, unsigned int size, int* __restrict__ counts,
+                              int* __restrict__ flags) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < size) counts[i] = table[i].count;
+    if (i < size) {
+        const int c = table[i].count;
+        counts[i] = c;
+        flags[i] = c > 0 ? 1 : 0;
+    }
 }
 
-__global__ void k_grid_starts(GridEntry* __restrict__ table, unsigned int size, const int* __restrict__ starts) {
+__global__ void k_grid_starts(GridEntry* __restrict__ table, unsigned int size, const int* __restrict__ starts,
+                              const int* __restrict__ flags, const int* __restrict__ cell_ids,
+                              int* __restrict__ row_of_slot, int* __restrict__ slot_of_cell) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    table[i].start = starts[i];
+    const int r = flags[i] ? cell_ids[i] : -1;
+    row_of_slot[i] = r;
+    if (r >= 0) slot_of_cell[r] = (int)i;
+}
+
+__global__ void k_grid_starts_plain(GridEntry* __restrict__ table, unsigned int size, const int* __restrict__ starts) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < size) table[i].start = starts[i];
 }
 
+// rows[cell][c] = (start, count) of the neighbour cell c of every occupied cell (0,0 if that neighbour is empty)
+__global__ void k_build_rows(const GridEntry* __restrict__ table, unsigned int mask,
+                             const int* __restrict__ slot_of_cell, const int* __restrict__ ncells_dev,
+                             int2* __restrict__ rows) {
+    const long long total = (long long)(*ncells_dev) * 27;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(t / 27), c = (int)(t % 27);
+        const GridEntry own = table[slot_of_cell[j]];
+        int2 out = make_int2(0, 0);
+        if (c == 13) {
+            out = make_int2(own.start, own.count);
+        } else {
+            const int cx = (int)(own.key & 0x1FFFFFull) - CELL_OFFSET, cy = (int)((own.key >> 21) & 0x1FFFFFull) - CELL_OFFSET,
+                      cz = (int)((own.key >> 42) & 0x1FFFFFull) - CELL_OFFSET;
+            const unsigned long long key = pack_cell(cx + c % 3 - 1, cy + (c / 3) % 3 - 1, cz + c / 9 - 1);
+            unsigned int slot = hash_cell(key) & mask;
+            while (true) {
+                const GridEntry e = table[slot];
+                if (e.key == key) {
+                    out = make_int2(e.start, e.count);
+                    break;
+                }
+                if (e.key == GRID_EMPTY) break;
+                slot = (slot + 1) & mask;
+            }
+        }
+        rows[(size_t)j * ROW_STRIDE + c] = out;
+        if (c == 26) rows[(size_t)j * ROW_STRIDE + 27] = make_int2(0, 0);  // padding entry
+    }
+}
+
 __global__ void k_grid_scatter(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
                                const int* __restrict__ slot_of, const int* __restrict__ rank_of,
-                               float4* __restrict__ sorted, float4* __restrict__ normals, int* __restrict__ nflag) {
+                               const int* __restrict__ row_of_slot, float4* __restrict__ sorted,
+                               float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
+                               int* __restrict__ pos_of_orig) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const int pos = table[slot_of[i]].start + rank_of[i];
+    row_of_pos[pos] = row_of_slot[slot_of[i]];
+    pos_of_orig[i] = pos;
     sorted[pos] = make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
     // the normal cache is cleared on every rebuild (local_map.py:368)
     normals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     nflag[i] = 0;
+}
+
+__global__ void k_grid_scatter_plain(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
+                                     const int* __restrict__ slot_of, const int* __restrict__ rank_of,
+                                     float4* __restrict__ sorted) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    sorted[table[slot_of[i]].start + rank_of[i]] =
+        make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
 static unsigned int next_pow2(unsigned int v) {
@@ -231,16 +292,23 @@ int build_grid(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->rank_of.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->worklist.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->scan_b.reserve((size_t)tsize * sizeof(int)));
+    ICP_HIP(ctx, ctx->cell_flags.reserve((size_t)tsize * sizeof(int)));
+    ICP_HIP(ctx, ctx->cell_ids.reserve((size_t)tsize * sizeof(int)));
+    ICP_HIP(ctx, ctx->row_of_slot.reserve((size_t)tsize * sizeof(int)));
+    ICP_HIP(ctx, ctx->slot_of_cell.reserve((size_t)m * sizeof(int)));
+    ICP_HIP(ctx, ctx->row_of_pos.reserve((size_t)m * sizeof(int)));
+    ICP_HIP(ctx, ctx->pos_of_orig.reserve((size_t)m * sizeof(int)));
+    ICP_HIP(ctx, ctx->rows.reserve((size_t)m * ROW_STRIDE * sizeof(int2)));  // worst case: one cell per point
     ctx->table_size = tsize;
     GridEntry* table = ctx->table.as<GridEntry>();
     const float* xyz = ctx->map_xyz[ctx->map_cur].as<float>();
-    // cell edge: fixed by the configuration, or auto-tuned towards ~6 map points per occupied cell from the occupancy
+    // cell edge: fixed by the configuration, or auto-tuned towards ~4 map points per occupied cell from the occupancy
     // measured on the previous build (surface-like scaling: points per cell ~ h^2)
     if (ctx->cfg.cell_size > 0.f) {
         ctx->cell_h = ctx->cfg.cell_size;
     } else if (ctx->occupied_cells > 0 && ctx->stats_m > 0) {
         const double mean = (double)ctx->stats_m / (double)ctx->occupied_cells;
-        double f = sqrt(6.0 / mean);
+        double f = sqrt(ctx->target_occupancy / mean);
         if (f < 0.5) f = 0.5;
         if (f > 2.0) f = 2.0;
         if (f < 0.85 || f > 1.18) ctx->cell_h = (float)fmin(fmax(ctx->cell_h * f, 0.05), 8.0);
@@ -256,13 +324,43 @@ int build_grid(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_grid_insert, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, table, tsize - 1,
                        ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->grid_stats.as<int>());
     int* counts = ctx->scan_b.as<int>();
-    hipLaunchKernelGGL(k_grid_counts, dim3(tb), dim3(256), 0, ctx->stream, table, tsize, counts);
+    int* flags = ctx->cell_flags.as<int>();
+    int* cell_ids = ctx->cell_ids.as<int>();
+    int* ncells_dev = ctx->grid_stats.as<int>() + 1;
+    hipLaunchKernelGGL(k_grid_counts, dim3(tb), dim3(256), 0, ctx->stream, table, tsize, counts, flags);
     int rc = exclusive_scan_i32(ctx, counts, counts, tsize, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_starts, dim3(tb), dim3(256), 0, ctx->stream, table, tsize, counts);
+    if ((rc = exclusive_scan_i32(ctx, flags, cell_ids, tsize, ncells_dev))) return rc;
+    hipLaunchKernelGGL(k_grid_starts, dim3(tb), dim3(256), 0, ctx->stream, table, tsize, counts, flags, cell_ids,
+                       ctx->row_of_slot.as<int>(), ctx->slot_of_cell.as<int>());
+    {
+        long long want = ((long long)m * 27 + 255) / 256;
+        const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
+        hipLaunchKernelGGL(k_build_rows, dim3(rb), dim3(256), 0, ctx->stream, table, tsize - 1,
+                           ctx->slot_of_cell.as<int>(), ncells_dev, ctx->rows.as<int2>());
+    }
     hipLaunchKernelGGL(k_grid_scatter, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, table,
-                       ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->sorted_pts.as<float4>(),
-                       ctx->normals.as<float4>(), ctx->nflag.as<int>());
+                       ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->row_of_slot.as<int>(),
+                       ctx->sorted_pts.as<float4>(), ctx->normals.as<float4>(), ctx->nflag.as<int>(),
+                       ctx->row_of_pos.as<int>(), ctx->pos_of_orig.as<int>());
+    // ---- coarse level: the same counting sort with cells COARSE_FACTOR times larger (table sized for fewer cells)
+    {
+        const unsigned int csize = tsize;  // worst case (every point in its own coarse cell) must still fit
+        ICP_HIP(ctx, ctx->ctable.reserve((size_t)csize * sizeof(GridEntry)));
+        ICP_HIP(ctx, ctx->csorted.reserve((size_t)m * sizeof(float4)));
+        ctx->ctable_size = csize;
+        GridEntry* ctable = ctx->ctable.as<GridEntry>();
+        const unsigned cb = (csize + 255) / 256;
+        hipLaunchKernelGGL(k_grid_clear, dim3(cb), dim3(256), 0, ctx->stream, ctable, csize);
+        hipLaunchKernelGGL(k_grid_insert, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h / COARSE_FACTOR,
+                           ctable, csize - 1, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(),
+                           ctx->grid_stats.as<int>() + 2);
+        hipLaunchKernelGGL(k_grid_counts, dim3(cb), dim3(256), 0, ctx->stream, ctable, csize, counts, flags);
+        if ((rc = exclusive_scan_i32(ctx, counts, counts, csize, nullptr))) return rc;
+        hipLaunchKernelGGL(k_grid_starts_plain, dim3(cb), dim3(256), 0, ctx->stream, ctable, csize, counts);
+        hipLaunchKernelGGL(k_grid_scatter_plain, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, ctable,
+                           ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->csorted.as<float4>());
+    }
     ICP_HIP(ctx, hipGetLastError());
     ctx->grid_valid = true;
     return ICP_OK;

@@ -28,7 +28,22 @@ struct GridView {
     float inv_h;
     const float4* pts;   // cell-sorted map points: (x, y, z, bits(original index))
     int m;               // number of map points
+    // neighbour rows: for every occupied cell the (start, count) of its 27-neighbourhood (index = (oz+1)*9+(oy+1)*3+
+    // (ox+1), own cell at 13), so that a query in an occupied cell needs ONE hash probe instead of 27
+    const int* row_of_slot;  // table slot -> row (-1 if the slot is free)
+    const int2* rows;        // [cells][ROW_STRIDE]
+    const int* row_of_pos;   // cell-sorted point position -> row of its cell
+    // coarse level (cell edge COARSE_FACTOR * h, hashed, own cell-sorted copy of the points): takes over when a query is
+    // farther than `max_rings` fine cells from the map, so that the exhaustive scan stays a last resort
+    const GridEntry* ctable;
+    unsigned int cmask;
+    float ch, cinv_h;
+    const float4* cpts;
+    const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
 };
+static constexpr float COARSE_FACTOR = 4.0f;
+static constexpr int COARSE_RINGS = 6;
+static constexpr int ROW_STRIDE = 28;  // 27 cells + 1 pad: rows are 224 B, 16-byte aligned
 
 __host__ __device__ inline unsigned long long pack_cell(int cx, int cy, int cz) {
     return ((unsigned long long)((unsigned)(cx + CELL_OFFSET) & 0x1FFFFFu)) |
@@ -117,14 +132,20 @@ struct icp_ctx {
     icp::DeviceBuffer normals;         // float4[M] (by cell-sorted position)
     icp::DeviceBuffer nflag;           // int[M]: 0 none, 2 queued, 1 ready
     icp::DeviceBuffer slot_of, rank_of;  // int[M] temporaries of the build
+    icp::DeviceBuffer row_of_slot, slot_of_cell, rows, row_of_pos, cell_flags, cell_ids;
+    icp::DeviceBuffer ctable, csorted, pos_of_orig;  // coarse level
+    unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
     icp::DeviceBuffer worklist;        // int[M]
     bool grid_valid = false;
+    int search_variant = 2;            // 0: per-lane ring search, 1: wave tiles in LDS, 2: neighbour rows + 4 lanes per
+                                       // query (default); env ICP_SEARCH_VARIANT — all three give identical results
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
     int64_t normals_eager_count = 0;
     float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
     icp::DeviceBuffer grid_stats;      // int[4]: occupied cells of the last build
     int occupied_cells = 0;
+    double target_occupancy = 5.0;     // auto-tuning target, map points per occupied cell (env ICP_TARGET_OCCUPANCY)
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
@@ -134,6 +155,9 @@ struct icp_ctx {
     int64_t tgt_n = 0;
     int tgt_mode = 0;
     icp::DeviceBuffer nn_pos;          // int[N]
+    icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
+    icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row
+    int sort_targets = 0;              // Morton-sort the targets of a registration (env ICP_SORT_TARGETS)
     icp::DeviceBuffer partials;        // double[blocks][NEQ]
     icp::DeviceBuffer state;           // RegState + histories
     icp::DeviceBuffer loss_hist;       // double[max_iters]
@@ -188,6 +212,8 @@ int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* 
 // ---- grid_sample.hip
 int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                       long long* hashes_dev);
+// targets -> float4 rows in ctx->tgt4; sorted along a Morton curve of the map's cells under `pose` when sort != 0
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const float* pose16_host, int sort);
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
                        float* points_dev, int* count_dev);
 

@@ -10,64 +10,238 @@
 // Queries that exhaust `max_rings` fall back to an exhaustive scan, so the result is the exact NN for every input.
 // Distance ties are broken on the smaller original map index (the kd-tree's tie order is unspecified).
 #include "icp_internal.h"
+#include "search_device.h"
 
 namespace icp {
 
-struct Best {
-    float d2;
-    int idx;  // original index (tie-break)
-    int pos;  // cell-sorted position
+// ---------------------------------------------------------------------------------------------------------------------
+// K1: transform + exact 1-NN; queue the hit map points that have no normal yet
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_search(GridView g, const float4* __restrict__ tgt, int n, int mode,
+                                                int transform, RegState* __restrict__ st, int max_rings,
+                                                int* __restrict__ nn_pos, int* __restrict__ nflag,
+                                                int* __restrict__ worklist, int queue_normals) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 t4 = tgt[i];
+    const float x = t4.x, y = t4.y, z = t4.z;
+    if (!target_valid(x, y, z, mode)) {
+        nn_pos[i] = -1;
+        return;
+    }
+    float px = x, py = y, pz = z;
+    if (transform) transform_point(st->pose, x, y, z, px, py, pz);
+    const Best b = nearest_in_grid(g, px, py, pz, max_rings);
+    nn_pos[i] = b.pos;
+    if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
+        if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K1 (tiled): the same exact search, with the candidate cells of each WAVE staged in LDS.
+//
+// 64 consecutive scan points are spatially adjacent (ring-major order), so their 27-cell neighbourhoods overlap almost
+// completely.  Per wave: (1) cell box of its 64 queries dilated by one cell; (2) the lanes probe the hash table for the
+// cells of that box IN PARALLEL (independent probes instead of 27 dependent ones per lane) and copy the found cells'
+// points into an LDS tile; (3) every lane walks its own 27 cells through a dense LDS cell index, pruning by box
+// distance, reading candidates from LDS.  A lane whose best is not provably exact after ring 1 (or a wave whose box or
+// tile does not fit) falls back to the per-lane global search above, so results are identical to `k_search`.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int WS_CELLS = 512;   // cells of a wave's dilated box
+static constexpr int WS_POINTS = 768;  // map points staged per wave
+
+struct WaveTile {
+    float4 pts[WS_POINTS];
+    unsigned seg[WS_CELLS];  // (tile offset << 16) | count, 0 = empty cell
+    int gstart[WS_CELLS];    // cell start in the global cell-sorted array (to report positions)
 };
 
-__device__ inline bool better(float d2, int idx, float bd2, int bidx) { return d2 < bd2 || (d2 == bd2 && idx < bidx); }
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
-__device__ inline bool grid_lookup(const GridView& g, int cx, int cy, int cz, int& start, int& count) {
-    const unsigned long long key = pack_cell(cx, cy, cz);
-    unsigned int slot = hash_cell(key) & g.mask;
-    while (true) {
-        const GridEntry e = g.table[slot];
-        if (e.key == key) {
-            start = e.start;
-            count = e.count;
-            return true;
+__device__ inline void scan_tile_cell(const WaveTile& T, unsigned packed, int gstart, float px, float py, float pz,
+                                      Best& b) {
+    const int off = (int)(packed >> 16), count = (int)(packed & 0xffffu);
+    const int last = count - 1;
+    for (int k = 0; k <= last; k += 2) {
+        const int k1 = min(k + 1, last);
+        const float4 q0 = T.pts[off + k], q1 = T.pts[off + k1];
+        consider(q0, gstart + k, px, py, pz, b);
+        consider(q1, gstart + k1, px, py, pz, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_search_tiled(GridView g, const float4* __restrict__ tgt, int n, int mode,
+                                                      int transform, RegState* __restrict__ st, int max_rings,
+                                                      int* __restrict__ nn_pos, int* __restrict__ nflag,
+                                                      int* __restrict__ worklist, int queue_normals) {
+    __shared__ WaveTile tiles[4];
+    __shared__ int cursor[4];
+    __shared__ int overflow[4];
+    if (st->done) return;  // block-uniform
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    WaveTile& T = tiles[w];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = i < n;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+        const float4 t4 = tgt[i];
+        const float x = t4.x, y = t4.y, z = t4.z;
+        valid = target_valid(x, y, z, mode);
+        px = x;
+        py = y;
+        pz = z;
+        if (valid && transform) transform_point(st->pose, x, y, z, px, py, pz);
+    }
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const int BIG = 0x3fffffff;
+    const int mnx = wave_min_i(valid ? cx : BIG), mny = wave_min_i(valid ? cy : BIG), mnz = wave_min_i(valid ? cz : BIG);
+    const int mxx = wave_max_i(valid ? cx : -BIG), mxy = wave_max_i(valid ? cy : -BIG),
+              mxz = wave_max_i(valid ? cz : -BIG);
+    const bool any_valid = mnx != BIG;
+    const long long X = (long long)mxx - mnx + 3, Y = (long long)mxy - mny + 3, Z = (long long)mxz - mnz + 3;
+    const bool tiled = any_valid && X <= WS_CELLS && Y <= WS_CELLS && Z <= WS_CELLS && X * Y * Z <= WS_CELLS;
+    if (lane == 0) {
+        cursor[w] = 0;
+        overflow[w] = 0;
+    }
+    __syncthreads();
+    const int iX = (int)X, iY = (int)Y;
+    if (tiled) {
+        const int ncells = (int)(X * Y * Z);
+        for (int c = lane; c < ncells; c += 64) {
+            const int ix = c % iX, iy = (c / iX) % iY, iz = c / (iX * iY);
+            int start, count;
+            unsigned packed = 0;
+            int gs = 0;
+            if (grid_lookup(g, mnx - 1 + ix, mny - 1 + iy, mnz - 1 + iz, start, count)) {
+                const int off = atomicAdd(&cursor[w], count);
+                if (off + count <= WS_POINTS) {
+                    packed = ((unsigned)off << 16) | (unsigned)count;
+                    gs = start;
+                    for (int k = 0; k < count; ++k) T.pts[off + k] = g.pts[start + k];
+                } else {
+                    overflow[w] = 1;
+                }
+            }
+            T.seg[c] = packed;
+            T.gstart[c] = gs;
         }
-        if (e.key == GRID_EMPTY) return false;
-        slot = (slot + 1) & g.mask;
+    }
+    __syncthreads();
+    if (!valid) {
+        if (i < n) nn_pos[i] = -1;
+        return;
+    }
+    Best b;
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    bool resolved = false;
+    if (tiled && !overflow[w]) {
+        const float h = g.h;
+        const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+        const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+        const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+        const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+        const int lx = cx - (mnx - 1), ly = cy - (mny - 1), lz = cz - (mnz - 1);
+        const int c0 = (lz * iY + ly) * iX + lx;
+        unsigned packed = T.seg[c0];
+        if (packed) scan_tile_cell(T, packed, T.gstart[c0], px, py, pz, b);
+#pragma unroll
+        for (int oz = -1; oz <= 1; ++oz) {
+            const float gz = axis_gap(oz, fz, h);
+            const float gz2 = gz * gz;
+            if (gz2 > b.d2) continue;
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy) {
+                const float gy = axis_gap(oy, fy, h);
+                const float gyz2 = fmaf(gy, gy, gz2);
+                if (gyz2 > b.d2) continue;
+#pragma unroll
+                for (int ox = -1; ox <= 1; ++ox) {
+                    if (ox == 0 && oy == 0 && oz == 0) continue;
+                    const float gx = axis_gap(ox, fx, h);
+                    if (fmaf(gx, gx, gyz2) > b.d2) continue;
+                    const int c = c0 + (oz * iY + oy) * iX + ox;
+                    packed = T.seg[c];
+                    if (packed) scan_tile_cell(T, packed, T.gstart[c], px, py, pz, b);
+                }
+            }
+        }
+        const float bound = h + edge;
+        resolved = b.d2 <= bound * bound * 0.999999f;
+    }
+    if (!resolved) b = nearest_in_grid(g, px, py, pz, max_rings);
+    nn_pos[i] = b.pos;
+    if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
+        if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
     }
 }
 
-// squared distance from the query (offset f inside its own cell, per axis) to the box of the cell at offset o
-__device__ inline float axis_gap(int o, float f, float h) {
-    if (o == 0) return 0.f;
-    return o < 0 ? f + (float)(-o - 1) * h : (h - f) + (float)(o - 1) * h;
-}
-
-__device__ inline void consider(const float4 q, int pos, float px, float py, float pz, Best& b) {
-    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    const int idx = __float_as_int(q.w);
-    if (better(d2, idx, b.d2, b.idx)) {
-        b.d2 = d2;
-        b.idx = idx;
-        b.pos = pos;
+// ---------------------------------------------------------------------------------------------------------------------
+// K1 (rows, 4 lanes per query) — the default.
+//
+// What the hardware counters said about `k_search` (tools/pmc_probe.sh): L1 hit rate > 90 %, HBM traffic = the
+// compulsory bytes, yet 160 dependent load instructions and ~3000 VALU instructions per wave: the 27-cell loop runs
+// once per cell for the union of the lanes, each pass = hash + dependent probe + dependent candidate rounds.  So:
+//   * one hash probe per query (its own cell); the 27 neighbour (start, count) pairs come from the cell's ROW
+//     (contiguous, loaded in one round, no hashing);
+//   * FOUR lanes per query: own-cell candidates strided over the lanes, the 26 neighbours split 7/6/7/6, two
+//     shuffle min-reductions.  4x the waves in flight (32 per CU instead of 8) and a 4x shorter dependent chain.
+// A query whose own cell is empty (no row) splits the 26 hashed probes over its 4 lanes instead.  Anything not provably
+// exact after ring 1 goes to the per-lane ring search, so results equal `k_search` bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline void group_min4(Best& b) {
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+        const float d2 = __shfl_xor(b.d2, o, 64);
+        const int idx = __shfl_xor(b.idx, o, 64);
+        const int pos = __shfl_xor(b.pos, o, 64);
+        if (better(d2, idx, b.d2, b.idx)) {
+            b.d2 = d2;
+            b.idx = idx;
+            b.pos = pos;
+        }
     }
 }
 
-// candidates are fetched four at a time (independent 16-byte loads in flight together); the tail re-reads the last
-// point of the cell, which cannot change the (d2, index) minimum
-__device__ inline void scan_cell_1nn(const GridView& g, int start, int count, float px, float py, float pz, Best& b) {
+__device__ inline void scan_strided4(const GridView& g, int start, int count, int sub, float px, float py, float pz,
+                                     Best& b) {
     const int last = start + count - 1;
-    for (int k = start; k <= last; k += 4) {
-        const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
-        const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+    for (int k = start + sub; k <= last; k += 8) {
+        const int k1 = min(k + 4, last);
+        const float4 q0 = g.pts[k], q1 = g.pts[k1];
         consider(q0, k, px, py, pz, b);
         consider(q1, k1, px, py, pz, b);
-        consider(q2, k2, px, py, pz, b);
-        consider(q3, k3, px, py, pz, b);
     }
 }
 
-__device__ inline Best nearest_in_grid(const GridView& g, float px, float py, float pz, int max_rings) {
+__global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* __restrict__ tgt, int n, int mode,
+                                                     int transform, RegState* __restrict__ st, int max_rings,
+                                                     int* __restrict__ nn_pos, int* __restrict__ nflag,
+                                                     int* __restrict__ worklist, int queue_normals) {
+    if (st->done) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = gid >> 2, sub = gid & 3;
+    if (qi >= n) return;  // group-uniform
+    const float4 t4 = tgt[qi];
+    if (!target_valid(t4.x, t4.y, t4.z, mode)) {  // group-uniform
+        if (sub == 0) nn_pos[qi] = -1;
+        return;
+    }
+    float px = t4.x, py = t4.y, pz = t4.z;
+    if (transform) transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
     Best b;
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
@@ -78,74 +252,69 @@ __device__ inline Best nearest_in_grid(const GridView& g, float px, float py, fl
     const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-    int start, count;
-    if (grid_lookup(g, cx, cy, cz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
-    for (int r = 1; r <= max_rings; ++r) {
-        for (int oz = -r; oz <= r; ++oz) {
-            const float gz = axis_gap(oz, fz, h);
-            const float gz2 = gz * gz;
-            if (gz2 > b.d2) continue;
-            const int az = oz < 0 ? -oz : oz;
-            for (int oy = -r; oy <= r; ++oy) {
-                const float gy = axis_gap(oy, fy, h);
-                const float gyz2 = fmaf(gy, gy, gz2);
-                if (gyz2 > b.d2) continue;
-                const int ay = oy < 0 ? -oy : oy;
-                const bool shell_yz = (az == r) || (ay == r);
-                // on the shell in y/z every x is visited, otherwise only x = -r and x = +r
-                const int step = shell_yz ? 1 : 2 * r;
-                for (int ox = -r; ox <= r; ox += step) {
-                    const float gx = axis_gap(ox, fx, h);
-                    if (fmaf(gx, gx, gyz2) > b.d2) continue;
-                    if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
-                        scan_cell_1nn(g, start, count, px, py, pz, b);
-                }
-            }
+    // own cell: entry and row id of the first slot are fetched together (a first-probe hit is the common case)
+    const unsigned long long key = pack_cell(cx, cy, cz);
+    unsigned int slot = hash_cell(key) & g.mask;
+    GridEntry e = g.table[slot];
+    int row = g.row_of_slot[slot];
+    if (e.key != key && e.key != GRID_EMPTY) {
+        while (true) {
+            slot = (slot + 1) & g.mask;
+            e = g.table[slot];
+            if (e.key == key || e.key == GRID_EMPTY) break;
         }
-        const float bound = (float)r * h + edge;
-        if (b.d2 <= bound * bound * 0.999999f) return b;
+        row = g.row_of_slot[slot];
     }
-    // exhaustive fallback: keeps the search exact for queries farther than max_rings cells from the map
-    b.d2 = INFINITY;
-    b.idx = 0x7fffffff;
-    b.pos = -1;
-    scan_cell_1nn(g, 0, g.m, px, py, pz, b);
-    return b;
-}
-
-__device__ inline bool target_valid(float x, float y, float z, int mode) {
-    if (!(x == x) || !(y == y) || !(z == z)) return false;  // remove_nan, icp_odometry.py:357
-    if (mode == ICP_TARGETS_SKIP_NULL && x == 0.f && y == 0.f && z == 0.f) return false;  // :303-305
-    return true;
-}
-
-// p' = p R^T + t  (Pose.apply_transformation, slam/common/pose.py:169-186)
-__device__ inline void transform_point(const float* __restrict__ T, float x, float y, float z, float& px, float& py,
-                                       float& pz) {
-    px = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
-    py = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
-    pz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K1: transform + exact 1-NN; queue the hit map points that have no normal yet
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_search(GridView g, const float* __restrict__ tgt, int n, int mode,
-                                                int transform, RegState* __restrict__ st, int max_rings,
-                                                int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                int* __restrict__ worklist, int queue_normals) {
-    if (st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = tgt[3 * i + 0], y = tgt[3 * i + 1], z = tgt[3 * i + 2];
-    if (!target_valid(x, y, z, mode)) {
-        nn_pos[i] = -1;
-        return;
+    if (e.key == key) {
+        // ---- row path
+        const int2* __restrict__ r = g.rows + (size_t)row * ROW_STRIDE;
+        int2 cell[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];  // entry 27 is padding (0, 0)
+        scan_strided4(g, e.start, e.count, sub, px, py, pz, b);
+        group_min4(b);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int c = sub * 7 + k;
+            if (c == 13 || c >= 27 || cell[k].y <= 0) continue;  // own cell done above; entry 27 is padding
+            const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                        gz = axis_gap(c / 9 - 1, fz, h);
+            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+            scan_cell_1nn(g, cell[k].x, cell[k].y, px, py, pz, b);
+        }
+        group_min4(b);
+    } else {
+        // ---- own cell empty: hashed probes of the 26 neighbours, split over the 4 lanes
+        for (int c0 = sub; c0 < 26; c0 += 4) {
+            const int c = c0 + (c0 >= 13 ? 1 : 0);
+            const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
+            const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+            int start, count;
+            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
+        }
+        group_min4(b);
     }
-    float px = x, py = y, pz = z;
-    if (transform) transform_point(st->pose, x, y, z, px, py, pz);
-    const Best b = nearest_in_grid(g, px, py, pz, max_rings);
-    nn_pos[i] = b.pos;
+    float bound = h + edge;
+    bool resolved = b.d2 <= bound * bound * 0.999999f;  // group-uniform: b is shared after the reduction
+    if (!resolved && max_rings >= 2) {
+        // ring 2 (the 98 cells of the 5x5x5 shell), hashed probes split over the 4 lanes, pruned by box distance
+        for (int c = sub; c < 125; c += 4) {
+            const int ox = c % 5 - 2, oy = (c / 5) % 5 - 2, oz = c / 25 - 2;
+            const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+            if (m < 2) continue;
+            const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+            int start, count;
+            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
+        }
+        group_min4(b);
+        bound = 2.0f * h + edge;
+        resolved = b.d2 <= bound * bound * 0.999999f;
+    }
+    if (sub != 0) return;
+    if (!resolved) b = nearest_in_grid(g, px, py, pz, max_rings);
+    nn_pos[qi] = b.pos;
     if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
         if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
     }
@@ -248,48 +417,8 @@ __device__ inline void smallest_eigenvector(double a00, double a01, double a02, 
 }
 
 template <int KN>
-__device__ inline void estimate_normal(const GridView& g, int s, int max_rings, float4* __restrict__ normals,
-                                       int* __restrict__ nflag) {
-    const float4 P = g.pts[s];
-    const float px = P.x, py = P.y, pz = P.z;
-    TopK<KN> t;
-    t.init();
-    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
-    const float h = g.h;
-    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
-    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
-    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
-    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-    int start, count;
-    if (grid_lookup(g, cx, cy, cz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
-    bool exact = false;
-    for (int r = 1; r <= max_rings && !exact; ++r) {
-        for (int oz = -r; oz <= r; ++oz) {
-            const float gz = axis_gap(oz, fz, h);
-            const float gz2 = gz * gz;
-            if (gz2 > t.d2[KN - 1]) continue;
-            const int az = oz < 0 ? -oz : oz;
-            for (int oy = -r; oy <= r; ++oy) {
-                const float gy = axis_gap(oy, fy, h);
-                const float gyz2 = fmaf(gy, gy, gz2);
-                if (gyz2 > t.d2[KN - 1]) continue;
-                const int ay = oy < 0 ? -oy : oy;
-                const int step = ((az == r) || (ay == r)) ? 1 : 2 * r;
-                for (int ox = -r; ox <= r; ox += step) {
-                    const float gx = axis_gap(ox, fx, h);
-                    if (fmaf(gx, gx, gyz2) > t.d2[KN - 1]) continue;
-                    if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
-                        scan_cell_knn<KN>(g, start, count, px, py, pz, t);
-                }
-            }
-        }
-        const float bound = (float)r * h + edge;
-        exact = t.d2[KN - 1] <= bound * bound * 0.999999f;
-    }
-    if (!exact) {
-        t.init();
-        scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
-    }
+__device__ inline void finish_normal(const GridView& g, int s, float px, float py, float pz, const TopK<KN>& t,
+                                     float4* __restrict__ normals, int* __restrict__ nflag) {
     // covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32
     float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     int used = 0;
@@ -312,6 +441,97 @@ __device__ inline void estimate_normal(const GridView& g, int s, int max_rings, 
                          (double)(c12 * invk), (double)(c22 * invk), nx, ny, nz);
     normals[s] = make_float4(nx, ny, nz, 1.f);
     nflag[s] = 1;
+}
+
+// hashed ring search on one level from ring `first_ring` on (rings below it were already visited by the caller);
+// true when the k-th neighbour is provably exact
+template <int KN>
+__device__ inline bool knn_level(const GridView& g, float px, float py, float pz, int first_ring, int max_rings,
+                                 bool translate, TopK<KN>& t) {
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float h = g.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    int start, count;
+    if (first_ring == 0 && grid_lookup(g, cx, cy, cz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+    bool exact = false;
+    for (int r = first_ring < 1 ? 1 : first_ring; r <= max_rings && !exact; ++r) {
+        for (int oz = -r; oz <= r; ++oz) {
+            const float gz = axis_gap(oz, fz, h);
+            const float gz2 = gz * gz;
+            if (gz2 > t.d2[KN - 1]) continue;
+            const int az = oz < 0 ? -oz : oz;
+            for (int oy = -r; oy <= r; ++oy) {
+                const float gy = axis_gap(oy, fy, h);
+                const float gyz2 = fmaf(gy, gy, gz2);
+                if (gyz2 > t.d2[KN - 1]) continue;
+                const int ay = oy < 0 ? -oy : oy;
+                const int step = ((az == r) || (ay == r)) ? 1 : 2 * r;
+                for (int ox = -r; ox <= r; ox += step) {
+                    const float gx = axis_gap(ox, fx, h);
+                    if (fmaf(gx, gx, gyz2) > t.d2[KN - 1]) continue;
+                    if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
+                        scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+                }
+            }
+        }
+        const float bound = (float)r * h + edge;
+        exact = t.d2[KN - 1] <= bound * bound * 0.999999f;
+    }
+    if (translate) {  // coarse positions -> fine positions
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (t.pos[k] >= 0) t.pos[k] = g.pos_of_orig[t.idx[k]];
+    }
+    return exact;
+}
+
+// continuation after the fine ring 1 (rows): fine ring 2.., then the coarse level, then the exhaustive scan
+template <int KN>
+__device__ inline void knn_rings(const GridView& g, float px, float py, float pz, int first_ring, int max_rings,
+                                 TopK<KN>& t) {
+    if (knn_level<KN>(g, px, py, pz, first_ring, max_rings, false, t)) return;
+    if (g.ctable) {
+        t.init();
+        if (knn_level<KN>(coarse_view(g), px, py, pz, 0, COARSE_RINGS, true, t)) return;
+    }
+    t.init();
+    scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
+}
+
+// a map point always lies in an occupied cell: its 27-neighbourhood comes from the cell's row (no hashing), further
+// rings — only if the k-th neighbour is not provably inside ring 1 — from the hashed search
+template <int KN>
+__device__ inline void estimate_normal(const GridView& g, int s, int max_rings, float4* __restrict__ normals,
+                                       int* __restrict__ nflag) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    TopK<KN> t;
+    t.init();
+    const float h = g.h;
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const int2* __restrict__ r = g.rows + (size_t)g.row_of_pos[s] * ROW_STRIDE;
+    int2 cell[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) cell[c] = r[c];
+    scan_cell_knn<KN>(g, cell[13].x, cell[13].y, px, py, pz, t);
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        if (c == 13 || cell[c].y <= 0) continue;
+        const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                    gz = axis_gap(c / 9 - 1, fz, h);
+        if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.d2[KN - 1]) continue;
+        scan_cell_knn<KN>(g, cell[c].x, cell[c].y, px, py, pz, t);
+    }
+    const float bound = h + edge;
+    if (!(t.d2[KN - 1] <= bound * bound * 0.999999f)) knn_rings<KN>(g, px, py, pz, 2, max_rings, t);
+    finish_normal<KN>(g, s, px, py, pz, t, normals, nflag);
 }
 
 // lazy: the map points queued by the search of this iteration
@@ -429,6 +649,15 @@ static GridView make_view(icp_ctx* ctx) {
     g.inv_h = 1.0f / ctx->cell_h;
     g.pts = ctx->sorted_pts.as<float4>();
     g.m = (int)ctx->map_m;
+    g.row_of_slot = ctx->row_of_slot.as<int>();
+    g.rows = ctx->rows.as<int2>();
+    g.row_of_pos = ctx->row_of_pos.as<int>();
+    g.ctable = ctx->ctable.as<GridEntry>();
+    g.cmask = ctx->ctable_size ? ctx->ctable_size - 1 : 0;
+    g.ch = ctx->cell_h * COARSE_FACTOR;
+    g.cinv_h = 1.0f / g.ch;
+    g.cpts = ctx->csorted.as<float4>();
+    g.pos_of_orig = ctx->pos_of_orig.as<int>();
     return g;
 }
 
@@ -436,9 +665,20 @@ int launch_search(icp_ctx* ctx) {
     const int n = (int)ctx->tgt_n;
     if (n <= 0) return ICP_OK;
     const int tok = prof_begin(ctx, 0);
-    hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt_ptr, n,
-                       ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                       ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
+    if (ctx->search_variant == 0)
+        hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
+                           ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
+                           ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
+    else if (ctx->search_variant == 1)
+        hipLaunchKernelGGL(k_search_tiled, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx),
+                           ctx->tgt4.as<float4>(), n, ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings,
+                           ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
+                           ctx->normals_ready ? 0 : 1);
+    else
+        hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           make_view(ctx), ctx->tgt4.as<float4>(), n, ctx->tgt_mode, 1, reg_state(ctx),
+                           ctx->cfg.max_rings, ctx->nn_pos.as<int>(), ctx->nflag.as<int>(),
+                           ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -503,9 +743,20 @@ int launch_normals(icp_ctx* ctx) {
 int launch_search_raw(icp_ctx* ctx) {
     const int n = (int)ctx->tgt_n;
     if (n <= 0) return ICP_OK;
-    hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt_ptr, n,
-                       ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                       ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
+    if (ctx->search_variant == 0)
+        hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
+                           ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
+                           ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
+    else if (ctx->search_variant == 1)
+        hipLaunchKernelGGL(k_search_tiled, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx),
+                           ctx->tgt4.as<float4>(), n, ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings,
+                           ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
+                           ctx->normals_ready ? 0 : 1);
+    else
+        hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           make_view(ctx), ctx->tgt4.as<float4>(), n, ICP_TARGETS_ALL, 0, reg_state(ctx),
+                           ctx->cfg.max_rings, ctx->nn_pos.as<int>(), ctx->nflag.as<int>(),
+                           ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -1,0 +1,146 @@
+// Device-side building blocks of the exact voxel-hash nearest-neighbour search (shared by search.hip and tools/).
+#pragma once
+#include "icp_internal.h"
+
+namespace icp {
+
+struct Best {
+    float d2;
+    int idx;  // original index (tie-break)
+    int pos;  // cell-sorted position
+};
+
+__device__ inline bool better(float d2, int idx, float bd2, int bidx) { return d2 < bd2 || (d2 == bd2 && idx < bidx); }
+
+__device__ inline bool grid_lookup(const GridView& g, int cx, int cy, int cz, int& start, int& count) {
+    const unsigned long long key = pack_cell(cx, cy, cz);
+    unsigned int slot = hash_cell(key) & g.mask;
+    while (true) {
+        const GridEntry e = g.table[slot];
+        if (e.key == key) {
+            start = e.start;
+            count = e.count;
+            return true;
+        }
+        if (e.key == GRID_EMPTY) return false;
+        slot = (slot + 1) & g.mask;
+    }
+}
+
+// squared distance from the query (offset f inside its own cell, per axis) to the box of the cell at offset o
+__device__ inline float axis_gap(int o, float f, float h) {
+    if (o == 0) return 0.f;
+    return o < 0 ? f + (float)(-o - 1) * h : (h - f) + (float)(o - 1) * h;
+}
+
+__device__ inline void consider(const float4 q, int pos, float px, float py, float pz, Best& b) {
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const int idx = __float_as_int(q.w);
+    if (better(d2, idx, b.d2, b.idx)) {
+        b.d2 = d2;
+        b.idx = idx;
+        b.pos = pos;
+    }
+}
+
+// candidates are fetched four at a time (independent 16-byte loads in flight together); the tail re-reads the last
+// point of the cell, which cannot change the (d2, index) minimum
+__device__ inline void scan_cell_1nn(const GridView& g, int start, int count, float px, float py, float pz, Best& b) {
+    const int last = start + count - 1;
+    for (int k = start; k <= last; k += 4) {
+        const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+        const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+        consider(q0, k, px, py, pz, b);
+        consider(q1, k1, px, py, pz, b);
+        consider(q2, k2, px, py, pz, b);
+        consider(q3, k3, px, py, pz, b);
+    }
+}
+
+// ring search on ONE level; returns true when the result is provably exact within `max_rings`
+__device__ inline bool nearest_in_level(const GridView& g, float px, float py, float pz, int max_rings, Best& b) {
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float h = g.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    int start, count;
+    if (grid_lookup(g, cx, cy, cz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
+    for (int r = 1; r <= max_rings; ++r) {
+        for (int oz = -r; oz <= r; ++oz) {
+            const float gz = axis_gap(oz, fz, h);
+            const float gz2 = gz * gz;
+            if (gz2 > b.d2) continue;
+            const int az = oz < 0 ? -oz : oz;
+            for (int oy = -r; oy <= r; ++oy) {
+                const float gy = axis_gap(oy, fy, h);
+                const float gyz2 = fmaf(gy, gy, gz2);
+                if (gyz2 > b.d2) continue;
+                const int ay = oy < 0 ? -oy : oy;
+                const bool shell_yz = (az == r) || (ay == r);
+                // on the shell in y/z every x is visited, otherwise only x = -r and x = +r
+                const int step = shell_yz ? 1 : 2 * r;
+                for (int ox = -r; ox <= r; ox += step) {
+                    const float gx = axis_gap(ox, fx, h);
+                    if (fmaf(gx, gx, gyz2) > b.d2) continue;
+                    if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
+                        scan_cell_1nn(g, start, count, px, py, pz, b);
+                }
+            }
+        }
+        const float bound = (float)r * h + edge;
+        if (b.d2 <= bound * bound * 0.999999f) return true;
+    }
+    return false;
+}
+
+// view of the coarse level through the same struct (only the fields the generic search reads)
+__device__ inline GridView coarse_view(const GridView& g) {
+    GridView c = g;
+    c.table = g.ctable;
+    c.mask = g.cmask;
+    c.h = g.ch;
+    c.inv_h = g.cinv_h;
+    c.pts = g.cpts;
+    return c;
+}
+
+// exact NN for any input: fine rings, then coarse rings, then (queries farther than COARSE_RINGS coarse cells from
+// every map point) the exhaustive scan
+__device__ inline Best nearest_in_grid(const GridView& g, float px, float py, float pz, int max_rings) {
+    Best b;
+    if (nearest_in_level(g, px, py, pz, max_rings, b)) return b;
+    if (g.ctable) {
+        const GridView c = coarse_view(g);
+        if (nearest_in_level(c, px, py, pz, COARSE_RINGS, b)) {
+            b.pos = g.pos_of_orig[b.idx];
+            return b;
+        }
+    }
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    scan_cell_1nn(g, 0, g.m, px, py, pz, b);
+    return b;
+}
+
+__device__ inline bool target_valid(float x, float y, float z, int mode) {
+    if (!(x == x) || !(y == y) || !(z == z)) return false;  // remove_nan, icp_odometry.py:357
+    if (mode == ICP_TARGETS_SKIP_NULL && x == 0.f && y == 0.f && z == 0.f) return false;  // :303-305
+    return true;
+}
+
+// p' = p R^T + t  (Pose.apply_transformation, slam/common/pose.py:169-186)
+__device__ inline void transform_point(const float* __restrict__ T, float x, float y, float z, float& px, float& py,
+                                       float& pz) {
+    px = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
+    py = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
+    pz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
+}
+
+}  // namespace icp

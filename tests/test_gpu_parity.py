@@ -257,6 +257,22 @@ def test_register_masks_nan_and_null_rows(torch_cuda, O, golden_components):
     assert empty.num_targets == 0 and empty.converged and np.array_equal(empty.pose, np.eye(4, dtype=np.float32))
 
 
+def test_fresh_context_after_a_large_one_reads_no_stale_memory(torch_cuda, O, golden_components):
+    """Regression: device buffers recycled from a freed (larger) context hold garbage; nothing may depend on
+    zero-initialised memory (the padding entry of the neighbour rows once did)."""
+    rng = np.random.default_rng(0)
+    big = _ctx()
+    big.map_set((rng.normal(size=(300_000, 3)) * 20).astype(np.float32))
+    big.register((rng.normal(size=(50_000, 3)) * 20).astype(np.float32))
+    big.close()
+    g = golden_components
+    ctx = _ctx(max_num_alignments=3, threshold_delta_pose=0.0)
+    ctx.map_set(g["nn_map"])
+    _, _, ix = ctx.nearest_neighbor_search(g["nn_queries"], with_index=True)
+    np.testing.assert_array_equal(ix, O.brute_force_nn(g["nn_queries"], g["nn_map"])[0])
+    assert ctx.register(g["nn_queries"]).iterations == 3
+
+
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
     """The multi-GPU seam (accumulate -> [all-reduce] -> solve) with world size 1 reproduces icp_register bit for bit,
     and two half-slices summed by hand give the same normal equations as the whole scan."""
