@@ -262,6 +262,7 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
     ctx->cell_h = cfg->cell_size > 0.f ? cfg->cell_size : 0.5f;
     if (const char* v = getenv("ICP_SEARCH_VARIANT")) ctx->search_variant = atoi(v);
     if (const char* v = getenv("ICP_SORT_TARGETS")) ctx->sort_targets = atoi(v);
+    if (const char* v = getenv("ICP_FUSE_ITERATION")) ctx->fuse_iteration = atoi(v);
     if (const char* v = getenv("ICP_TARGET_OCCUPANCY")) ctx->target_occupancy = atof(v) > 0.1 ? atof(v) : 4.0;
     int rc = ensure_state(ctx);
     if (rc == ICP_OK) rc = init_state(ctx, nullptr);
@@ -598,9 +599,17 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     return ICP_OK;
 }
 
+// the fused search + rows kernel needs every normal it may touch: eager mode, and the rows search variant
+static bool fused_path(const icp_ctx* ctx) { return ctx->normals_ready && ctx->search_variant == 2 && ctx->fuse_iteration; }
+
 int icp_iteration_accumulate(icp_ctx* ctx) {
     if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
     int rc;
+    if (fused_path(ctx)) {
+        int blocks = 0;
+        if ((rc = launch_iterate_fused(ctx, &blocks))) return rc;
+        return launch_sum_partials(ctx, blocks);
+    }
     if ((rc = launch_search(ctx))) return rc;
     if ((rc = launch_normals(ctx))) return rc;
     return launch_reduce(ctx);
@@ -654,7 +663,14 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
     // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
     const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
     for (int it = 0; it < iters; ++it) {
-        if ((rc = launch_search(ctx)) || (rc = launch_normals(ctx)) || (rc = launch_reduce_solve(ctx))) {
+        if (fused_path(ctx)) {
+            int blocks = 0;
+            rc = launch_iterate_fused(ctx, &blocks);
+            if (!rc) rc = launch_sum_solve(ctx, blocks);
+        } else {
+            (rc = launch_search(ctx)) || (rc = launch_normals(ctx)) || (rc = launch_reduce_solve(ctx));
+        }
+        if (rc) {
             ctx->in_registration = false;
             return rc;
         }

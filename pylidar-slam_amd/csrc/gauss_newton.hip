@@ -9,50 +9,12 @@
 // (r = (p - q).n, J = [n, p x n], w = sqrt(cost)/clamp(|r|,1e-4)), but the 21 + 6 + 3 sums are accumulated in f64:
 // wave64 shuffle reduction -> LDS across the 4 waves of a block -> one partial row per block -> fixed-order final sum
 // (bit-reproducible run to run).  No MFMA: this is a gather + reduce, not a dense contraction.
+#include "gn_device.h"
 #include "icp_internal.h"
 
 namespace icp {
 
 static constexpr int RED_THREADS = 256;
-
-__device__ inline float robust_weight(int scheme, float sigma, float r, float dist2_pq) {
-    // slam/common/optimization.py:45-50 with the per-scheme cost(); least_square short-circuits to 1 (:70-72)
-    if (scheme == ICP_SCHEME_LEAST_SQUARE) return 1.0f;
-    const float a = fabsf(r);
-    float cost;
-    switch (scheme) {
-        case ICP_SCHEME_HUBER:  // :87-97
-            cost = a < sigma ? r * r : (2.0f * sigma * a - sigma * sigma);
-            break;
-        case ICP_SCHEME_EXP:  // :110-117
-            cost = (r * r) * expf(-(r * r) / (sigma * sigma));
-            break;
-        case ICP_SCHEME_NEIGHBORHOOD: {  // :132-145  exp(-||p - q||^2 / sigma^2), norm taken then squared
-            const float nrm = sqrtf(dist2_pq);
-            cost = r * r * expf(-(nrm * nrm) / (sigma * sigma));
-            break;
-        }
-        case ICP_SCHEME_GEMAN_MCCLURE: {  // :158-166
-            const float r2 = r * r;
-            cost = sigma * r2 / (sigma + r2);
-            break;
-        }
-        case ICP_SCHEME_SQUARE_GEMAN_MCCLURE: {  // :179-187
-            const float r2 = r * r;
-            const float q = sigma / (sigma + r2);
-            cost = r2 * (q * q);
-            break;
-        }
-        case ICP_SCHEME_CAUCHY: {  // :200-208
-            const float q = r / sigma;
-            cost = logf(1.0f + q * q);
-            break;
-        }
-        default:
-            cost = r * r;
-    }
-    return sqrtf(cost) / fmaxf(a, 1.0e-4f);
-}
 
 struct RowAcc {
     double v[NEQ_USED];
@@ -394,7 +356,7 @@ __global__ void k_solve_given(const double* __restrict__ neq, float* __restrict_
     *out_loss = loss;
 }
 
-static AlignParams align_params(const icp_ctx* ctx) {
+AlignParams make_align_params(const icp_ctx* ctx) {
     AlignParams ap;
     ap.scheme = ctx->cfg.scheme;
     ap.sigma = ctx->cfg.sigma;
@@ -417,10 +379,26 @@ int launch_reduce(icp_ctx* ctx) {
     const int tok = prof_begin(ctx, 1);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
-                       align_params(ctx), ctx->partials.as<double>());
+                       make_align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 1, ctx->neq);
     prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
+int launch_sum_solve(icp_ctx* ctx, int blocks) {
+    hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
+                       ctx->dx_hist.as<float>(), ctx->hist_cap);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int launch_sum_partials(icp_ctx* ctx, int blocks) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), 1, ctx->neq);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -432,9 +410,9 @@ int launch_reduce_solve(icp_ctx* ctx) {
     const int tok = prof_begin(ctx, 1);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
-                       align_params(ctx), ctx->partials.as<double>());
+                       make_align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                       reg_state(ctx), align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
+                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
                        ctx->dx_hist.as<float>(), ctx->hist_cap);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
@@ -442,7 +420,7 @@ int launch_reduce_solve(icp_ctx* ctx) {
 }
 
 int launch_solve(icp_ctx* ctx) {
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), ctx->neq, align_params(ctx),
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), ctx->neq, make_align_params(ctx),
                        ctx->loss_hist.as<double>(), ctx->dx_hist.as<float>(), ctx->hist_cap);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -454,7 +432,7 @@ int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const f
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     ICP_HIP(ctx, ctx->stage_out.reserve(256));
     hipLaunchKernelGGL(k_reduce_given, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, nrm, (int)n,
-                       align_params(ctx), ctx->partials.as<double>());
+                       make_align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 0, ctx->neq);
     char* out = ctx->stage_out.as<char>();

@@ -157,6 +157,7 @@ struct icp_ctx {
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
     icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row
+    int fuse_iteration = 1;            // search + rows + partial sums in one kernel when normals are ready (env ICP_FUSE_ITERATION)
     int sort_targets = 0;              // Morton-sort the targets of a registration (env ICP_SORT_TARGETS)
     icp::DeviceBuffer partials;        // double[blocks][NEQ]
     icp::DeviceBuffer state;           // RegState + histories
@@ -200,8 +201,13 @@ int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager 
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
 
 // ---- gauss_newton.hip
+AlignParams make_align_params(const icp_ctx* ctx);
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
+int launch_sum_solve(icp_ctx* ctx, int blocks);
+int launch_sum_partials(icp_ctx* ctx, int blocks);
+// fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
+int launch_iterate_fused(icp_ctx* ctx, int* blocks_out);
 int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n);
 

@@ -9,10 +9,15 @@
 // the query inside its cell.  Cells whose box is farther than the current best are skipped without a table probe.
 // Queries that exhaust `max_rings` fall back to an exhaustive scan, so the result is the exact NN for every input.
 // Distance ties are broken on the smaller original map index (the kd-tree's tie order is unspecified).
+#include <stdlib.h>
+
+#include "gn_device.h"
 #include "icp_internal.h"
 #include "search_device.h"
 
 namespace icp {
+
+__constant__ int g_debug_flags = 0;  // dev-only ablation switches (env ICP_DEBUG_FLAGS), 0 in production
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K1: transform + exact 1-NN; queue the hit map points that have no normal yet
@@ -202,6 +207,17 @@ __global__ __launch_bounds__(256) void k_search_tiled(GridView g, const float4* 
 // A query whose own cell is empty (no row) splits the 26 hashed probes over its 4 lanes instead.  Anything not provably
 // exact after ring 1 goes to the per-lane ring search, so results equal `k_search` bit for bit.
 // ---------------------------------------------------------------------------------------------------------------------
+// e-th (0..47) shell cell of the three middle z-slabs of the 5x5x5 block: each slab contributes its 16 border cells
+__device__ inline int shell_mid(int e) {
+    const int slab = e >> 4, j = e & 15;  // slab 0..2 -> z index 1..3
+    // border of a 5x5 square in row-major order: row 0 (5), rows 1-3 (2 each), row 4 (5)
+    int cell;
+    if (j < 5) cell = j;
+    else if (j < 11) cell = 5 * (1 + ((j - 5) >> 1)) + (((j - 5) & 1) ? 4 : 0);
+    else cell = 20 + (j - 11);
+    return 25 * (slab + 1) + cell;
+}
+
 __device__ inline void group_min4(Best& b) {
 #pragma unroll
     for (int o = 1; o <= 2; o <<= 1) {
@@ -227,21 +243,13 @@ __device__ inline void scan_strided4(const GridView& g, int start, int count, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* __restrict__ tgt, int n, int mode,
-                                                     int transform, RegState* __restrict__ st, int max_rings,
-                                                     int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                     int* __restrict__ worklist, int queue_normals) {
-    if (st->done) return;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int qi = gid >> 2, sub = gid & 3;
-    if (qi >= n) return;  // group-uniform
-    const float4 t4 = tgt[qi];
-    if (!target_valid(t4.x, t4.y, t4.z, mode)) {  // group-uniform
-        if (sub == 0) nn_pos[qi] = -1;
-        return;
-    }
-    float px = t4.x, py = t4.y, pz = t4.z;
-    if (transform) transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
+// the search of one query by its 4 lanes; the result is valid in every lane of the group (b is shared after the
+// reductions) except when the per-lane fallback ran, which only lane 0 executes (and only lane 0 consumes)
+// `stack` = this lane's column of an LDS array [7][blockDim] (stride = blockDim): the neighbour cells it still has to
+// scan.  Scanning them from a per-lane list lets every lane walk ITS cells back to back; looping over the 7 row entries
+// in lockstep instead makes the whole wave pay one pass (probe of the predicate + 4 loads + wait) per entry.
+__device__ inline Best search_rows_group(const GridView& g, float px, float py, float pz, int sub, int max_rings,
+                                         int2* __restrict__ stack, int stride) {
     Best b;
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
@@ -270,9 +278,10 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
         const int2* __restrict__ r = g.rows + (size_t)row * ROW_STRIDE;
         int2 cell[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];  // entry 27 is padding (0, 0)
+        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
         scan_strided4(g, e.start, e.count, sub, px, py, pz, b);
         group_min4(b);
+        int nl = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int c = sub * 7 + k;
@@ -280,7 +289,32 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
             const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                         gz = axis_gap(c / 9 - 1, fz, h);
             if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
-            scan_cell_1nn(g, cell[k].x, cell[k].y, px, py, pz, b);
+            stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
+            ++nl;
+        }
+        int ci = 0, st = 0, cnt = 0, k = 0;
+        for (;;) {
+            if (k >= cnt) {
+                if (ci >= nl) break;
+                const int2 nx = stack[ci * stride];
+                ++ci;
+                const int c = (int)((unsigned)nx.y >> 24);
+                // the best may have shrunk since the cell was queued
+                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                            gz = axis_gap(c / 9 - 1, fz, h);
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+                st = nx.x;
+                cnt = nx.y & 0xffffff;
+                k = 0;
+            }
+            const int last = st + cnt - 1, k0 = st + k;
+            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
+            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+            consider(q0, k0, px, py, pz, b);
+            consider(q1, k1, px, py, pz, b);
+            consider(q2, k2, px, py, pz, b);
+            consider(q3, k3, px, py, pz, b);
+            k += 4;
         }
         group_min4(b);
     } else {
@@ -299,10 +333,9 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
     bool resolved = b.d2 <= bound * bound * 0.999999f;  // group-uniform: b is shared after the reduction
     if (!resolved && max_rings >= 2) {
         // ring 2 (the 98 cells of the 5x5x5 shell), hashed probes split over the 4 lanes, pruned by box distance
-        for (int c = sub; c < 125; c += 4) {
+        for (int e = sub; e < 98; e += 4) {  // the 98 cells of the 5x5x5 shell
+            const int c = e < 25 ? e : (e >= 73 ? e + 27 : shell_mid(e - 25));
             const int ox = c % 5 - 2, oy = (c / 5) % 5 - 2, oz = c / 25 - 2;
-            const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
-            if (m < 2) continue;
             const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
             if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
             int start, count;
@@ -312,8 +345,28 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
         bound = 2.0f * h + edge;
         resolved = b.d2 <= bound * bound * 0.999999f;
     }
+    if (!resolved && sub == 0) b = nearest_in_grid(g, px, py, pz, max_rings);
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* __restrict__ tgt, int n, int mode,
+                                                     int transform, RegState* __restrict__ st, int max_rings,
+                                                     int* __restrict__ nn_pos, int* __restrict__ nflag,
+                                                     int* __restrict__ worklist, int queue_normals) {
+    __shared__ int2 cellstack[7][256];
+    if (st->done) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = gid >> 2, sub = gid & 3;
+    if (qi >= n) return;  // group-uniform
+    const float4 t4 = tgt[qi];
+    if (!target_valid(t4.x, t4.y, t4.z, mode)) {  // group-uniform
+        if (sub == 0) nn_pos[qi] = -1;
+        return;
+    }
+    float px = t4.x, py = t4.y, pz = t4.z;
+    if (transform) transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
+    const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], 256);
     if (sub != 0) return;
-    if (!resolved) b = nearest_in_grid(g, px, py, pz, max_rings);
     nn_pos[qi] = b.pos;
     if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
         if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
@@ -321,37 +374,99 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K2: kNN normals for the queued map points
+// Fused iteration kernel (every needed normal is ready): the search above + the point-to-plane row of each query +
+// the per-block partial normal equations, in one launch — no nn_pos round trip, no second pass over the targets.
+// 64 queries per block: their 9-float rows go to LDS, then 30 threads each own one packed element and add up its 64
+// products in f64 in a fixed order (bit-reproducible), one partial row per block.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KN>
-struct TopK {
-    float d2[KN];
-    int idx[KN];
-    int pos[KN];
-    __device__ inline void init() {
+static constexpr int IT_THREADS = 512;            // 128 queries x 4 lanes per block -> N/128 partial rows
+static constexpr int IT_QUERIES = IT_THREADS / 4;
+
+__global__ __launch_bounds__(IT_THREADS, 8) void k_iterate_rows(GridView g, const float4* __restrict__ tgt, int n,
+                                                             int mode, RegState* __restrict__ st, int max_rings,
+                                                             const float4* __restrict__ normals, AlignParams ap,
+                                                             double* __restrict__ partials) {
+    __shared__ float rowbuf[IT_QUERIES][9];
+    __shared__ double part[4][NEQ];
+    __shared__ int2 cellstack[7][IT_THREADS];
+    if (st->done) return;  // block-uniform
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = gid >> 2, sub = gid & 3;
+    const int lq = threadIdx.x >> 2;  // query slot in the block
+    bool valid = qi < n;
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        t4 = tgt[qi];
+        valid = target_valid(t4.x, t4.y, t4.z, mode);
+    }
+    float row[9];
 #pragma unroll
-        for (int k = 0; k < KN; ++k) {
-            d2[k] = INFINITY;
-            idx[k] = 0x7fffffff;
-            pos[k] = -1;
+    for (int k = 0; k < 9; ++k) row[k] = 0.f;
+    if (valid) {  // group-uniform
+        float px, py, pz;
+        transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
+        const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS);
+        if (sub == 0 && b.pos >= 0) {
+            const float4 q = g.pts[b.pos];
+            const float4 nn = normals[b.pos];
+            point_to_plane_row(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
         }
     }
-    __device__ inline void insert(float d, int i, int p) {
-        if (!better(d, i, d2[KN - 1], idx[KN - 1])) return;
-        d2[KN - 1] = d;
-        idx[KN - 1] = i;
-        pos[KN - 1] = p;
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+    }
+    __syncthreads();
+    // 4 x 30 threads: element e of quarter `qtr` of the block's queries, fixed order
+    if (threadIdx.x < 4 * NEQ) {
+        const int e = threadIdx.x & (NEQ - 1), qtr = threadIdx.x / NEQ;
+        double acc = 0.0;
+        if (e < NEQ_USED) {
+            int a, b2;
+            neq_operands(e, a, b2);
+            const int j0 = qtr * (IT_QUERIES / 4);
+#pragma unroll 8
+            for (int j = 0; j < IT_QUERIES / 4; ++j) acc += (double)rowbuf[j0 + j][a] * (double)rowbuf[j0 + j][b2];
+        }
+        part[qtr][e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < NEQ)
+        partials[(size_t)blockIdx.x * NEQ + threadIdx.x] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2: kNN normals for the queued map points
+// ---------------------------------------------------------------------------------------------------------------------
+// k smallest (distance, original index) pairs as 64-bit keys (d2 bits << 32 | index): d2 >= 0, so the float bits order
+// like the values and one unsigned 64-bit compare gives the lexicographic (distance, index) order the search breaks
+// ties with.  Sorted ascending; a compare-swap step is 1 compare + 4 selects.
+static constexpr unsigned long long KEY_EMPTY = (0x7f800000ull << 32) | 0x7fffffffull;  // (+inf, max index)
+
+__device__ inline unsigned long long make_key(float d2, int idx) {
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)idx;
+}
+__device__ inline float key_d2(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ inline int key_idx(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
+
+template <int KN>
+struct TopK {
+    unsigned long long key[KN];
+    __device__ inline void init() {
+#pragma unroll
+        for (int k = 0; k < KN; ++k) key[k] = KEY_EMPTY;
+    }
+    __device__ inline float kth() const { return key_d2(key[KN - 1]); }
+    __device__ inline void insert(unsigned long long c) {
+        if (!(c < key[KN - 1])) return;
+        key[KN - 1] = c;
 #pragma unroll
         for (int k = KN - 1; k > 0; --k) {
-            const bool sw = better(d2[k], idx[k], d2[k - 1], idx[k - 1]);
-            const float td = d2[k];
-            const int ti = idx[k], tp = pos[k];
-            d2[k] = sw ? d2[k - 1] : td;
-            idx[k] = sw ? idx[k - 1] : ti;
-            pos[k] = sw ? pos[k - 1] : tp;
-            d2[k - 1] = sw ? td : d2[k - 1];
-            idx[k - 1] = sw ? ti : idx[k - 1];
-            pos[k - 1] = sw ? tp : pos[k - 1];
+            const unsigned long long lo = key[k] < key[k - 1] ? key[k] : key[k - 1];
+            const unsigned long long hi = key[k] < key[k - 1] ? key[k - 1] : key[k];
+            key[k - 1] = lo;
+            key[k] = hi;
         }
     }
 };
@@ -362,45 +477,48 @@ __device__ inline void scan_cell_knn(const GridView& g, int start, int count, fl
     for (int k = 0; k < count; ++k) {
         const float4 q = g.pts[start + k];
         const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-        t.insert(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w), start + k);
+        t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
     }
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi in f64).  The reference takes vh[2] of an f32
 // LAPACK SVD of the same matrix (local_map.py:414-416); for a symmetric PSD matrix that is this eigenvector up to sign,
 // and the sign cancels in J^T J and J^T r.
-__device__ inline void smallest_eigenvector(double a00, double a01, double a02, double a11, double a12, double a22,
+__device__ inline void smallest_eigenvector(float a00, float a01, float a02, float a11, float a12, float a22,
                                             float& nx, float& ny, float& nz) {
-    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    const double scale = fabs(a00) + fabs(a11) + fabs(a22);
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        if (off <= 1e-17 * scale || off == 0.0) break;
+    // cyclic Jacobi in f32 (the reference's own decomposition is an f32 LAPACK SVD); the matrix is first scaled to
+    // unit trace so that tiny covariances do not underflow the rotation tests
+    const float tr = a00 + a11 + a22;
+    const float sc = tr > 0.f ? 1.0f / tr : 1.0f;
+    float A[3][3] = {{a00 * sc, a01 * sc, a02 * sc}, {a01 * sc, a11 * sc, a12 * sc}, {a02 * sc, a12 * sc, a22 * sc}};
+    float V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        const float off = fabsf(A[0][1]) + fabsf(A[0][2]) + fabsf(A[1][2]);
+        if (off <= 1e-9f) break;
 #pragma unroll
         for (int pq = 0; pq < 3; ++pq) {
             const int p = pq == 2 ? 1 : 0;
             const int q = pq == 0 ? 1 : 2;
-            const double apq = A[p][q];
-            if (apq == 0.0) continue;
-            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            const float apq = A[p][q];
+            if (apq == 0.0f) continue;
+            const float theta = (A[q][q] - A[p][p]) / (2.0f * apq);
+            const float t = (theta >= 0 ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.0f)));
+            const float c = 1.0f / sqrtf(fmaf(t, t, 1.0f)), s = t * c;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {  // A <- A J
-                const double akp = A[k][p], akq = A[k][q];
+                const float akp = A[k][p], akq = A[k][q];
                 A[k][p] = c * akp - s * akq;
                 A[k][q] = s * akp + c * akq;
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {  // A <- J^T A
-                const double apk = A[p][k], aqk = A[q][k];
+                const float apk = A[p][k], aqk = A[q][k];
                 A[p][k] = c * apk - s * aqk;
                 A[q][k] = s * apk + c * aqk;
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double vkp = V[k][p], vkq = V[k][q];
+                const float vkp = V[k][p], vkq = V[k][q];
                 V[k][p] = c * vkp - s * vkq;
                 V[k][q] = s * vkp + c * vkq;
             }
@@ -409,11 +527,11 @@ __device__ inline void smallest_eigenvector(double a00, double a01, double a02, 
     int m = 2;  // ties -> the last axis, like vh[2] of an already diagonal input
     if (A[1][1] < A[m][m]) m = 1;
     if (A[0][0] < A[m][m]) m = 0;
-    const double x = V[0][m], y = V[1][m], z = V[2][m];
-    const double inv = 1.0 / sqrt(x * x + y * y + z * z);
-    nx = (float)(x * inv);
-    ny = (float)(y * inv);
-    nz = (float)(z * inv);
+    const float x = V[0][m], y = V[1][m], z = V[2][m];
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+    nx = x * inv;
+    ny = y * inv;
+    nz = z * inv;
 }
 
 template <int KN>
@@ -424,8 +542,8 @@ __device__ inline void finish_normal(const GridView& g, int s, float px, float p
     int used = 0;
 #pragma unroll
     for (int k = 1; k < KN; ++k) {
-        if (t.pos[k] < 0) continue;  // map smaller than k + 1 points
-        const float4 q = g.pts[t.pos[k]];
+        if (t.key[k] == KEY_EMPTY) continue;  // map smaller than k + 1 points
+        const float4 q = g.pts[g.pos_of_orig[key_idx(t.key[k])]];
         const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
         c00 += dx * dx;
         c01 += dx * dy;
@@ -437,8 +555,10 @@ __device__ inline void finish_normal(const GridView& g, int s, float px, float p
     }
     const float invk = used > 0 ? 1.0f / (float)used : 0.f;
     float nx, ny, nz;
-    smallest_eigenvector((double)(c00 * invk), (double)(c01 * invk), (double)(c02 * invk), (double)(c11 * invk),
-                         (double)(c12 * invk), (double)(c22 * invk), nx, ny, nz);
+    if (g_debug_flags & 1) {
+        nx = c00 * invk; ny = c01 * invk + c11; nz = c22 + c12 + c02;
+    } else
+    smallest_eigenvector(c00 * invk, c01 * invk, c02 * invk, c11 * invk, c12 * invk, c22 * invk, nx, ny, nz);
     normals[s] = make_float4(nx, ny, nz, 1.f);
     nflag[s] = 1;
 }
@@ -461,30 +581,26 @@ __device__ inline bool knn_level(const GridView& g, float px, float py, float pz
         for (int oz = -r; oz <= r; ++oz) {
             const float gz = axis_gap(oz, fz, h);
             const float gz2 = gz * gz;
-            if (gz2 > t.d2[KN - 1]) continue;
+            if (gz2 > t.kth()) continue;
             const int az = oz < 0 ? -oz : oz;
             for (int oy = -r; oy <= r; ++oy) {
                 const float gy = axis_gap(oy, fy, h);
                 const float gyz2 = fmaf(gy, gy, gz2);
-                if (gyz2 > t.d2[KN - 1]) continue;
+                if (gyz2 > t.kth()) continue;
                 const int ay = oy < 0 ? -oy : oy;
                 const int step = ((az == r) || (ay == r)) ? 1 : 2 * r;
                 for (int ox = -r; ox <= r; ox += step) {
                     const float gx = axis_gap(ox, fx, h);
-                    if (fmaf(gx, gx, gyz2) > t.d2[KN - 1]) continue;
+                    if (fmaf(gx, gx, gyz2) > t.kth()) continue;
                     if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
                         scan_cell_knn<KN>(g, start, count, px, py, pz, t);
                 }
             }
         }
         const float bound = (float)r * h + edge;
-        exact = t.d2[KN - 1] <= bound * bound * 0.999999f;
+        exact = t.kth() <= bound * bound * 0.999999f;
     }
-    if (translate) {  // coarse positions -> fine positions
-#pragma unroll
-        for (int k = 0; k < KN; ++k)
-            if (t.pos[k] >= 0) t.pos[k] = g.pos_of_orig[t.idx[k]];
-    }
+    (void)translate;  // keys carry original indices: nothing to translate between levels
     return exact;
 }
 
@@ -501,11 +617,17 @@ __device__ inline void knn_rings(const GridView& g, float px, float py, float pz
     scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
 }
 
-// a map point always lies in an occupied cell: its 27-neighbourhood comes from the cell's row (no hashing), further
-// rings — only if the k-th neighbour is not provably inside ring 1 — from the hashed search
 template <int KN>
-__device__ inline void estimate_normal(const GridView& g, int s, int max_rings, float4* __restrict__ normals,
-                                       int* __restrict__ nflag) {
+__device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m);
+
+// Normal of one map point by FOUR lanes.  A map point always lies in an occupied cell, so its 27-neighbourhood comes
+// from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
+// neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
+// pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
+// level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
+template <int KN>
+__device__ inline void estimate_normal(const GridView& g, int s, int sub, int max_rings, float4* __restrict__ normals,
+                                       int* __restrict__ nflag, int2* __restrict__ stack, int stride) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     TopK<KN> t;
@@ -517,21 +639,96 @@ __device__ inline void estimate_normal(const GridView& g, int s, int max_rings, 
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
     const int2* __restrict__ r = g.rows + (size_t)g.row_of_pos[s] * ROW_STRIDE;
-    int2 cell[27];
+    const int2 own = r[13];
+    int2 cell[7];
 #pragma unroll
-    for (int c = 0; c < 27; ++c) cell[c] = r[c];
-    scan_cell_knn<KN>(g, cell[13].x, cell[13].y, px, py, pz, t);
-#pragma unroll
-    for (int c = 0; c < 27; ++c) {
-        if (c == 13 || cell[c].y <= 0) continue;
-        const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
-                    gz = axis_gap(c / 9 - 1, fz, h);
-        if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.d2[KN - 1]) continue;
-        scan_cell_knn<KN>(g, cell[c].x, cell[c].y, px, py, pz, t);
+    for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
+    for (int k = own.x + sub; k < own.x + own.y; k += 4) {
+        const float4 q = g.pts[k];
+        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+        t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
     }
-    const float bound = h + edge;
-    if (!(t.d2[KN - 1] <= bound * bound * 0.999999f)) knn_rings<KN>(g, px, py, pz, 2, max_rings, t);
-    finish_normal<KN>(g, s, px, py, pz, t, normals, nflag);
+    // the lane's neighbour cells go to its LDS list, then ONE loop streams their candidates (an insert is ~100 VALU:
+    // walking the 7 row entries in lockstep would make the wave pay every lane's longest cell 7 times over)
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int c = sub * 7 + k;
+        if (c == 13 || c >= 27 || cell[k].y <= 0) continue;
+        stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
+        ++nl;
+    }
+    {
+        int ci = 0, st = 0, cnt = 0, k = 0;
+        for (;;) {
+            if (k >= cnt) {
+                if (ci >= nl) break;
+                const int2 nx = stack[ci * stride];
+                ++ci;
+                const int c = (int)((unsigned)nx.y >> 24);
+                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                            gz = axis_gap(c / 9 - 1, fz, h);
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.kth()) continue;
+                st = nx.x;
+                cnt = nx.y & 0xffffff;
+                k = 0;
+            }
+            const float4 q = g.pts[st + k];
+            const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+            t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
+            ++k;
+        }
+    }
+    TopK<KN> m;
+    merge_group4<KN>(t, m);
+    const float bound1 = h + edge;
+    if (!(g_debug_flags & 4) && !(m.kth() <= bound1 * bound1 * 0.999999f) && max_rings >= 2) {  // group-uniform
+        // ring 2 by the four lanes: hashed probes pruned against the group's current k-th distance
+        if (sub == 0) {
+            t = m;
+        } else {
+            t.init();
+        }
+        const float kth = m.kth();
+        for (int e = sub; e < 98; e += 4) {  // the 98 cells of the 5x5x5 shell
+            const int c = e < 25 ? e : (e >= 73 ? e + 27 : shell_mid(e - 25));
+            const int ox = c % 5 - 2, oy = (c / 5) % 5 - 2, oz = c / 25 - 2;
+            const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth) continue;
+            int start, count;
+            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+        }
+        merge_group4<KN>(t, m);
+        if (sub != 0) return;
+        const float bound2 = 2.0f * h + edge;
+        if (!(g_debug_flags & 2) && !(m.kth() <= bound2 * bound2 * 0.999999f)) knn_rings<KN>(g, px, py, pz, 3, max_rings, m);
+        finish_normal<KN>(g, s, px, py, pz, m, normals, nflag);
+        return;
+    }
+    if (sub != 0) return;
+    if (!(g_debug_flags & 4) && !(m.kth() <= bound1 * bound1 * 0.999999f)) knn_rings<KN>(g, px, py, pz, 2, max_rings, m);
+    finish_normal<KN>(g, s, px, py, pz, m, normals, nflag);
+}
+
+// merge of the four lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
+template <int KN>
+__device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m) {
+#pragma unroll
+    for (int round = 0; round < KN; ++round) {
+        unsigned long long best = t.key[0];
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        m.key[round] = best;
+        const bool won = (t.key[0] == best) && (best != KEY_EMPTY);  // original indices are unique: one winner
+#pragma unroll
+        for (int k = 0; k < KN - 1; ++k) t.key[k] = won ? t.key[k + 1] : t.key[k];
+        if (won) t.key[KN - 1] = KEY_EMPTY;
+    }
 }
 
 // lazy: the map points queued by the search of this iteration
@@ -540,9 +737,11 @@ __global__ __launch_bounds__(128) void k_normals(GridView g, RegState* __restric
                                                  const int* __restrict__ worklist, int max_rings,
                                                  float4* __restrict__ normals, int* __restrict__ nflag) {
     if (st->done) return;
+    __shared__ int2 cellstack[7][128];
     const int nw = st->n_worklist;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x)
-        estimate_normal<KN>(g, worklist[w], max_rings, normals, nflag);
+    const int sub = threadIdx.x & 3;
+    for (int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; w < nw; w += (gridDim.x * blockDim.x) >> 2)
+        estimate_normal<KN>(g, worklist[w], sub, max_rings, normals, nflag, &cellstack[0][threadIdx.x], 128);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
 }
 
@@ -551,8 +750,10 @@ __global__ __launch_bounds__(128) void k_normals(GridView g, RegState* __restric
 template <int KN>
 __global__ __launch_bounds__(128) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                      int* __restrict__ nflag) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < g.m) estimate_normal<KN>(g, s, max_rings, normals, nflag);
+    __shared__ int2 cellstack[7][128];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = gid >> 2;
+    if (s < g.m) estimate_normal<KN>(g, s, gid & 3, max_rings, normals, nflag, &cellstack[0][threadIdx.x], 128);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -686,10 +887,18 @@ int launch_search(icp_ctx* ctx) {
 
 // eager estimation of every map normal (only for the k with a register-resident top-k list)
 int launch_normals_all(icp_ctx* ctx) {
+    static int dbg_init = 0;
+    if (!dbg_init) {
+        dbg_init = 1;
+        if (const char* v = getenv("ICP_DEBUG_FLAGS")) {
+            int f = atoi(v);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_flags), &f, sizeof(int));
+        }
+    }
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
-    const int blocks = (int)((ctx->map_m + 127) / 128);
+    const int blocks = (int)((ctx->map_m * 4 + 127) / 128);
     GridView g = make_view(ctx);
     const int tok = prof_begin(ctx, 2);
     if (kn == 11)
@@ -708,14 +917,28 @@ int launch_normals_all(icp_ctx* ctx) {
     return ICP_OK;
 }
 
+int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
+    const int n = (int)ctx->tgt_n;
+    const int blocks = n > 0 ? (int)(((long long)n * 4 + IT_THREADS - 1) / IT_THREADS) : 1;
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    const int tok = prof_begin(ctx, 0);
+    hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
+                       ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings, ctx->normals.as<float4>(),
+                       make_align_params(ctx), ctx->partials.as<double>());
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    *blocks_out = blocks;
+    return ICP_OK;
+}
+
 int launch_normals(icp_ctx* ctx) {
     if (ctx->normals_ready) return ICP_OK;
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     // the worklist length lives on the device: launch a fixed grid and stride over it
     int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
-    int blocks = (int)((cap + 127) / 128);
+    int blocks = (int)((cap * 4 + 127) / 128);  // 4 lanes per queued map point
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 8192) blocks = 8192;
     const int tok = prof_begin(ctx, 2);
     GridView g = make_view(ctx);
     if (kn == 11) {
