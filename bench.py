@@ -12,13 +12,14 @@ One step = one frame of the hot path, everything the reference does per frame on
   residual/Jacobian reduction, 6x6 solve, pose update] (:274-297) -> pose read back to the host -> local-map update
   (re-express the 100k map by inv(T), rebuild the search structure, clear the normal cache; local_map.py:346-369).
 The scans form a ping-pong sequence along a trajectory, so every step registers a genuinely moved scan from an
-identity initial guess; nothing is cached between steps.
+constant-velocity initial guess (the reference's default initialisation; wrong by twice the motion at the two
+turn-arounds of the ping-pong); nothing is cached between steps.
 
 N > 1: one process per GPU, every rank tracks its own independent scan sequence (replicated map, no data-path
 collective) -> weak scaling; `--mode sharded` instead splits every scan's points across the ranks and all-reduces the
 packed 6x6 normal equations (32 doubles) over RCCL once per ICP iteration (strong scaling of one sequence).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-iteration nearest-neighbour search),
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-iteration fused search + rows kernel),
 timed with HIP events on the library's stream inside the timed region; `cpu_baseline` times the numpy/cKDTree oracle
 (oracle/icp_oracle.py, a restatement of the reference's CPU path) on one frame of the same workload.
 """
@@ -49,6 +50,9 @@ def parse():
     ap.add_argument("--sigma", type=float, default=0.3)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--init", choices=["cv", "identity"], default="cv",
+                    help="initial guess per frame: constant velocity = last relative pose (the reference's default, "
+                         "config/slam.yaml: slam/initialization: CV) or identity (initialization: NI)")
     ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
@@ -64,18 +68,18 @@ def make_workload(rank: int):
     return cfg, scans, poses, model, order
 
 
-def step_replica(ctx, scan_dev, vmap_out):
+def step_replica(ctx, scan_dev, vmap_out, init):
     ctx.project(scan_dev, out=vmap_out)
-    res = ctx.register(scan_dev)  # identity initial guess; synchronises to return the pose
+    res = ctx.register(scan_dev, init)  # synchronises to return the pose
     ctx.map_update(res.pose, None)
     return res
 
 
-def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, iters):
+def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, iters, init):
     from pylidar_slam_amd.distributed import sharded_register
     ctx.project(full_scan_dev, out=vmap_out)
     # per iteration: accumulate -> all-reduce (RCCL, 256 B, in place on the library's vector) -> identical solve
-    res = sharded_register(ctx, scan_slice_dev, None, iters)
+    res = sharded_register(ctx, scan_slice_dev, init, iters)
     ctx.map_update(res.pose, None)
     return res
 
@@ -132,14 +136,21 @@ def main():
         b, e = shard_bounds(n_pts, world, rank)
         slices = [s[b:e].contiguous() for s in scans_dev]
 
+    state = {"last": None, "prev_frame": 0, "max_err": 0.0}
+
     def run(k, first_frame):
         res = None
         for i in range(k):
             f = order[(first_frame + i) % len(order)]
+            init = state["last"] if args.init == "cv" else None  # ConstantVelocityInitialization: last relative pose
             if sharded:
-                res = step_sharded(ctx, slices[f], scans_dev[f], vmap, args.iters)
+                res = step_sharded(ctx, slices[f], scans_dev[f], vmap, args.iters, init)
             else:
-                res = step_replica(ctx, scans_dev[f], vmap)
+                res = step_replica(ctx, scans_dev[f], vmap, init)
+            state["last"] = res.pose
+            gt_rel = np.linalg.inv(poses[state["prev_frame"]]) @ poses[f]  # O(1) host bookkeeping, not device work
+            state["max_err"] = max(state["max_err"], float(np.linalg.norm(gt_rel[:3, 3] - res.pose[:3, 3])))
+            state["prev_frame"] = f
         return res
 
     run(args.warmup, 0)
@@ -183,6 +194,7 @@ def main():
                        "parallelism": ("points-sharded + RCCL all-reduce of 6x6 normal equations" if sharded else
                                        f"{world} independent sequences (replicated map, no collective)")},
             "last_pose_error_vs_ground_truth_m": gt_err,
+            "max_pose_error_vs_ground_truth_m": state["max_err"], "init": args.init,
             "iterations_last_frame": int(res.iterations),
         }
         if prof and prof["search_launches"] > 0:
@@ -196,7 +208,8 @@ def main():
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "k_search (per-iteration exact 1-NN in the voxel-hash grid)",
+            out["roofline"] = {"bound": "hbm", "kernel": "k_iterate_rows (per-iteration fused kernel: transform + exact 1-NN in the voxel-hash grid + "
+                                         "point-to-plane rows + per-block partial normal equations)",
                                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic,
                                "avg_launch_us": avg_s * 1e6, "launches": prof["search_launches"],
