@@ -1,6 +1,7 @@
 // C ABI of libicp_mi355x.so: context management, staging, and the orchestration of the kernels in the other
 // translation units.  Signatures and the reference interfaces they replace: include/icp_mi355x.h.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -74,7 +75,7 @@ struct Pose16 {
 
 __global__ void k_state_init(RegState* st, Pose16 init) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 16; ++k) st->pose[k] = init.m[k];
+    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = init.m[k];
     for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
     st->iter = 0;
     st->done = 0;
@@ -262,6 +263,12 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
     ctx->cell_h = cfg->cell_size > 0.f ? cfg->cell_size : 0.5f;
     if (const char* v = getenv("ICP_SEARCH_VARIANT")) ctx->search_variant = atoi(v);
     if (const char* v = getenv("ICP_SORT_TARGETS")) ctx->sort_targets = atoi(v);
+    if (const char* v = getenv("ICP_NN_CACHE")) ctx->use_nn_cache = atoi(v);
+    if (const char* v = getenv("ICP_SEARCH_STATS")) ctx->search_stats = atoi(v);
+    if (ctx->search_stats) {
+        if (ctx->dbg_counts.reserve(64) != hipSuccess) ctx->search_stats = 0;
+        else (void)hipMemset(ctx->dbg_counts.ptr, 0, 64);
+    }
     if (const char* v = getenv("ICP_FUSE_ITERATION")) ctx->fuse_iteration = atoi(v);
     if (const char* v = getenv("ICP_TARGET_OCCUPANCY")) ctx->target_occupancy = atof(v) > 0.1 ? atof(v) : 4.0;
     int rc = ensure_state(ctx);
@@ -285,7 +292,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
                             &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->ctable,
-                            &ctx->csorted,    &ctx->pos_of_orig};
+                            &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
@@ -596,6 +603,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
     if (!ctx->normals_ready && ctx->map_m <= 2 * n && (rc = launch_normals_all(ctx))) return rc;
     ctx->in_registration = true;
+    ctx->iter_in_registration = 0;
     return ICP_OK;
 }
 
@@ -633,6 +641,14 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         ctx->occupied_cells = stats[0];
         ctx->stats_m = ctx->stats_m_pending;
         ctx->stats_pending = false;
+    }
+    if (ctx->search_stats) {
+        int c[8];
+        if (hipMemcpy(c, ctx->dbg_counts.ptr, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[icp stats] N=%lld M=%lld h=%.3f iters=%d ring1=%d need_ring2=%d need_ring3=%d fine_failed=%d exhaustive=%d own_empty=%d\n",
+                    (long long)ctx->tgt_n, (long long)ctx->map_m, ctx->cell_h, st.iter, c[0], c[1], c[2], c[3], c[4], c[5]);
+            (void)hipMemset(ctx->dbg_counts.ptr, 0, 64);
+        }
     }
     st.normals_computed += ctx->normals_eager_count;
     ctx->normals_eager_count = 0;

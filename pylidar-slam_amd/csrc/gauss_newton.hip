@@ -309,6 +309,7 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
     }
     // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
     float D[16], P[16];
+    for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = st->pose[k2];
     build_pose_f32(dx, D);
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 4; ++c) {

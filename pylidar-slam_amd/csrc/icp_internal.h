@@ -40,6 +40,7 @@ struct GridView {
     float ch, cinv_h;
     const float4* cpts;
     const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
+    int* dbg;                // dev-only path counters (env ICP_SEARCH_STATS), nullptr in production
 };
 static constexpr float COARSE_FACTOR = 4.0f;
 static constexpr int COARSE_RINGS = 6;
@@ -75,6 +76,7 @@ static constexpr int NEQ_USED = 30;
 
 struct RegState {
     float pose[16];
+    float pose_prev[16];  // pose of the previous iteration (the NN cache bounds how far each target moved since)
     float params[6];
     int iter;        // align() calls made so far
     int done;        // 1: loop finished (converged / guard / error); later launches are no-ops
@@ -155,8 +157,13 @@ struct icp_ctx {
     int64_t tgt_n = 0;
     int tgt_mode = 0;
     icp::DeviceBuffer nn_pos;          // int[N]
+    icp::DeviceBuffer nn_cache;        // int2[N]: (NN position, bits(L)) — L = lower bound on the distance to every other map point
+    int iter_in_registration = 0;
+    int use_nn_cache = 1;              // env ICP_NN_CACHE
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
     icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row
+    int search_stats = 0;              // env ICP_SEARCH_STATS: count which path resolved each query (dev)
+    icp::DeviceBuffer dbg_counts;
     int fuse_iteration = 1;            // search + rows + partial sums in one kernel when normals are ready (env ICP_FUSE_ITERATION)
     int sort_targets = 0;              // Morton-sort the targets of a registration (env ICP_SORT_TARGETS)
     icp::DeviceBuffer partials;        // double[blocks][NEQ]

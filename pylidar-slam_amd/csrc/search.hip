@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_search_tiled(GridView g, const float4* 
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
     b.pos = -1;
+    b.second = 0.f;
     bool resolved = false;
     if (tiled && !overflow[w]) {
         const float h = g.h;
@@ -224,11 +225,14 @@ __device__ inline void group_min4(Best& b) {
         const float d2 = __shfl_xor(b.d2, o, 64);
         const int idx = __shfl_xor(b.idx, o, 64);
         const int pos = __shfl_xor(b.pos, o, 64);
+        float sec = fminf(b.second, __shfl_xor(b.second, o, 64));
+        if (pos != b.pos) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
         if (better(d2, idx, b.d2, b.idx)) {
             b.d2 = d2;
             b.idx = idx;
             b.pos = pos;
         }
+        b.second = sec;
     }
 }
 
@@ -254,6 +258,7 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
     b.pos = -1;
+    b.second = INFINITY;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -288,7 +293,11 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             if (c == 13 || c >= 27 || cell[k].y <= 0) continue;  // own cell done above; entry 27 is padding
             const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                         gz = axis_gap(c / 9 - 1, fz, h);
-            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+            const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+            if (gap2 > b.d2) {
+                b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
+                continue;
+            }
             stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
             ++nl;
         }
@@ -302,7 +311,11 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
                 // the best may have shrunk since the cell was queued
                 const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                             gz = axis_gap(c / 9 - 1, fz, h);
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+                const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+                if (gap2 > b.d2) {
+                    b.second = fminf(b.second, gap2);
+                    continue;
+                }
                 st = nx.x;
                 cnt = nx.y & 0xffffff;
                 k = 0;
@@ -323,7 +336,11 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             const int c = c0 + (c0 >= 13 ? 1 : 0);
             const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
             const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+            const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+            if (gap2 > b.d2) {
+                b.second = fminf(b.second, gap2);
+                continue;
+            }
             int start, count;
             if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
         }
@@ -331,21 +348,32 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     }
     float bound = h + edge;
     bool resolved = b.d2 <= bound * bound * 0.999999f;  // group-uniform: b is shared after the reduction
-    if (!resolved && max_rings >= 2) {
-        // ring 2 (the 98 cells of the 5x5x5 shell), hashed probes split over the 4 lanes, pruned by box distance
-        for (int e = sub; e < 98; e += 4) {  // the 98 cells of the 5x5x5 shell
-            const int c = e < 25 ? e : (e >= 73 ? e + 27 : shell_mid(e - 25));
-            const int ox = c % 5 - 2, oy = (c / 5) % 5 - 2, oz = c / 25 - 2;
+    // nothing outside the 27-cell block is closer than `bound`; beyond ring 1 the cache is simply not fed
+    b.second = resolved ? fminf(b.second, bound * bound * 0.999999f) : 0.f;
+    if (g.dbg && sub == 0) atomicAdd(&g.dbg[resolved ? 0 : 1], 1);
+    if (g.dbg && sub == 0 && e.key != key) atomicAdd(&g.dbg[5], 1);
+    // rings 2..max_rings: the shell of each ring split over the 4 lanes (hashed probes, pruned by box distance against
+    // the best found so far), one group reduction per ring
+    for (int r = 2; r <= max_rings && !resolved; ++r) {
+        const int side = 2 * r + 1, total = side * side * side;
+        for (int c = sub; c < total; c += 4) {
+            const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
+            const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+            if (m < r) continue;  // interior: visited by the previous rings
             const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
             if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
             int start, count;
             if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
         }
         group_min4(b);
-        bound = 2.0f * h + edge;
+        bound = (float)r * h + edge;
         resolved = b.d2 <= bound * bound * 0.999999f;
+        if (g.dbg && sub == 0 && !resolved) atomicAdd(&g.dbg[2], 1);
     }
-    if (!resolved && sub == 0) b = nearest_in_grid(g, px, py, pz, max_rings);
+    // still unresolved: farther than max_rings fine cells from the map -> coarse level (then exhaustive), lane 0
+    if (!resolved && sub == 0) b = nearest_beyond_fine(g, px, py, pz);
+    b.second = resolved ? b.second : 0.f;
+    if (!(b.d2 <= (h + edge) * (h + edge) * 0.999999f)) b.second = 0.f;  // only ring-1 results feed the NN cache
     return b;
 }
 
@@ -382,10 +410,11 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 static constexpr int IT_THREADS = 512;            // 128 queries x 4 lanes per block -> N/128 partial rows
 static constexpr int IT_QUERIES = IT_THREADS / 4;
 
-__global__ __launch_bounds__(IT_THREADS, 8) void k_iterate_rows(GridView g, const float4* __restrict__ tgt, int n,
+__global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const float4* __restrict__ tgt, int n,
                                                              int mode, RegState* __restrict__ st, int max_rings,
                                                              const float4* __restrict__ normals, AlignParams ap,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials,
+                                                             int2* __restrict__ nn_cache, int use_cache) {
     __shared__ float rowbuf[IT_QUERIES][9];
     __shared__ double part[4][NEQ];
     __shared__ int2 cellstack[7][IT_THREADS];
@@ -405,10 +434,40 @@ __global__ __launch_bounds__(IT_THREADS, 8) void k_iterate_rows(GridView g, cons
     if (valid) {  // group-uniform
         float px, py, pz;
         transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
-        const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS);
-        if (sub == 0 && b.pos >= 0) {
-            const float4 q = g.pts[b.pos];
-            const float4 nn = normals[b.pos];
+        // NN cache (exact): the previous search left, besides the neighbour, a lower bound L on the distance to EVERY
+        // OTHER map point.  The target moved by delta since, so every other point is still >= L - delta away: if the
+        // cached neighbour is strictly closer than that it is still THE nearest neighbour and the search is skipped.
+        int pos = -1;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool hit = false;
+        if (use_cache) {
+            const int2 c = nn_cache[qi];
+            if (c.x >= 0) {
+                float ox, oy, oz;
+                transform_point(st->pose_prev, t4.x, t4.y, t4.z, ox, oy, oz);
+                const float mx = px - ox, my = py - oy, mz = pz - oz;
+                const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                const float L = __int_as_float(c.y) - delta;
+                q = g.pts[c.x];
+                const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+                const float d = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) * 1.000001f;
+                hit = d < L;
+                if (hit) {
+                    pos = c.x;
+                    if (sub == 0) nn_cache[qi] = make_int2(c.x, __float_as_int(L));
+                }
+            }
+        }
+        if (!hit) {  // group-uniform: the 4 lanes read the same cache entry
+            const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS);
+            if (sub == 0) {
+                pos = b.pos;
+                if (pos >= 0) q = g.pts[pos];
+                if (nn_cache) nn_cache[qi] = make_int2(pos, __float_as_int(sqrtf(b.second) * 0.999999f));
+            }
+        }
+        if (sub == 0 && pos >= 0) {
+            const float4 nn = normals[pos];
             point_to_plane_row(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
         }
     }
@@ -859,6 +918,7 @@ static GridView make_view(icp_ctx* ctx) {
     g.cinv_h = 1.0f / g.ch;
     g.cpts = ctx->csorted.as<float4>();
     g.pos_of_orig = ctx->pos_of_orig.as<int>();
+    g.dbg = ctx->search_stats ? ctx->dbg_counts.as<int>() : nullptr;
     return g;
 }
 
@@ -921,12 +981,15 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     const int n = (int)ctx->tgt_n;
     const int blocks = n > 0 ? (int)(((long long)n * 4 + IT_THREADS - 1) / IT_THREADS) : 1;
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
     const int tok = prof_begin(ctx, 0);
     hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
                        ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings, ctx->normals.as<float4>(),
-                       make_align_params(ctx), ctx->partials.as<double>());
+                       make_align_params(ctx), ctx->partials.as<double>(), ctx->nn_cache.as<int2>(),
+                       (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? 1 : 0);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
+    ctx->iter_in_registration += 1;
     *blocks_out = blocks;
     return ICP_OK;
 }

@@ -6,8 +6,9 @@ namespace icp {
 
 struct Best {
     float d2;
-    int idx;  // original index (tie-break)
-    int pos;  // cell-sorted position
+    int idx;       // original index (tie-break)
+    int pos;       // cell-sorted position
+    float second;  // lower bound on the squared distance of every OTHER map point seen or pruned so far (NN cache)
 };
 
 __device__ inline bool better(float d2, int idx, float bd2, int bidx) { return d2 < bd2 || (d2 == bd2 && idx < bidx); }
@@ -37,10 +38,14 @@ __device__ inline void consider(const float4 q, int pos, float px, float py, flo
     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const int idx = __float_as_int(q.w);
+    if (pos == b.pos) return;  // clamped re-read of the current best (tail of a 4-wide fetch)
     if (better(d2, idx, b.d2, b.idx)) {
+        b.second = fminf(b.second, b.d2);
         b.d2 = d2;
         b.idx = idx;
         b.pos = pos;
+    } else {
+        b.second = fminf(b.second, d2);
     }
 }
 
@@ -63,6 +68,7 @@ __device__ inline bool nearest_in_level(const GridView& g, float px, float py, f
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
     b.pos = -1;
+    b.second = 0.f;  // the generic path does not feed the NN cache
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -110,11 +116,10 @@ __device__ inline GridView coarse_view(const GridView& g) {
     return c;
 }
 
-// exact NN for any input: fine rings, then coarse rings, then (queries farther than COARSE_RINGS coarse cells from
-// every map point) the exhaustive scan
-__device__ inline Best nearest_in_grid(const GridView& g, float px, float py, float pz, int max_rings) {
+// the tail of `nearest_in_grid` for a caller that has already exhausted the fine rings
+__device__ inline Best nearest_beyond_fine(const GridView& g, float px, float py, float pz) {
     Best b;
-    if (nearest_in_level(g, px, py, pz, max_rings, b)) return b;
+    if (g.dbg) atomicAdd(&g.dbg[3], 1);
     if (g.ctable) {
         const GridView c = coarse_view(g);
         if (nearest_in_level(c, px, py, pz, COARSE_RINGS, b)) {
@@ -122,10 +127,36 @@ __device__ inline Best nearest_in_grid(const GridView& g, float px, float py, fl
             return b;
         }
     }
+    if (g.dbg) atomicAdd(&g.dbg[4], 1);
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
     b.pos = -1;
+    b.second = 0.f;
     scan_cell_1nn(g, 0, g.m, px, py, pz, b);
+    b.second = 0.f;
+    return b;
+}
+
+// exact NN for any input: fine rings, then coarse rings, then (queries farther than COARSE_RINGS coarse cells from
+// every map point) the exhaustive scan
+__device__ inline Best nearest_in_grid(const GridView& g, float px, float py, float pz, int max_rings) {
+    Best b;
+    if (nearest_in_level(g, px, py, pz, max_rings, b)) return b;
+    if (g.dbg) atomicAdd(&g.dbg[3], 1);
+    if (g.ctable) {
+        const GridView c = coarse_view(g);
+        if (nearest_in_level(c, px, py, pz, COARSE_RINGS, b)) {
+            b.pos = g.pos_of_orig[b.idx];
+            return b;
+        }
+    }
+    if (g.dbg) atomicAdd(&g.dbg[4], 1);
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    b.second = 0.f;
+    scan_cell_1nn(g, 0, g.m, px, py, pz, b);
+    b.second = 0.f;
     return b;
 }
 

@@ -273,6 +273,34 @@ def test_fresh_context_after_a_large_one_reads_no_stale_memory(torch_cuda, O, go
     assert ctx.register(g["nn_queries"]).iterations == 3
 
 
+def test_nn_cache_and_kernel_variants_are_bit_identical(torch_cuda, monkeypatch):
+    """The per-iteration NN cache (skip the search when the cached neighbour is provably still the nearest), the fused
+    search+rows kernel and the alternative search kernels are pure schedule changes: same poses and losses, bit for bit
+    where the reduction order is shared, to 1e-12 relative otherwise."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 5)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    results = {}
+    for name, env in (("default", {}), ("nocache", {"ICP_NN_CACHE": "0"}), ("unfused", {"ICP_FUSE_ITERATION": "0"}),
+                      ("perlane", {"ICP_SEARCH_VARIANT": "0"}), ("tiles", {"ICP_SEARCH_VARIANT": "1"}),
+                      ("sorted", {"ICP_SORT_TARGETS": "1"})):
+        for k in ("ICP_NN_CACHE", "ICP_FUSE_ITERATION", "ICP_SEARCH_VARIANT", "ICP_SORT_TARGETS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                   sigma=0.3)
+        ctx.map_set(model)
+        results[name] = ctx.register(scans[4])
+        ctx.close()
+    ref = results["default"]
+    assert np.array_equal(results["nocache"].pose, ref.pose) and np.array_equal(results["nocache"].losses, ref.losses)
+    for name in ("unfused", "perlane", "tiles", "sorted"):
+        np.testing.assert_allclose(results[name].pose, ref.pose, atol=2e-7)
+        np.testing.assert_allclose(results[name].losses, ref.losses, rtol=1e-6)
+
+
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
     """The multi-GPU seam (accumulate -> [all-reduce] -> solve) with world size 1 reproduces icp_register bit for bit,
     and two half-slices summed by hand give the same normal equations as the whole scan."""

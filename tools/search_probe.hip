@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dt, table.data(), T * sizeof(GridEntry), hipMemcpyHostToDevice));
     CK(hipMemcpy(dp, sorted.data(), M * sizeof(float4), hipMemcpyHostToDevice));
     CK(hipMemcpy(dq, q4.data(), N * sizeof(float4), hipMemcpyHostToDevice));
-    GridView g; g.table = dt; g.mask = T - 1; g.h = h; g.inv_h = inv_h; g.pts = dp; g.m = M; g.row_of_slot = nullptr; g.rows = nullptr; g.row_of_pos = nullptr; g.ctable = nullptr; g.cmask = 0; g.ch = 0; g.cinv_h = 0; g.cpts = nullptr; g.pos_of_orig = nullptr;
+    GridView g; g.table = dt; g.mask = T - 1; g.h = h; g.inv_h = inv_h; g.pts = dp; g.m = M; g.row_of_slot = nullptr; g.rows = nullptr; g.row_of_pos = nullptr; g.ctable = nullptr; g.cmask = 0; g.ch = 0; g.cinv_h = 0; g.cpts = nullptr; g.pos_of_orig = nullptr; g.dbg = nullptr;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto timeit = [&](const char* name, auto kern, int block) {
         float best = 1e9, tot = 0; const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 20;
