@@ -126,16 +126,20 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_given(const float* __res
 __device__ inline void sum_partials_block(const double* __restrict__ partials, int nblocks, double* out /* LDS or global */) {
     __shared__ double lds[32][NEQ];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     int b = grp;
-    for (; b + 96 < nblocks; b += 128) {  // four independent loads in flight
+    for (; b + 224 < nblocks; b += 256) {  // eight independent loads in flight
         s0 += partials[(size_t)b * NEQ + col];
         s1 += partials[(size_t)(b + 32) * NEQ + col];
         s2 += partials[(size_t)(b + 64) * NEQ + col];
         s3 += partials[(size_t)(b + 96) * NEQ + col];
+        s4 += partials[(size_t)(b + 128) * NEQ + col];
+        s5 += partials[(size_t)(b + 160) * NEQ + col];
+        s6 += partials[(size_t)(b + 192) * NEQ + col];
+        s7 += partials[(size_t)(b + 224) * NEQ + col];
     }
     for (; b < nblocks; b += 32) s0 += partials[(size_t)b * NEQ + col];
-    lds[grp][col] = (s0 + s1) + (s2 + s3);
+    lds[grp][col] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (threadIdx.x < NEQ) {
         double t = 0.0;
