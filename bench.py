@@ -112,11 +112,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the product path has no CPU fallback"
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU for a dry run
+    if backend != "nccl":
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from pylidar_slam_amd.engine import IcpContext
     sharded = args.mode == "sharded" and world > 1
