@@ -247,6 +247,40 @@ __device__ inline void scan_strided4(const GridView& g, int start, int count, in
     }
 }
 
+// Rings r_begin..r_end of ONE level searched by the 4 lanes of a query (hashed probes; ring 0 = the query's own cell with
+// its candidates strided over the lanes, ring r >= 1 = the shell split over the lanes), pruned by box distance against
+// the best so far, one group reduction per ring.  Returns true as soon as the best is provably exact on this level.
+__device__ inline bool coop_rings(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end,
+                                  Best& b) {
+    const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
+    const float h = lv.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    for (int r = r_begin; r <= r_end; ++r) {
+        int start, count;
+        if (r == 0) {
+            if (grid_lookup(lv, cx, cy, cz, start, count)) scan_strided4(lv, start, count, sub, px, py, pz, b);
+        } else {
+            const int side = 2 * r + 1, total = side * side * side;
+            for (int c = sub; c < total; c += 4) {
+                const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
+                const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+                if (m < r) continue;  // interior: visited by the previous rings
+                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+                if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
+                    scan_cell_1nn(lv, start, count, px, py, pz, b);
+            }
+        }
+        group_min4(b);
+        const float bound = (float)r * h + edge;
+        if (b.d2 <= bound * bound * 0.999999f) return true;
+    }
+    return false;
+}
+
 // the search of one query by its 4 lanes; the result is valid in every lane of the group (b is shared after the
 // reductions) except when the per-lane fallback ran, which only lane 0 executes (and only lane 0 consumes)
 // `stack` = this lane's column of an LDS array [7][blockDim] (stride = blockDim): the neighbour cells it still has to
@@ -352,28 +386,27 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     b.second = resolved ? fminf(b.second, bound * bound * 0.999999f) : 0.f;
     if (g.dbg && sub == 0) atomicAdd(&g.dbg[resolved ? 0 : 1], 1);
     if (g.dbg && sub == 0 && e.key != key) atomicAdd(&g.dbg[5], 1);
-    // rings 2..max_rings: the shell of each ring split over the 4 lanes (hashed probes, pruned by box distance against
-    // the best found so far), one group reduction per ring
-    for (int r = 2; r <= max_rings && !resolved; ++r) {
-        const int side = 2 * r + 1, total = side * side * side;
-        for (int c = sub; c < total; c += 4) {
-            const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
-            const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
-            if (m < r) continue;  // interior: visited by the previous rings
-            const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
-            int start, count;
-            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
+    const bool ring1 = resolved;
+    if (!resolved) {
+        // rings 2..max_rings of the fine level, then the coarse level (4x cells), every ring split over the 4 lanes
+        if (g.dbg && sub == 0) atomicAdd(&g.dbg[2], 1);
+        resolved = max_rings >= 2 && coop_rings(g, px, py, pz, sub, 2, max_rings, b);
+        if (!resolved && g.ctable) {
+            if (g.dbg && sub == 0) atomicAdd(&g.dbg[3], 1);
+            // candidates of the coarse level carry positions of ITS point array: identify the winner by original index
+            b.pos = -2;  // the fine position must not alias a coarse one in the re-read test of `consider`
+            resolved = coop_rings(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b);
+            if (b.idx != 0x7fffffff) b.pos = g.pos_of_orig[b.idx];
         }
-        group_min4(b);
-        bound = (float)r * h + edge;
-        resolved = b.d2 <= bound * bound * 0.999999f;
-        if (g.dbg && sub == 0 && !resolved) atomicAdd(&g.dbg[2], 1);
+        if (!resolved && sub == 0) {  // farther than COARSE_RINGS coarse cells from every map point
+            if (g.dbg) atomicAdd(&g.dbg[4], 1);
+            b.d2 = INFINITY;
+            b.idx = 0x7fffffff;
+            b.pos = -1;
+            scan_cell_1nn(g, 0, g.m, px, py, pz, b);
+        }
     }
-    // still unresolved: farther than max_rings fine cells from the map -> coarse level (then exhaustive), lane 0
-    if (!resolved && sub == 0) b = nearest_beyond_fine(g, px, py, pz);
-    b.second = resolved ? b.second : 0.f;
-    if (!(b.d2 <= (h + edge) * (h + edge) * 0.999999f)) b.second = 0.f;  // only ring-1 results feed the NN cache
+    if (!ring1) b.second = 0.f;  // only ring-1 results feed the NN cache
     return b;
 }
 
