@@ -712,6 +712,55 @@ __device__ inline void knn_rings(const GridView& g, float px, float py, float pz
 template <int KN>
 __device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m);
 
+// kNN counterpart of `coop_rings`: rings r_begin..r_end of one level by the 4 lanes of a map point.  `m` is the merged
+// list so far (identical in the 4 lanes); per ring lane 0 continues from it, the others from empty lists, every lane
+// inserts its share of the ring, and the lists are merged again.  Keys carry original indices, so fine and coarse
+// levels mix freely.  Returns true when the k-th neighbour is provably exact on this level.
+template <int KN>
+__device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end,
+                                      TopK<KN>& m) {
+    const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
+    const float h = lv.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    for (int r = r_begin; r <= r_end; ++r) {
+        TopK<KN> t;
+        if (sub == 0) {
+            t = m;
+        } else {
+            t.init();
+        }
+        const float kth = m.kth();
+        int start, count;
+        if (r == 0) {
+            if (grid_lookup(lv, cx, cy, cz, start, count)) {
+                for (int k = start + sub; k < start + count; k += 4) {
+                    const float4 q = lv.pts[k];
+                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+                    t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
+                }
+            }
+        } else {
+            const int side = 2 * r + 1, total = side * side * side;
+            for (int c = sub; c < total; c += 4) {
+                const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
+                const int mx = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+                if (mx < r) continue;
+                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth) continue;
+                if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
+                    scan_cell_knn<KN>(lv, start, count, px, py, pz, t);
+            }
+        }
+        merge_group4<KN>(t, m);
+        const float bound = (float)r * h + edge;
+        if (m.kth() <= bound * bound * 0.999999f) return true;
+    }
+    return false;
+}
+
 // Normal of one map point by FOUR lanes.  A map point always lies in an occupied cell, so its 27-neighbourhood comes
 // from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
 // neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
@@ -774,31 +823,20 @@ __device__ inline void estimate_normal(const GridView& g, int s, int sub, int ma
     TopK<KN> m;
     merge_group4<KN>(t, m);
     const float bound1 = h + edge;
-    if (!(g_debug_flags & 4) && !(m.kth() <= bound1 * bound1 * 0.999999f) && max_rings >= 2) {  // group-uniform
-        // ring 2 by the four lanes: hashed probes pruned against the group's current k-th distance
-        if (sub == 0) {
-            t = m;
-        } else {
-            t.init();
+    bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
+    if (!exact && !(g_debug_flags & 4)) {
+        // fine rings 2..max_rings, then the coarse level, each ring split over the 4 lanes
+        exact = max_rings >= 2 && coop_knn_rings<KN>(g, px, py, pz, sub, 2, max_rings, m);
+        if (!exact && g.ctable) {
+            m.init();  // the coarse rings start at ring 0 and re-find the fine results: starting empty avoids duplicates
+            exact = coop_knn_rings<KN>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, m);
         }
-        const float kth = m.kth();
-        for (int e = sub; e < 98; e += 4) {  // the 98 cells of the 5x5x5 shell
-            const int c = e < 25 ? e : (e >= 73 ? e + 27 : shell_mid(e - 25));
-            const int ox = c % 5 - 2, oy = (c / 5) % 5 - 2, oz = c / 25 - 2;
-            const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-            if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth) continue;
-            int start, count;
-            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_knn<KN>(g, start, count, px, py, pz, t);
+        if (!exact && sub == 0) {  // farther than COARSE_RINGS coarse cells from k map points: exhaustive
+            m.init();
+            scan_cell_knn<KN>(g, 0, g.m, px, py, pz, m);
         }
-        merge_group4<KN>(t, m);
-        if (sub != 0) return;
-        const float bound2 = 2.0f * h + edge;
-        if (!(g_debug_flags & 2) && !(m.kth() <= bound2 * bound2 * 0.999999f)) knn_rings<KN>(g, px, py, pz, 3, max_rings, m);
-        finish_normal<KN>(g, s, px, py, pz, m, normals, nflag);
-        return;
     }
     if (sub != 0) return;
-    if (!(g_debug_flags & 4) && !(m.kth() <= bound1 * bound1 * 0.999999f)) knn_rings<KN>(g, px, py, pz, 2, max_rings, m);
     finish_normal<KN>(g, s, px, py, pz, m, normals, nflag);
 }
 
