@@ -119,6 +119,18 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
 int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                    int64_t* hashes_out, int out_mem);
 
+/* float64-input variants: `GridSample` applied to the float64 output of `Distortion` (config/slam/preprocessing/
+ * grid_sample.yaml: distortion -> grid_sample on "distorted"); points_out is float64 [count,3] */
+int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
+                        double* points_out, int64_t* count_out, int out_mem);
+
+/* ---- de-skew: Distortion.filter (slam/preprocessing.py:144-191) --------------------------------------------------
+ * Every point moves by the fraction alpha = (t - t_min) / (t_max - t_min) of the initial motion estimate `rel_pose`:
+ * out = slerp(I, R, alpha) p + alpha t  (alpha = 0 when all timestamps are equal).  xyz [n,3] float32, timestamps [n]
+ * float64, rel_pose row-major 4x4 float64, out [n,3] float64 (the reference's einsum promotes to float64). */
+int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_t n, int mem, const double rel_pose[16],
+                double* xyz_out, int out_mem);
+
 /* ---- local map: KdTreeLocalMap (slam/odometry/local_map.py:254-427) ---------------------------------------------- */
 int icp_map_init(icp_ctx* ctx);                                             /* init()               :279-288 */
 int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* set_map_pointcloud() :289-299 */

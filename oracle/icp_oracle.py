@@ -121,6 +121,26 @@ def grid_sample(pc: np.ndarray, voxel: float):
     return sample_from_hashes(pc, voxel_hashing(voxelise(pc, voxel)))
 
 
+def distort(pc: np.ndarray, timestamps: np.ndarray, rpose: np.ndarray) -> np.ndarray:
+    """reference slam/preprocessing.py:144-191 (`Distortion.filter`): every point is moved by the
+    fraction alpha = (t - t_min) / (t_max - t_min) of the initial motion estimate: rotation slerp(I, R, alpha)
+    (scipy `Slerp`, i.e. exp(alpha * log R)) and translation alpha * t.  float64 out, like the reference's einsum."""
+    ts = np.asarray(timestamps, dtype=np.float64).reshape(-1)
+    diff = ts.max() - ts.min()
+    alpha = ts * 0 if diff == 0.0 else (ts - ts.min()) / diff  # :177-179
+    rot = np.asarray(rpose)[:3, :3].astype(np.float64)
+    # log map: (R - R^T) / 2 = sin(theta) [axis]x, trace = 1 + 2 cos(theta)   (theta < pi)
+    v = 0.5 * np.array([rot[2, 1] - rot[1, 2], rot[0, 2] - rot[2, 0], rot[1, 0] - rot[0, 1]])
+    nv = np.linalg.norm(v)
+    theta = np.arctan2(nv, 0.5 * (np.trace(rot) - 1.0))
+    axis = v / nv if nv > 0 else np.zeros(3)
+    phi = alpha * theta
+    p = np.asarray(pc).astype(np.float64)
+    c, s_ = np.cos(phi)[:, None], np.sin(phi)[:, None]
+    rotated = p * c + np.cross(axis[None, :], p) * s_ + axis[None, :] * (p @ axis)[:, None] * (1.0 - c)
+    return rotated + alpha[:, None] * np.asarray(rpose)[:3, 3].astype(np.float64)[None, :]  # :183-185
+
+
 # ======================================================================================================================
 # a9 / a17  pose parametrisation (euler xyz, R = Rz Ry Rx), float32 like the reference's torch tensors
 # ======================================================================================================================

@@ -400,6 +400,45 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
     return ICP_OK;
 }
 
+int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
+                        double* points_out, int64_t* count_out, int out_mem) {
+    if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 24, mem, ctx->stage_in, &in))) return rc;
+    void *idev, *pdev;
+    if ((rc = export_target(ctx, indices_out, (size_t)n * 8, out_mem, ctx->stage_out, &idev))) return rc;
+    if ((rc = export_target(ctx, points_out, (size_t)n * 24, out_mem, ctx->stage_out2, &pdev))) return rc;
+    int* count_dev = ctx->counter.as<int>();
+    if ((rc = grid_sample_f64_device(ctx, (const double*)in, n, voxel_size, (long long*)idev, (double*)pdev, count_dev)))
+        return rc;
+    int count = 0;
+    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count_out = count;
+    if ((rc = export_finish(ctx, indices_out, idev, (size_t)count * 8, out_mem))) return rc;
+    if ((rc = export_finish(ctx, points_out, pdev, (size_t)count * 24, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+// ---- de-skew --------------------------------------------------------------------------------------------------------
+int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_t n, int mem, const double rel_pose[16],
+                double* xyz_out, int out_mem) {
+    if (!ctx || n < 0 || !rel_pose || (n > 0 && (!xyz || !timestamps || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
+    const void *in, *ts;
+    int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    if ((rc = import_buffer(ctx, timestamps, (size_t)n * 8, mem, ctx->stage_out2, &ts))) return rc;
+    void* odev;
+    if ((rc = export_target(ctx, xyz_out, (size_t)n * 24, out_mem, ctx->stage_out, &odev))) return rc;
+    if ((rc = distort_device(ctx, (const float*)in, (const double*)ts, n, rel_pose, (double*)odev))) return rc;
+    if ((rc = export_finish(ctx, xyz_out, odev, (size_t)n * 24, out_mem))) return rc;
+    if (out_mem == ICP_MEM_HOST || mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
 // ---- local map ------------------------------------------------------------------------------------------------------
 int icp_map_init(icp_ctx* ctx) {
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;

@@ -9,6 +9,7 @@
 //   hash   = 73856093 x + 19349669 y + 83492791 z                wrapping int64
 //   sort (hash, index) by hash — stable LSD radix sort, so equal hashes keep ascending index — keep run heads.
 // The sort is rocPRIM's device radix sort (a library primitive); everything else is hand-written.
+#include <cmath>
 #include <cstring>
 #include <string.h>
 
@@ -18,12 +19,14 @@
 
 namespace icp {
 
-__device__ inline long long voxel_coord(float v, double voxel) {
+template <typename T>
+__device__ inline long long voxel_coord(T v, double voxel) {
     // int(np.round_(p / voxel)); rint = round-half-even
     return (long long)rint((double)v / voxel);
 }
 
-__global__ void k_voxel_hash(const float* __restrict__ xyz, int n, double voxel, long long* __restrict__ voxels,
+template <typename T>
+__global__ void k_voxel_hash(const T* __restrict__ xyz, int n, double voxel, long long* __restrict__ voxels,
                              long long* __restrict__ hashes, unsigned long long* __restrict__ sort_keys,
                              int* __restrict__ sort_vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,9 +54,10 @@ __global__ void k_run_heads(const unsigned long long* __restrict__ keys, int n, 
     flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-__global__ void k_emit_samples(const float* __restrict__ xyz, const int* __restrict__ vals,
+template <typename T>
+__global__ void k_emit_samples(const T* __restrict__ xyz, const int* __restrict__ vals,
                                const int* __restrict__ flags, const int* __restrict__ offs, int n,
-                               long long* __restrict__ indices, float* __restrict__ points) {
+                               long long* __restrict__ indices, T* __restrict__ points) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
     const int o = offs[i];
@@ -69,14 +73,15 @@ __global__ void k_emit_samples(const float* __restrict__ xyz, const int* __restr
 int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                       long long* hashes_dev) {
     if (n <= 0) return ICP_OK;
-    hipLaunchKernelGGL(k_voxel_hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
+    hipLaunchKernelGGL(k_voxel_hash<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
                        voxel, voxels_dev, hashes_dev, (unsigned long long*)nullptr, (int*)nullptr);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
-int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                       float* points_dev, int* count_dev) {
+template <typename T>
+static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                            T* points_dev, int* count_dev) {
     if (n <= 0) {
         ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
         return ICP_OK;
@@ -92,7 +97,7 @@ int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double vox
     int* va = ctx->vals_a.as<int>();
     int* vb = ctx->vals_b.as<int>();
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_voxel_hash, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, (long long*)nullptr,
+    hipLaunchKernelGGL(k_voxel_hash<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, (long long*)nullptr,
                        (long long*)nullptr, ka, va);
     size_t tmp_bytes = 0;
     ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64, ctx->stream));
@@ -104,8 +109,100 @@ int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double vox
     hipLaunchKernelGGL(k_run_heads, dim3(nb), dim3(256), 0, ctx->stream, kb, (int)n, flags);
     int rc = exclusive_scan_i32(ctx, flags, offs, n, count_dev);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_emit_samples, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, vb, flags, offs, (int)n,
+    hipLaunchKernelGGL(k_emit_samples<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, vb, flags, offs, (int)n,
                        indices_dev, points_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                       float* points_dev, int* count_dev) {
+    return grid_sample_impl<float>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev);
+}
+
+int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                           double* points_dev, int* count_dev) {
+    return grid_sample_impl<double>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// De-skew (`Distortion.filter`, slam/preprocessing.py:144-191): timestamp range by a two-level f64 min/max reduction,
+// then per point the Rodrigues rotation by alpha * theta about the axis of the initial motion + alpha * translation,
+// all in float64 like the reference (scipy Slerp + a float64 einsum).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_f64(const double* __restrict__ v, int n, double* __restrict__ part) {
+    __shared__ double smin[4], smax[4];
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = v[i];
+        mn = fmin(mn, x);
+        mx = fmax(mx, x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_down(mn, o, 64));
+        mx = fmax(mx, __shfl_down(mx, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = mn;
+        smax[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+        part[2 * blockIdx.x + 1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
+}
+
+struct DistortArg {
+    double axis[3];
+    double theta;
+    double t[3];
+};
+
+__global__ void k_distort(const float* __restrict__ xyz, const double* __restrict__ ts, int n,
+                          const double* __restrict__ part, int nparts, DistortArg a, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double tmin = INFINITY, tmax = -INFINITY;
+    for (int k = 0; k < nparts; ++k) {  // a few dozen values, L2-resident
+        tmin = fmin(tmin, part[2 * k]);
+        tmax = fmax(tmax, part[2 * k + 1]);
+    }
+    const double diff = tmax - tmin;
+    const double alpha = diff == 0.0 ? 0.0 : (ts[i] - tmin) / diff;  // :177-179
+    const double px = (double)xyz[3 * i], py = (double)xyz[3 * i + 1], pz = (double)xyz[3 * i + 2];
+    double s, c;
+    sincos(alpha * a.theta, &s, &c);
+    const double ux = a.axis[0], uy = a.axis[1], uz = a.axis[2];
+    const double dot = ux * px + uy * py + uz * pz;
+    const double cx = uy * pz - uz * py, cy = uz * px - ux * pz, cz = ux * py - uy * px;
+    out[3 * i] = px * c + cx * s + ux * dot * (1.0 - c) + alpha * a.t[0];
+    out[3 * i + 1] = py * c + cy * s + uy * dot * (1.0 - c) + alpha * a.t[1];
+    out[3 * i + 2] = pz * c + cz * s + uz * dot * (1.0 - c) + alpha * a.t[2];
+}
+
+int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int64_t n, const double* rel_pose16,
+                   double* out_dev) {
+    if (n <= 0) return ICP_OK;
+    const int nparts = 64;
+    ICP_HIP(ctx, ctx->scan_b.reserve((size_t)nparts * 2 * sizeof(double)));
+    double* part = ctx->scan_b.as<double>();
+    hipLaunchKernelGGL(k_minmax_f64, dim3(nparts), dim3(256), 0, ctx->stream, ts_dev, (int)n, part);
+    // log map of the rotation: (R - R^T) / 2 = sin(theta) [axis]x, trace = 1 + 2 cos(theta)
+    const double* R = rel_pose16;
+    const double vx = 0.5 * (R[9] - R[6]), vy = 0.5 * (R[2] - R[8]), vz = 0.5 * (R[4] - R[1]);
+    const double nv = sqrt(vx * vx + vy * vy + vz * vz);
+    DistortArg a;
+    a.theta = atan2(nv, 0.5 * (R[0] + R[5] + R[10] - 1.0));
+    a.axis[0] = nv > 0 ? vx / nv : 0.0;
+    a.axis[1] = nv > 0 ? vy / nv : 0.0;
+    a.axis[2] = nv > 0 ? vz / nv : 0.0;
+    a.t[0] = R[3];
+    a.t[1] = R[7];
+    a.t[2] = R[11];
+    hipLaunchKernelGGL(k_distort, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, ts_dev, (int)n,
+                       (const double*)part, nparts, a, out_dev);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -225,6 +225,10 @@ int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* 
 // ---- grid_sample.hip
 int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                       long long* hashes_dev);
+int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, double voxel, long long* indices_dev,
+                           double* points_dev, int* count_dev);
+int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int64_t n, const double* rel_pose16,
+                   double* out_dev);
 // targets -> float4 rows in ctx->tgt4; sorted along a Morton curve of the map's cells under `pose` when sort != 0
 int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const float* pose16_host, int sort);
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,

@@ -167,6 +167,30 @@ class IcpContext:
                                               pts.ctypes.data, C.byref(count), MEM_HOST))
         return pts[:count.value].copy(), idx[:count.value].copy()
 
+    def grid_sample_f64(self, points: np.ndarray, voxel_size: float):
+        """float64 cloud (the output of `distort`) -> (sample points [V,3] f64, indices [V] int64)."""
+        pts64 = np.ascontiguousarray(points, dtype=np.float64)
+        n = int(pts64.shape[0])
+        count = C.c_int64(0)
+        idx = np.empty(max(n, 1), np.int64)
+        out = np.empty((max(n, 1), 3), np.float64)
+        self._check(self._lib.icp_grid_sample_f64(self._h, pts64.ctypes.data, n, MEM_HOST, float(voxel_size),
+                                                  idx.ctypes.data, out.ctypes.data, C.byref(count), MEM_HOST))
+        return out[:count.value].copy(), idx[:count.value].copy()
+
+    # ---- de-skew -----------------------------------------------------------------------------------------------------
+    def distort(self, points: np.ndarray, timestamps: np.ndarray, rel_pose) -> np.ndarray:
+        """`Distortion.filter`: [N,3] f32 points + [N] f64 timestamps + 4x4 initial motion -> [N,3] f64."""
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        ts = np.ascontiguousarray(np.asarray(timestamps).reshape(-1), dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3 or ts.shape[0] != pts.shape[0]:
+            raise AssertionError(f"expected [N,3] points and [N] timestamps, got {pts.shape} / {ts.shape}")
+        pose = np.ascontiguousarray(np.asarray(rel_pose, dtype=np.float64).reshape(4, 4))
+        out = np.empty((pts.shape[0], 3), np.float64)
+        self._check(self._lib.icp_distort(self._h, pts.ctypes.data, ts.ctypes.data, int(pts.shape[0]), MEM_HOST,
+                                          pose.ctypes.data, out.ctypes.data, MEM_HOST))
+        return out
+
     # ---- local map ---------------------------------------------------------------------------------------------------
     def map_init(self):
         self._check(self._lib.icp_map_init(self._h))

@@ -11,6 +11,7 @@ Same names, argument meaning and error behaviour as the reference classes they s
   GaussNewtonPointToPlaneAlignment slam/odometry/alignment.py:80-127    PointToPlaneAlignment
   SphericalProjector               slam/common/projection.py:426-508    SphericalProjector
   GridSample / grid_sample         slam/preprocessing.py:207-226        GridSample / grid_sample
+  Distortion                       slam/preprocessing.py:144-191        Distortion
   ConstantVelocityInitialization   slam/initialization.py:103-119       ConstantVelocityInitialization
 
 All array arithmetic over points happens in HIP kernels; this file only orchestrates (O(1) pose algebra per frame).
@@ -26,7 +27,8 @@ import torch
 
 from .engine import IcpContext, InvalidJacobianError, RegisterResult  # noqa: F401
 
-__all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap",
+__all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap", "Distortion",
+           "DistortionConfig",
            "PointToPlaneAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
            "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
 
@@ -126,6 +128,9 @@ class SphericalProjector:
 def grid_sample(pointcloud: np.ndarray, voxel_size: float, ctx: Optional[IcpContext] = None):
     """slam/common/pointcloud.py:182-195: (sample points, indices of the sampled points)."""
     ctx = ctx or _shared_context()
+    if isinstance(pointcloud, np.ndarray) and pointcloud.dtype == np.float64:
+        # e.g. the float64 output of `Distortion`: voxelised from the float64 values, like the reference
+        return ctx.grid_sample_f64(pointcloud, voxel_size)
     pts, idx = ctx.grid_sample(pointcloud, voxel_size)
     if isinstance(pointcloud, np.ndarray) and pointcloud.dtype != np.float32:
         pts = pointcloud[idx]  # keep the caller's dtype, like `pointcloud[unique_indices]`
@@ -166,6 +171,47 @@ class GridSample:
         sample, indices = grid_sample(pc, self.config.voxel_size, self._ctx)
         data_dict[self.config.output_sample_key] = sample
         data_dict[self.config.output_indices_key] = indices
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class DistortionConfig:
+    """slam/preprocessing.py:130-141."""
+    filter_name: str = "distortion"
+    pointcloud_key: str = "numpy_pc"
+    timestamps_key: str = "numpy_pc_timestamps"
+    pose_key: str = "init_rpose"
+    output_key: str = "input_data"
+    force: bool = False
+    activate: bool = True
+
+
+class Distortion:
+    """slam/preprocessing.py:144-191: de-skews a frame with the initial motion estimate (per-point slerp + linear
+    translation by the normalised timestamp).  Pass-through (same array object) when deactivated, without timestamps or
+    without an initial pose, exactly as the reference."""
+
+    def __init__(self, config: DistortionConfig, ctx: Optional[IcpContext] = None, **kwargs):
+        self.config = config
+        self._ctx = ctx
+
+    def filter(self, data_dict: dict):
+        c = self.config
+        pc = data_dict[c.pointcloud_key]
+        assert_debug(isinstance(pc, np.ndarray), "Cannot Distort a non numpy frame")
+        assert_debug(pc.ndim == 2 and pc.shape[1] == 3, f"expected [N, 3], got {pc.shape}")
+        no_distortion = not c.activate or (c.timestamps_key not in data_dict)
+        no_distortion = no_distortion or (data_dict[c.pose_key] is None if c.pose_key in data_dict else False)
+        if no_distortion:
+            data_dict[c.output_key] = pc
+            return
+        rpose = np.asarray(data_dict[c.pose_key])
+        assert_debug(rpose.shape == (4, 4))
+        timestamps = data_dict[c.timestamps_key]
+        assert_debug(isinstance(timestamps, np.ndarray))
+        timestamps = timestamps.reshape(-1)
+        assert_debug(timestamps.shape[0] == pc.shape[0])
+        data_dict[c.output_key] = (self._ctx or _shared_context()).distort(pc, timestamps, rpose)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -98,6 +98,34 @@ def test_voxel_hash_and_grid_sample(torch_cuda, O, golden_components):
     np.testing.assert_array_equal(ib, O.grid_sample(big, 1e-3)[1])
 
 
+def test_distortion_filter_and_f64_grid_sample(torch_cuda, O):
+    """SURVEY §8f rank 1 (`Distortion` -> `GridSample` on the float64 de-skewed cloud): HIP vs the reference's outputs."""
+    import os
+    from pylidar_slam_amd.odometry import Distortion, DistortionConfig, GridSample, GridSampleConfig
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "distortion.npz"))
+    ctx = _ctx()
+    dist = Distortion(DistortionConfig(output_key="distorted"), ctx=ctx)
+    gs = GridSample(GridSampleConfig(voxel_size=0.3, pointcloud_key="distorted"), ctx=ctx)
+    for name in ("small", "large", "identity", "pure_translation"):
+        d = {"numpy_pc": g["pc"], "numpy_pc_timestamps": g["timestamps"], "init_rpose": g[f"{name}_rpose"]}
+        dist.filter(d)
+        assert d["distorted"].dtype == np.float64
+        np.testing.assert_allclose(d["distorted"], g[f"{name}_distorted"], atol=1e-11)
+        gs.filter(d)
+        np.testing.assert_array_equal(d["sample_indices"], g[f"{name}_sample_indices"])
+        np.testing.assert_array_equal(d["sample_points"], d["distorted"][d["sample_indices"]])
+    # pass-through cases return the very same array (slam/preprocessing.py:158-163)
+    d = {"numpy_pc": g["pc"], "init_rpose": g["small_rpose"]}
+    dist.filter(d)
+    assert d["distorted"] is g["pc"] or d["distorted"] is d["numpy_pc"]
+    d = {"numpy_pc": g["pc"], "numpy_pc_timestamps": g["timestamps"], "init_rpose": None}
+    dist.filter(d)
+    assert d["distorted"] is d["numpy_pc"]
+    # constant timestamps -> alpha = 0
+    out = ctx.distort(g["pc"], np.full(g["pc"].shape[0], 3.0), g["small_rpose"])
+    np.testing.assert_allclose(out, g["constant_ts_distorted"], atol=1e-12)
+
+
 def test_nearest_neighbor_and_normals(torch_cuda, O, golden_components):
     g = golden_components
     ctx = _ctx(cell_size=0.5)

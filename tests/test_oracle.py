@@ -141,3 +141,17 @@ def test_c1_sequence_matches_reference(golden_c1, c1_scans, run):
             assert len(orc.traces[-1].dx) == int(g[f"{run}_iters"][f])
     assert orc.local_map.local_map.shape[0] == int(g[f"{run}_map_size"])
     np.testing.assert_allclose(np.stack(orc.absolute_poses), g[f"{run}_abs"], atol=1e-4)
+
+
+def test_distortion_matches_reference():
+    """the de-skew restatement against the reference's own Distortion + GridSample outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "distortion.npz"))
+    for name in ("small", "large", "identity", "pure_translation"):
+        d = O.distort(g["pc"], g["timestamps"], g[f"{name}_rpose"])
+        assert d.dtype == np.float64
+        np.testing.assert_allclose(d, g[f"{name}_distorted"], atol=1e-12)
+        _, idx = O.sample_from_hashes(d, O.voxel_hashing(O.voxelise(d, 0.3)))
+        np.testing.assert_array_equal(idx, g[f"{name}_sample_indices"])
+    np.testing.assert_allclose(O.distort(g["pc"], np.full(g["pc"].shape[0], 3.0), g["small_rpose"]),
+                               g["constant_ts_distorted"], atol=1e-12)
