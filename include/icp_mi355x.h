@@ -150,6 +150,31 @@ int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem); /* current map [M,3]
 int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* neighbor_points_out,
                                 float* neighbor_normals_out, int32_t* neighbor_index_out, int out_mem);
 
+/* ---- projective local map: ProjectiveLocalMap (slam/odometry/local_map.py:91-240), the reference's "GPU" variant -----
+ * compute_normal_map (slam/common/geometry.py:240-295): vertex map [3,H,W] -> normal map [3,H,W] (box-filter plane fit,
+ * zero where the pixel is null or |det| <= 1e-6). */
+int icp_compute_normal_map(icp_ctx* ctx, const float* vmap, int mem, int kernel_size, float* nmap_out, int out_mem);
+/* compute_neighbors (slam/common/geometry.py:397-439): per pixel the closest of k_maps reference vertex maps
+ * [k_maps,3,H,W] to the target map [3,H,W] (null pixels never match; ties -> the first map); optionally gathers
+ * ref_fields [k_maps,c_fields,H,W] along.  neighbors_out [3,H,W], fields_out [c_fields,H,W]. */
+int icp_compute_neighbors(icp_ctx* ctx, const float* tgt_vmap, const float* ref_vmaps, const float* ref_fields,
+                          int k_maps, int c_fields, int mem, float* neighbors_out, float* fields_out, int out_mem);
+int icp_pmap_init(icp_ctx* ctx); /* init() :113-119 */
+/* update() :122-174 — re-express the kept maps by inv(rel_pose), append `vmap` [3,H,W] with its normal map (NULL:
+ * pose-only update), drop the oldest beyond local_map_size, rebuild the model (build_model :177-202). */
+int icp_pmap_update(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem, int normals_kernel_size);
+int icp_pmap_num_maps(const icp_ctx* ctx);
+/* the model: `_model_vmap` / `_model_nmap` as [K, H*W, 4] float rows (xyz + valid flag, normal + 0) */
+int icp_pmap_get_model(icp_ctx* ctx, float* model_v4_out, float* model_n4_out, int out_mem);
+/* nearest_neighbor_search() :205-235 — projective association of the (already transformed) points xyz [n,3]:
+ * rows9_out [count,9] = neighbour point, neighbour normal, target point per matched pixel, in pixel order. */
+int icp_pmap_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows9_out,
+                                     int64_t* count_out, int out_mem);
+/* register_new_frame (slam/odometry/icp_odometry.py:248-299) against the projective map; same contract as
+ * icp_register. */
+int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
+                      icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);
+
 /* ---- rigid alignment: GaussNewtonPointToPlaneAlignment.align (slam/odometry/alignment.py:91-127) on given
  * correspondences; one Gauss-Newton step from x0 = 0 (slam/common/optimization.py:296-344).
  * dx_out[6], pose_out[16] = build_pose_matrix(dx), loss_out = sum (w r)^2, normal_eq_out (optional) = 32 doubles:

@@ -354,6 +354,188 @@ class KdTreeLocalMapOracle:
 
 
 # ======================================================================================================================
+# a19  projective local map (the reference's "GPU" variant): normal maps, per-pixel association over K maps
+# ======================================================================================================================
+def _box_sum(img: np.ndarray, k: int) -> np.ndarray:
+    """zero-padded k x k box sum of [C, H, W] (Fnn.conv2d with a ones kernel, geometry.py:262-270)."""
+    c, h, w = img.shape
+    r = k // 2
+    pad = np.zeros((c, h + 2 * r, w + 2 * r), dtype=img.dtype)
+    pad[:, r:r + h, r:r + w] = img
+    out = np.zeros_like(img)
+    for dy in range(k):
+        for dx in range(k):
+            out += pad[:, dy:dy + h, dx:dx + w]
+    return out
+
+
+def compute_normal_map(vmap: np.ndarray, kernel_size: int = 5, dtype=F32) -> np.ndarray:
+    """reference slam/common/geometry.py:240-295: n ~ (sum_box p p^T)^-1 (sum_box p), adjugate inverse (:63-98),
+    zero where |det| <= 1e-6 or the pixel is null, normalised.  vmap [3,H,W] f32 -> [3,H,W].
+    `dtype` = float32 restates the reference arithmetic (noise-dominated, see tests); float64 is the exact value the
+    HIP kernel is compared with."""
+    F32 = dtype  # noqa: N806 (shadows the module constant on purpose)
+    v = np.asarray(vmap, dtype=F32)
+    _, h, w = v.shape
+    cov = (v[None, :, :, :] * v[:, None, :, :]).reshape(9, h, w)  # cov[i*3+j] = v_i v_j
+    s = _box_sum(v, kernel_size)  # [3,H,W]
+    a = _box_sum(cov, kernel_size).reshape(3, 3, h, w)
+    A = np.moveaxis(a, (0, 1), (2, 3))  # [H,W,3,3]
+    S = np.moveaxis(s, 0, 2)  # [H,W,3]
+    adj = np.empty_like(A)
+    for i in range(3):
+        adj[..., i, :] = np.cross(A[..., i - 2, :], A[..., i - 1, :])  # :74-76
+    det = (adj * A).sum(axis=-1).mean(axis=-1)  # :88
+    ok = np.abs(det) > 1.0e-6
+    safe = np.where(ok, det, F32(1.0))
+    inv_t = adj / safe[..., None, None]
+    inv_t[~ok] = 0.0
+    inv = np.swapaxes(inv_t, -1, -2)  # :109-110
+    n = np.einsum("...ij,...j->...i", inv, S).astype(F32)
+    norms = np.sqrt((n * n).sum(axis=-1, keepdims=True, dtype=F32))
+    n = np.where(norms > 0, n / np.where(norms > 0, norms, F32(1.0)), F32(0.0)).astype(F32)
+    null = np.sqrt((v * v).sum(axis=0, dtype=F32)) == 0.0
+    n[null] = 0.0
+    return np.ascontiguousarray(np.moveaxis(n, 2, 0))
+
+
+def compute_neighbors(vm_target: np.ndarray, vm_reference: np.ndarray, reference_fields: Optional[np.ndarray] = None):
+    """reference slam/common/geometry.py:397-439: per pixel, the closest of the K reference vertex maps (inf where the
+    target or the reference pixel is null; ties -> the first).  vm_target [3,H,W], vm_reference [K,3,H,W]."""
+    t = np.asarray(vm_target, dtype=F32)
+    r = np.asarray(vm_reference, dtype=F32)
+    mask_t = np.abs(t).max(axis=0) > 0  # [H,W]
+    mask_r = np.abs(r).max(axis=1) > 0  # [K,H,W]
+    diff = np.sqrt(((t[None] - r) ** 2).sum(axis=1, dtype=F32))
+    diff = np.where(mask_r & mask_t[None], diff, np.inf)
+    idx = diff.argmin(axis=0)  # first minimum
+    nb = np.take_along_axis(r, idx[None, None], axis=0)[0]
+    nb = nb * mask_t[None]
+    fields = None
+    if reference_fields is not None:
+        fields = np.take_along_axis(np.asarray(reference_fields, dtype=F32), idx[None, None], axis=0)[0]
+    return nb.astype(F32), fields
+
+
+class ProjectiveLocalMapOracle:
+    """reference slam/odometry/local_map.py:91-240 (`ProjectiveLocalMap`)."""
+
+    def __init__(self, height, width, up_fov, down_fov, local_map_size: int = 20, normals_kernel_size: int = 5,
+                 normals_dtype=F32):
+        self.h, self.w, self.up, self.down = height, width, up_fov, down_fov
+        self.size, self.ks = local_map_size, normals_kernel_size
+        self.normals_dtype = normals_dtype
+        self.init()
+
+    def init(self):  # :113-119
+        self.vmaps: List[np.ndarray] = []
+        self.nmaps: List[np.ndarray] = []
+        self.masks: List[np.ndarray] = []
+        self.poses: List[np.ndarray] = []
+        self.model_vmap = None
+        self.model_nmap = None
+
+    def update(self, rel_pose: np.ndarray, new_vertex_map: Optional[np.ndarray] = None):  # :122-174
+        rel_pose = np.asarray(rel_pose, dtype=F32).reshape(4, 4)
+        if new_vertex_map is not None:
+            v = np.asarray(new_vertex_map, dtype=F32).reshape(3, self.h, self.w)
+            nm = compute_normal_map(v, self.ks, self.normals_dtype).astype(F32)
+            mask = np.abs(v).max(axis=0) > 0
+        if not self.vmaps:
+            self.vmaps, self.nmaps, self.masks, self.poses = [v], [nm], [mask], [rel_pose]
+        else:
+            inv = np.linalg.inv(rel_pose)
+            self.poses = [(inv @ p).astype(F32) for p in self.poses]  # :149
+            if new_vertex_map is not None:
+                self.poses.append(np.eye(4, dtype=F32))
+                self.vmaps.append(v)
+                self.nmaps.append(nm)
+                self.masks.append(mask)
+            if len(self.poses) > self.size:  # :166-171
+                self.vmaps, self.nmaps, self.masks, self.poses = self.vmaps[1:], self.nmaps[1:], self.masks[1:], \
+                    self.poses[1:]
+        self.build_model()
+
+    def build_model(self):  # :177-202
+        mv, mn = [], []
+        for v, nm, mask, pose in zip(self.vmaps, self.nmaps, self.masks, self.poses):
+            pts = apply_transformation(vertex_map_to_points(v), pose)
+            nrm = (vertex_map_to_points(nm) @ pose[:3, :3].T).astype(F32)  # apply_rotation, pose.py:154-167
+            m = mask.reshape(-1, 1).astype(F32)
+            pts, nrm = pts * m, nrm * m
+            six = build_projection_map(pts, self.h, self.w, self.up, self.down,
+                                       channels=np.concatenate([pts, nrm], axis=1))
+            mv.append(six[:3])
+            mn.append(six[3:6])
+        self.model_vmap = np.stack(mv)
+        self.model_nmap = np.stack(mn)
+
+    def nearest_neighbor_search(self, pts: np.ndarray):  # :205-235
+        tv = build_projection_map(pts, self.h, self.w, self.up, self.down)
+        nb_v, nb_n = compute_neighbors(tv, self.model_vmap, self.model_nmap)
+        new_points = vertex_map_to_points(tv)
+        nb_points = vertex_map_to_points(nb_v)
+        mask = (np.abs(new_points).max(axis=1) > 0) & (np.abs(nb_points).max(axis=1) > 0)
+        return nb_points[mask], vertex_map_to_points(nb_n)[mask], new_points[mask]
+
+
+class ICPProjectiveOracle:
+    """`ICPFrameToModel` (icp_odometry.py:72-381) with the projective local map and vertex-map input
+    (data_key = "vertex_map", the reference's default): targets = non-null pixels of the scan's own projection."""
+
+    def __init__(self, config: "ICPOracleConfig", normals_dtype=F32):
+        self.config = config
+        c = config
+        self.local_map = ProjectiveLocalMapOracle(c.height, c.width, c.up_fov, c.down_fov, c.local_map_size,
+                                                  normals_dtype=normals_dtype)
+        self.init()
+
+    def init(self):
+        self.local_map.init()
+        self.relative_poses: List[np.ndarray] = []
+        self._iter = 0
+        self._delta = np.eye(4, dtype=F32)
+        self.traces: List["FrameTrace"] = []
+
+    def process_next_frame(self, vmap: np.ndarray, init_rpose: Optional[np.ndarray] = None):
+        c = self.config
+        vmap = np.asarray(vmap, dtype=F32).reshape(3, c.height, c.width)
+        if self._iter == 0:
+            self.local_map.update(np.eye(4, dtype=F32), vmap)
+            self.relative_poses.append(np.eye(4, dtype=F32))
+            self._iter += 1
+            return None
+        pts = vertex_map_to_points(vmap)
+        target = pts[np.sqrt((pts * pts).sum(axis=1, dtype=F32)) > 0.0]  # sample_points, :303-305
+        pose = np.eye(4, dtype=F32) if init_rpose is None else np.asarray(init_rpose).astype(F32)
+        params = np.zeros(6, dtype=F32)
+        trace = FrameTrace()
+        for _ in range(c.max_num_alignments):
+            p = apply_transformation(target, pose)
+            q, n, t = self.local_map.nearest_neighbor_search(p)
+            step = gauss_newton_step(t, q, n, c.scheme, c.sigma, c.accumulate)
+            trace.dx.append(step.dx)
+            trace.loss.append(step.loss)
+            if np.sqrt((step.dx.astype(F32) ** 2).sum(dtype=F32)) < c.threshold_delta_pose:
+                break
+            params = from_pose_matrix((build_pose_matrix(step.dx) @ pose).astype(F32))
+            pose = build_pose_matrix(params)
+        trace.params = params
+        self.traces.append(trace)
+        new_delta = (self._delta @ pose).astype(F32)
+        dp = from_pose_matrix(new_delta)
+        if np.linalg.norm(dp[:3]) > c.threshold_trans or np.linalg.norm(dp[3:]) * 180 / np.pi > c.threshold_rot:
+            self.local_map.update(pose, vmap)
+            self._delta = np.eye(4, dtype=F32)
+        else:
+            self.local_map.update(pose)
+            self._delta = new_delta
+        self.relative_poses.append(pose)
+        self._iter += 1
+        return pose
+
+
+# ======================================================================================================================
 # a7, a8, a17, a18  the frame-to-model ICP driver
 # ======================================================================================================================
 @dataclass

@@ -292,7 +292,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
                             &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->ctable,
-                            &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache};
+                            &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
+                            &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
@@ -592,6 +593,188 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     if ((rc = export_finish(ctx, neighbor_index_out, idev, (size_t)n * 4, out_mem))) return rc;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
+}
+
+// ---- projective local map -------------------------------------------------------------------------------------------
+int icp_compute_normal_map(icp_ctx* ctx, const float* vmap, int mem, int kernel_size, float* nmap_out, int out_mem) {
+    if (!ctx || !vmap || !nmap_out || kernel_size < 1 || kernel_size > 15 || !(kernel_size & 1))
+        return ICP_ERR_INVALID_ARGUMENT;
+    const size_t bytes = (size_t)ctx->cfg.height * ctx->cfg.width * 12;
+    const void* in;
+    int rc = import_buffer(ctx, vmap, bytes, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    void* odev;
+    if ((rc = export_target(ctx, nmap_out, bytes, out_mem, ctx->stage_out, &odev))) return rc;
+    if ((rc = normal_map_device(ctx, (const float*)in, kernel_size, (float*)odev))) return rc;
+    if ((rc = export_finish(ctx, nmap_out, odev, bytes, out_mem))) return rc;
+    if (out_mem == ICP_MEM_HOST || mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_compute_neighbors(icp_ctx* ctx, const float* tgt_vmap, const float* ref_vmaps, const float* ref_fields,
+                          int k_maps, int c_fields, int mem, float* neighbors_out, float* fields_out, int out_mem) {
+    if (!ctx || !tgt_vmap || !ref_vmaps || !neighbors_out || k_maps < 1 || c_fields < 0) return ICP_ERR_INVALID_ARGUMENT;
+    const size_t px = (size_t)ctx->cfg.height * ctx->cfg.width;
+    const void *t, *r, *f = nullptr;
+    int rc = import_buffer(ctx, tgt_vmap, px * 12, mem, ctx->stage_in, &t);
+    if (rc) return rc;
+    if ((rc = import_buffer(ctx, ref_vmaps, px * 12 * k_maps, mem, ctx->targets, &r))) return rc;
+    if (ref_fields && c_fields > 0 &&
+        (rc = import_buffer(ctx, ref_fields, px * 4 * k_maps * c_fields, mem, ctx->pm_tmp, &f)))
+        return rc;
+    void *nb, *fo = nullptr;
+    if ((rc = export_target(ctx, neighbors_out, px * 12, out_mem, ctx->stage_out, &nb))) return rc;
+    if (f && fields_out && (rc = export_target(ctx, fields_out, px * 4 * c_fields, out_mem, ctx->stage_out2, &fo)))
+        return rc;
+    if ((rc = neighbors_device(ctx, (const float*)t, (const float*)r, (const float*)f, k_maps, c_fields, (float*)nb,
+                               (float*)fo)))
+        return rc;
+    if ((rc = export_finish(ctx, neighbors_out, nb, px * 12, out_mem))) return rc;
+    if (fo && (rc = export_finish(ctx, fields_out, fo, px * 4 * c_fields, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_pmap_init(icp_ctx* ctx) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    ctx->pm_slots.clear();
+    ctx->pm_poses.clear();
+    return ICP_OK;
+}
+
+int icp_pmap_num_maps(const icp_ctx* ctx) { return ctx ? (int)ctx->pm_slots.size() : 0; }
+
+int icp_pmap_update(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem, int normals_kernel_size) {
+    if (!ctx || !rel_pose) return ICP_ERR_INVALID_ARGUMENT;
+    if (vmap && (normals_kernel_size < 1 || normals_kernel_size > 15 || !(normals_kernel_size & 1)))
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "normals_kernel_size must be odd, 1..15");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)ctx->cfg.height * ctx->cfg.width * 12;
+    const void* in = nullptr;
+    if (vmap) {
+        if ((rc = import_buffer(ctx, vmap, bytes, mem, ctx->stage_in, &in))) return rc;
+        ICP_HIP(ctx, ctx->pm_tmp.reserve(bytes));
+        if ((rc = normal_map_device(ctx, (const float*)in, normals_kernel_size, ctx->pm_tmp.as<float>()))) return rc;
+    }
+    const int cap = ctx->cfg.local_map_size + 1;
+    auto free_slot = [&]() {
+        for (int s = 0; s < cap; ++s) {
+            bool used = false;
+            for (int u : ctx->pm_slots) used |= (u == s);
+            if (!used) return s;
+        }
+        return -1;
+    };
+    if (ctx->pm_slots.empty()) {
+        if (!vmap) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "the first update needs a vertex map");
+        icp_ctx::PmPose p;
+        memcpy(p.m, rel_pose, sizeof(p.m));  // `_local_map_poses = relative_pose` (local_map.py:147)
+        if ((rc = pmap_store_slot(ctx, 0, (const float*)in, ctx->pm_tmp.as<float>()))) return rc;
+        ctx->pm_slots.push_back(0);
+        ctx->pm_poses.push_back(p);
+    } else {
+        float inv[16];
+        if (!invert4(rel_pose, inv)) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "singular relative pose");
+        for (auto& p : ctx->pm_poses) {  // old_poses = relative_pose.inverse() @ poses (:149)
+            float out[16];
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) {
+                    double a = 0.0;
+                    for (int k = 0; k < 4; ++k) a += (double)inv[4 * r + k] * (double)p.m[4 * k + c];
+                    out[4 * r + c] = (float)a;
+                }
+            memcpy(p.m, out, sizeof(out));
+        }
+        if (vmap) {
+            const int slot = free_slot();
+            if (slot < 0) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "no free projective-map slot");
+            if ((rc = pmap_store_slot(ctx, slot, (const float*)in, ctx->pm_tmp.as<float>()))) return rc;
+            icp_ctx::PmPose eye;
+            memset(eye.m, 0, sizeof(eye.m));
+            eye.m[0] = eye.m[5] = eye.m[10] = eye.m[15] = 1.f;
+            ctx->pm_slots.push_back(slot);
+            ctx->pm_poses.push_back(eye);
+        }
+        if ((int)ctx->pm_poses.size() > ctx->cfg.local_map_size) {  // :166-171
+            ctx->pm_slots.erase(ctx->pm_slots.begin());
+            ctx->pm_poses.erase(ctx->pm_poses.begin());
+        }
+    }
+    if ((rc = pmap_build(ctx))) return rc;
+    if (vmap && mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_pmap_get_model(icp_ctx* ctx, float* model_v4_out, float* model_n4_out, int out_mem) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    const size_t bytes = (size_t)ctx->pm_slots.size() * ctx->cfg.height * ctx->cfg.width * 16;
+    if (bytes == 0) return ICP_OK;
+    const hipMemcpyKind kind = out_mem == ICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (model_v4_out) ICP_HIP(ctx, hipMemcpyAsync(model_v4_out, ctx->pm_mv.ptr, bytes, kind, ctx->stream));
+    if (model_n4_out) ICP_HIP(ctx, hipMemcpyAsync(model_n4_out, ctx->pm_mn.ptr, bytes, kind, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_pmap_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows9_out,
+                                     int64_t* count_out, int out_mem) {
+    if (!ctx || n < 0 || !rows9_out || !count_out) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->pm_slots.empty()) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const size_t npix = (size_t)ctx->cfg.height * ctx->cfg.width;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->targets, &in))) return rc;
+    ICP_HIP(ctx, ctx->pm_tmp.reserve(npix * 36));
+    ICP_HIP(ctx, ctx->flags.reserve(npix * 4));
+    if ((rc = pmap_associate(ctx, (const float*)in, n, ctx->pm_tmp.as<float>(), ctx->flags.as<int>()))) return rc;
+    void* odev;
+    if ((rc = export_target(ctx, rows9_out, npix * 36, out_mem, ctx->stage_out, &odev))) return rc;
+    int* count_dev = ctx->counter.as<int>();
+    if ((rc = compact_rows(ctx, ctx->pm_tmp.as<float>(), ctx->flags.as<int>(), (int64_t)npix, 9, (float*)odev, count_dev)))
+        return rc;
+    int count = 0;
+    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count_out = count;
+    if ((rc = export_finish(ctx, rows9_out, odev, (size_t)count * 36, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
+                      icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    if (!ctx || !result || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->pm_slots.empty()) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->targets, &in))) return rc;
+    ctx->tgt_ptr = (const float*)in;
+    ctx->tgt_n = n;
+    ctx->tgt_mode = target_mode;
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, init_pose, 0))) return rc;
+    if ((rc = init_state(ctx, init_pose))) return rc;
+    ctx->in_registration = true;
+    const int iters = ctx->cfg.max_num_alignments;
+    const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
+    for (int it = 0; it < iters; ++it) {
+        int blocks = 0;
+        rc = pmap_iterate(ctx, &blocks);
+        if (!rc) rc = launch_sum_solve(ctx, blocks);
+        if (rc) {
+            ctx->in_registration = false;
+            return rc;
+        }
+        if (poll > 0 && (it + 1) % poll == 0 && it + 1 < iters) {
+            int done = 0;
+            ICP_HIP(ctx, hipMemcpyAsync(&done, &reg_state(ctx)->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (done) break;
+        }
+    }
+    return icp_register_end(ctx, result, loss_per_iter_out, dx_per_iter_out);
 }
 
 // ---- alignment on given correspondences -----------------------------------------------------------------------------

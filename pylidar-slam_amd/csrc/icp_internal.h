@@ -178,6 +178,11 @@ struct icp_ctx {
     // ---- scratch for projection / sampling / io
     icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
         vals_b, counter;
+    // ---- projective local map (row a19)
+    icp::DeviceBuffer pm_v, pm_n, pm_mv, pm_mn, pm_z, pm_tmp;
+    std::vector<int> pm_slots;                 // storage slot of every kept map, oldest first
+    struct PmPose { float m[16]; };
+    std::vector<PmPose> pm_poses;              // pose of every kept map's frame in the current frame
     icp::Profile prof;
 };
 
@@ -221,6 +226,15 @@ int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const f
 // ---- projection.hip
 int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev);
 int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
+
+// ---- projective.hip
+int normal_map_device(icp_ctx* ctx, const float* vmap_dev, int ks, float* nmap_dev);
+int neighbors_device(icp_ctx* ctx, const float* tgt, const float* ref, const float* fld, int k_maps, int c_fld,
+                     float* nb_out, float* fld_out);
+int pmap_store_slot(icp_ctx* ctx, int slot, const float* vmap_dev, const float* nmap_dev);
+int pmap_build(icp_ctx* ctx);
+int pmap_iterate(icp_ctx* ctx, int* blocks_out);
+int pmap_associate(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows9_dev, int* flags_dev);
 
 // ---- grid_sample.hip
 int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,

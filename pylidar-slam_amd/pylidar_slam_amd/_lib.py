@@ -80,6 +80,14 @@ EXPORTED_SYMBOLS = {
     "icp_map_num_clouds": (_INT, [_P]),
     "icp_map_get": (_INT, [_P, _P, _INT]),
     "icp_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, _P, _P, _INT]),
+    "icp_compute_normal_map": (_INT, [_P, _P, _INT, _INT, _P, _INT]),
+    "icp_compute_neighbors": (_INT, [_P, _P, _P, _P, _INT, _INT, _INT, _P, _P, _INT]),
+    "icp_pmap_init": (_INT, [_P]),
+    "icp_pmap_update": (_INT, [_P, _P, _P, _INT, _INT]),
+    "icp_pmap_num_maps": (_INT, [_P]),
+    "icp_pmap_get_model": (_INT, [_P, _P, _P, _INT]),
+    "icp_pmap_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, C.POINTER(_I64), _INT]),
+    "icp_pmap_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_align_point_to_plane": (_INT, [_P, _P, _P, _P, _I64, _INT, _P, _P, _P, _P]),
     "icp_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_register_begin": (_INT, [_P, _P, _I64, _INT, _INT, _P]),

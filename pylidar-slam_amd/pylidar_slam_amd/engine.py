@@ -249,6 +249,100 @@ class IcpContext:
                 ix.ctypes.data if ix is not None else None, MEM_HOST))
         return nb, nm, ix
 
+    # ---- projective local map (SURVEY §8 row a19) --------------------------------------------------------------------
+    def _planar(self, vmap: Array):
+        """[3,H,W] float32 contiguous -> (pointer, mem, keep-alive)."""
+        h, w = self.config.height, self.config.width
+        if isinstance(vmap, torch.Tensor):
+            t = vmap.to(torch.float32).contiguous()
+            if tuple(t.shape[-3:]) != (3, h, w):
+                raise AssertionError(f"expected a [3,{h},{w}] vertex map, got {tuple(t.shape)}")
+            if t.is_cuda:
+                return t.data_ptr(), MEM_DEVICE, t
+            a = t.numpy()
+            return a.ctypes.data, MEM_HOST, a
+        a = np.ascontiguousarray(vmap, dtype=np.float32)
+        if a.shape[-3:] != (3, h, w):
+            raise AssertionError(f"expected a [3,{h},{w}] vertex map, got {a.shape}")
+        return a.ctypes.data, MEM_HOST, a
+
+    def compute_normal_map(self, vmap: Array, kernel_size: int = 5):
+        p, mem, keep = self._planar(vmap)
+        h, w = self.config.height, self.config.width
+        if mem == MEM_DEVICE:
+            out = torch.empty((3, h, w), dtype=torch.float32, device=keep.device)
+            self._check(self._lib.icp_compute_normal_map(self._h, p, mem, int(kernel_size), out.data_ptr(), MEM_DEVICE))
+            return out
+        out = np.empty((3, h, w), np.float32)
+        self._check(self._lib.icp_compute_normal_map(self._h, p, mem, int(kernel_size), out.ctypes.data, MEM_HOST))
+        return out
+
+    def compute_neighbors(self, vm_target: np.ndarray, vm_reference: np.ndarray,
+                          reference_fields: Optional[np.ndarray] = None):
+        h, w = self.config.height, self.config.width
+        t = np.ascontiguousarray(vm_target, dtype=np.float32).reshape(3, h, w)
+        r = np.ascontiguousarray(vm_reference, dtype=np.float32).reshape(-1, 3, h, w)
+        k = r.shape[0]
+        f = fo = None
+        c = 0
+        if reference_fields is not None:
+            f = np.ascontiguousarray(reference_fields, dtype=np.float32).reshape(k, -1, h, w)
+            c = f.shape[1]
+            fo = np.empty((c, h, w), np.float32)
+        nb = np.empty((3, h, w), np.float32)
+        self._check(self._lib.icp_compute_neighbors(self._h, t.ctypes.data, r.ctypes.data,
+                                                    f.ctypes.data if f is not None else None, k, c, MEM_HOST,
+                                                    nb.ctypes.data, fo.ctypes.data if fo is not None else None,
+                                                    MEM_HOST))
+        return nb, fo
+
+    def pmap_init(self):
+        self._check(self._lib.icp_pmap_init(self._h))
+
+    def pmap_update(self, rel_pose, vmap: Optional[Array] = None, normals_kernel_size: int = 5):
+        if vmap is None:
+            self._check(self._lib.icp_pmap_update(self._h, _pose16(rel_pose), None, MEM_HOST, int(normals_kernel_size)))
+            return
+        p, mem, keep = self._planar(vmap)
+        self._check(self._lib.icp_pmap_update(self._h, _pose16(rel_pose), p, mem, int(normals_kernel_size)))
+
+    def pmap_num_maps(self) -> int:
+        return int(self._lib.icp_pmap_num_maps(self._h))
+
+    def pmap_model(self):
+        """(`_model_vmap` [K,3,H,W], `_model_nmap` [K,3,H,W]) as numpy arrays."""
+        k, h, w = self.pmap_num_maps(), self.config.height, self.config.width
+        v4 = np.empty((k, h * w, 4), np.float32)
+        n4 = np.empty((k, h * w, 4), np.float32)
+        if k:
+            self._check(self._lib.icp_pmap_get_model(self._h, v4.ctypes.data, n4.ctypes.data, MEM_HOST))
+        to_maps = lambda a: np.ascontiguousarray(a[:, :, :3].reshape(k, h, w, 3).transpose(0, 3, 1, 2))
+        return to_maps(v4), to_maps(n4)
+
+    def pmap_nearest_neighbor_search(self, points: Array):
+        """(neighbour points, neighbour normals, new target points), each [n,3], matched pixels in pixel order."""
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        npix = self.config.height * self.config.width
+        rows = np.empty((npix, 9), np.float32)
+        count = C.c_int64(0)
+        self._check(self._lib.icp_pmap_nearest_neighbor_search(self._h, p, n, mem, rows.ctypes.data, C.byref(count),
+                                                               MEM_HOST))
+        r = rows[:count.value]
+        return r[:, 0:3].copy(), r[:, 3:6].copy(), r[:, 6:9].copy()
+
+    def pmap_register(self, points: Array, init_pose=None, skip_null: bool = False) -> RegisterResult:
+        p, mem, keep = _ptr_mem(points)
+        n = int(keep.shape[0])
+        cap = max(1, int(self.config.max_num_alignments))
+        losses = (C.c_double * cap)()
+        dxs = (C.c_float * (6 * cap))()
+        res = IcpRegisterResult()
+        init = _pose16(init_pose if init_pose is not None else np.eye(4))
+        self._check(self._lib.icp_pmap_register(self._h, p, n, mem, TARGETS_SKIP_NULL if skip_null else TARGETS_ALL,
+                                                init, C.byref(res), losses, dxs))
+        return self._result(res, losses, dxs)
+
     # ---- alignment ---------------------------------------------------------------------------------------------------
     def align_point_to_plane(self, ref_points: Array, tgt_points: Array, ref_normals: Array):
         """One Gauss-Newton point-to-plane step: (pose [4,4], dx [6], loss, normal equations [32] f64)."""

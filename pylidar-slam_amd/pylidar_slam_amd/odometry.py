@@ -8,6 +8,7 @@ Same names, argument meaning and error behaviour as the reference classes they s
   ICPFrameToModelConfig            slam/odometry/icp_odometry.py:29-64  MI355XICPConfig
   ICPFrameToModel                  slam/odometry/icp_odometry.py:72-381 MI355XICPFrameToModel
   KdTreeLocalMap                   slam/odometry/local_map.py:254-427   HashGridLocalMap
+  ProjectiveLocalMap               slam/odometry/local_map.py:91-240    ProjectiveLocalMap
   GaussNewtonPointToPlaneAlignment slam/odometry/alignment.py:80-127    PointToPlaneAlignment
   SphericalProjector               slam/common/projection.py:426-508    SphericalProjector
   GridSample / grid_sample         slam/preprocessing.py:207-226        GridSample / grid_sample
@@ -28,6 +29,7 @@ import torch
 from .engine import IcpContext, InvalidJacobianError, RegisterResult  # noqa: F401
 
 __all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap", "Distortion",
+           "ProjectiveLocalMap",
            "DistortionConfig",
            "PointToPlaneAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
            "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
@@ -305,6 +307,48 @@ class HashGridLocalMap:
         return torch.from_numpy(pts[pts.shape[0] - self._last_count:])
 
 
+class ProjectiveLocalMap:
+    """Drop-in for `ProjectiveLocalMap` (slam/odometry/local_map.py:91-240), the reference's "GPU" local map: the last
+    `local_map_size` vertex maps with box-filter normal maps, re-projected into the current frame on every update;
+    neighbours by per-pixel association over the stored maps."""
+
+    def __init__(self, ctx: IcpContext, normals_kernel_size: int = 5, **kwargs):
+        self.ctx = ctx
+        self.normals_kernel_size = normals_kernel_size
+
+    def init(self):  # :113-119
+        self.ctx.pmap_init()
+
+    def update(self, relative_pose, new_vertex_map=None, **kwargs):  # :122-174
+        if isinstance(relative_pose, torch.Tensor):
+            assert_debug(tuple(relative_pose.shape) == (1, 4, 4))
+            relative_pose = relative_pose[0].cpu().numpy()
+        rel = np.asarray(relative_pose, dtype=np.float32)
+        assert_debug(rel.shape == (4, 4))
+        if new_vertex_map is not None:
+            assert_debug(new_vertex_map.ndim == 4 and new_vertex_map.shape[0] == 1 and new_vertex_map.shape[1] == 3)
+            self.ctx.pmap_update(rel, new_vertex_map[0], self.normals_kernel_size)
+        else:
+            self.ctx.pmap_update(rel, None)
+
+    def nearest_neighbor_search(self, target_points, with_normals: bool = True, with_new_target_points: bool = True,
+                                **kwargs) -> NeighborhoodResult:  # :205-235
+        assert_debug(target_points.ndim == 2 and target_points.shape[1] == 3)
+        nb, nm, tg = self.ctx.pmap_nearest_neighbor_search(target_points)
+        is_torch = isinstance(target_points, torch.Tensor)
+        wrap = (lambda a: torch.from_numpy(a).unsqueeze(0)) if is_torch else (lambda a: a[None])
+        res = NeighborhoodResult()
+        res.neighbor_points = wrap(nb)
+        if with_normals:
+            res.neighbor_normals = wrap(nm)
+        if with_new_target_points:
+            res.new_target_points = wrap(tg)
+        return res
+
+    def get_last_frame(self):  # :238-240
+        raise NotImplementedError("the stored vertex maps stay on the device; use IcpContext.pmap_model()")
+
+
 class PointToPlaneAlignment:
     """Drop-in for `GaussNewtonPointToPlaneAlignment.align` (slam/odometry/alignment.py:91-127): one Gauss-Newton
     point-to-plane step from x0 = 0 on given correspondences; returns (pose [1,4,4], params [1,6], loss)."""
@@ -371,8 +415,9 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         assert_debug(projector is not None)
         self.projector = projector
         lm = config.local_map
-        assert_debug(_get(lm, "type", "kdtree_local_map") == "kdtree_local_map",
-                     "only the kd-tree local map semantics are implemented on the MI355X path")
+        self._projective = _get(lm, "type", "kdtree_local_map") == "projective_local_map"
+        assert_debug(self._projective or _get(lm, "type", "kdtree_local_map") == "kdtree_local_map",
+                     f"unknown local map type {_get(lm, 'type')}")
         gn = _get(config.alignment, "gauss_newton_config", {}) or {}
         assert_debug(_get(config.alignment, "mode", "point_to_plane_gauss_newton") == "point_to_plane_gauss_newton",
                      "only the point-to-plane Gauss-Newton alignment is implemented on the MI355X path")
@@ -387,7 +432,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             num_neighbors_normals=int(_get(lm, "num_neighbors_normals", 10)), cell_size=float(config.cell_size),
             max_rings=int(config.max_rings), device=dev_index)
         self.device = self.ctx.device
-        self.local_map = HashGridLocalMap(self.ctx)
+        self.local_map = ProjectiveLocalMap(self.ctx, int(_get(lm, "normals_kernel_size", 5))) if self._projective \
+            else HashGridLocalMap(self.ctx)
         self.rigid_alignment = PointToPlaneAlignment(self.ctx)
         self.gn_max_iters = config.max_num_alignments
         self._sample_pointcloud = False
@@ -459,7 +505,10 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         return self._tgt_pc, self._pc_is_pixels
 
     def register_new_frame(self, target_points, initial_estimate=None, skip_null: bool = False, **kwargs):  # :248-299
-        res = self.ctx.register(target_points, initial_estimate, skip_null=skip_null)
+        if self._projective:
+            res = self.ctx.pmap_register(target_points, initial_estimate, skip_null=skip_null)
+        else:
+            res = self.ctx.register(target_points, initial_estimate, skip_null=skip_null)
         self.last_result = res
         return res.params, res.pose, res.losses
 
@@ -500,6 +549,10 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         dp = from_pose_matrix(new_delta)
         if np.linalg.norm(dp[:3]) > self._register_threshold_trans or \
                 np.linalg.norm(dp[3:]) * 180 / np.pi > self._register_threshold_rot:
+            if self._projective:  # the projective map takes the vertex map (local_map.py:122-131)
+                self.local_map.update(new_rpose, new_vertex_map=self._tgt_vmap.unsqueeze(0))
+                self._delta_since_map_update = np.eye(4, dtype=np.float32)
+                return
             # vertex-map input: `_tgt_pc` = the non-null pixels (:342-344) -> null rows are dropped inside the library
             self.local_map.update(new_rpose, new_pc_data=self._tgt_pc, skip_null=self._pc_is_pixels)
             self._delta_since_map_update = np.eye(4, dtype=np.float32)

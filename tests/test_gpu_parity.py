@@ -393,3 +393,107 @@ def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
               f"{orc.traces[-1].loss[-1]:.4f}, normals computed {res.normals_computed}")
         assert dt < 1e-4 and dr < 1e-4, (scheme, dt, dr)
         np.testing.assert_allclose(res.losses[-1], orc.traces[-1].loss[-1], rtol=1e-3)
+
+
+# ---- projective local map ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_projective():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "projective.npz"))
+
+
+def test_projective_components(torch_cuda, O, golden_projective):
+    g = golden_projective
+    h, w = (int(v) for v in g["hw"])
+    vm = g["vmaps"]
+    ctx = _ctx(height=h, width=w)
+    # compute_neighbors: exact vs the reference's own output (and the reference's property test)
+    nb, nf = ctx.compute_neighbors(vm[1], np.stack([vm[0], vm[2], vm[3]]), g["cn_fields"])
+    np.testing.assert_array_equal(nb, g["cn_neighbors"])
+    np.testing.assert_array_equal(nf, g["cn_neighbor_fields"])
+    rng = np.random.default_rng(1)
+    tgt = rng.normal(size=(3, h, w)).astype(np.float32)
+    ref = rng.normal(size=(10, 3, h, w)).astype(np.float32)
+    tgt[:, 0, 0] = 0.0
+    nb2, _ = ctx.compute_neighbors(tgt, ref)
+    assert np.linalg.norm(nb2[:, 0, 0]) == 0.0
+    np.testing.assert_array_equal(nb2, O.compute_neighbors(tgt, ref)[0])
+    # normal map: float64 window sums on the device = the exact value (tight), which the reference's float32 result
+    # approximates with a median ~3e-4 rad / p99 ~5e-3 rad error (loose)
+    nm = ctx.compute_normal_map(vm[0], 5)
+    exact = O.compute_normal_map(vm[0], 5, dtype=np.float64)
+    both = (np.abs(nm).max(axis=0) > 0) & (np.abs(exact).max(axis=0) > 0)
+    assert ((np.abs(nm).max(axis=0) > 0) == (np.abs(exact).max(axis=0) > 0)).mean() > 0.999
+    ang = np.linalg.norm(np.cross(nm, exact, axis=0), axis=0)[both]  # sin(angle): well conditioned near 0
+    assert ang.max() < 1e-4 and np.median(ang) < 1e-6, (ang.max(), np.median(ang))
+    ref_n = g["nmap0"]
+    v2 = both & (np.abs(ref_n).max(axis=0) > 0)
+    ang_ref = np.linalg.norm(np.cross(nm, ref_n, axis=0), axis=0)[v2]
+    assert np.median(ang_ref) < 1e-3 and np.percentile(ang_ref, 99) < 2e-2
+    dn = ctx.compute_normal_map(torch_cuda.from_numpy(vm[0]).cuda(), 5)
+    assert dn.is_cuda and np.array_equal(dn.cpu().numpy(), nm)
+
+
+def test_projective_map_model_and_search(torch_cuda, O, golden_projective):
+    g = golden_projective
+    h, w = (int(v) for v in g["hw"])
+    vm = g["vmaps"]
+    ctx = _ctx(height=h, width=w, local_map_size=2)
+    orc = O.ProjectiveLocalMapOracle(h, w, 3.0, -24.0, local_map_size=2, normals_dtype=np.float64)
+    rel = O.build_pose_matrix(np.array([0.4, 0.01, -0.01, 0.002, -0.001, 0.01], np.float32))
+    ctx.pmap_init()
+    for k, (pose, v) in enumerate([(np.eye(4, dtype=np.float32), vm[0]), (rel, vm[1]), (rel, None), (rel, vm[2])]):
+        ctx.pmap_update(pose, v)
+        orc.update(pose, v)
+        assert ctx.pmap_num_maps() == len(orc.vmaps)
+    mv, mn = ctx.pmap_model()
+    # the model maps: same pixels occupied, same points (f32 transform rounding), normals within the f64-vs-f32 rounding
+    occ = np.abs(mv).max(axis=1) > 0
+    assert (occ == (np.abs(orc.model_vmap).max(axis=1) > 0)).mean() > 0.9995
+    same = occ & (np.abs(orc.model_vmap).max(axis=1) > 0)
+    dv = np.abs(mv - orc.model_vmap).max(axis=1)[same]
+    assert np.percentile(dv, 99.9) < 1e-4, np.percentile(dv, 99.9)  # a few pixels pick another z-buffer winner
+    # association of a transformed scan
+    pts = O.apply_transformation(O.vertex_map_to_points(vm[3]), rel)
+    pts = pts[np.abs(pts).max(axis=1) > 0]
+    nb, nm, tg = ctx.pmap_nearest_neighbor_search(pts)
+    onb, onm, otg = orc.nearest_neighbor_search(pts)
+    assert abs(nb.shape[0] - onb.shape[0]) <= max(3, onb.shape[0] // 2000)
+    if nb.shape[0] == onb.shape[0]:
+        close = np.abs(nb - onb).max(axis=1) < 1e-4
+        assert close.mean() > 0.998
+        np.testing.assert_array_equal(tg, otg)
+
+
+@pytest.mark.parametrize("run", ["ls", "nbh"])
+def test_projective_icp_sequence(torch_cuda, O, golden_projective, run):
+    """Row a19 end to end behind the plugin surface: `local_map.type = projective_local_map`, vertex-map input.
+    vs the oracle with exact (float64) normals: 1e-4 m / 1e-4 rad; vs the reference's own run: its float32 normal-map
+    noise floor (5e-3 m / 5e-4 rad, see tests/test_oracle.py)."""
+    from pylidar_slam_amd.odometry import MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector
+    g = golden_projective
+    h, w = (int(v) for v in g["hw"])
+    scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
+    cfg = MI355XICPConfig(max_num_alignments=int(iters), threshold_delta_pose=0.0, data_key="vertex_map",
+                          local_map=dict(type="projective_local_map", local_map_size=4),
+                          alignment=dict(mode="point_to_plane_gauss_newton",
+                                         gauss_newton_config=dict(max_iters=1, scheme=scheme, sigma=float(sigma))))
+    odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(h, w), device=torch_cuda.device("cuda:0"))
+    odo.init()
+    oc = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=0.0, scheme=scheme, sigma=float(sigma),
+                           height=h, width=w, local_map_size=4, accumulate=np.float64)
+    orc = O.ICPProjectiveOracle(oc, normals_dtype=np.float64)
+    last = None
+    for f, vm in enumerate(g["vmaps"]):
+        d = {"vertex_map": torch_cuda.from_numpy(vm), "init_rpose": last}
+        odo.process_next_frame(d)
+        opose = orc.process_next_frame(vm, last)
+        if f == 0:
+            continue
+        pose = d["odometry_pose"]
+        last = pose.astype(np.float64)
+        dt, dr = O.pose_error(pose, opose)
+        assert dt < 1e-4 and dr < 1e-4, ("oracle", run, f, dt, dr)
+        if float(thr) == 0.0:  # the reference ran the same forced iteration count
+            dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
+            assert dt < 5e-3 and dr < 5e-4, ("reference", run, f, dt, dr)

@@ -155,3 +155,61 @@ def test_distortion_matches_reference():
         np.testing.assert_array_equal(idx, g[f"{name}_sample_indices"])
     np.testing.assert_allclose(O.distort(g["pc"], np.full(g["pc"].shape[0], 3.0), g["small_rpose"]),
                                g["constant_ts_distorted"], atol=1e-12)
+
+
+# ---- projective local map ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_projective():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "projective.npz"))
+
+
+def test_compute_neighbors_property_like_reference_test():
+    """reference tests/test_geometry.py:6-24: the neighbour is no farther than any of the candidates; a null target
+    pixel yields a null neighbour."""
+    rng = np.random.default_rng(1)
+    tgt = rng.normal(size=(3, 10, 10)).astype(np.float32)
+    ref = rng.normal(size=(10, 3, 10, 10)).astype(np.float32)
+    tgt[:, 0, 0] = 0.0
+    nb, _ = O.compute_neighbors(tgt, ref)
+    assert np.linalg.norm(nb[:, 0, 0]) == 0.0
+    d_nb = np.linalg.norm(nb - tgt, axis=0)
+    d_all = np.linalg.norm(ref - tgt[None], axis=1)
+    assert (d_nb[1:, :] <= d_all[:, 1:, :] + 1e-6).all() and (d_nb[0, 1:] <= d_all[:, 0, 1:] + 1e-6).all()
+
+
+def test_projective_components_match_reference(golden_projective):
+    g = golden_projective
+    vm = g["vmaps"]
+    nb, nf = O.compute_neighbors(vm[1], np.stack([vm[0], vm[2], vm[3]]), g["cn_fields"])
+    np.testing.assert_array_equal(nb, g["cn_neighbors"])
+    np.testing.assert_array_equal(nf, g["cn_neighbor_fields"])
+    # normal maps: the reference's float32 adjugate inverse is noise-dominated (|p| ~ 10-30 m): its own result sits a
+    # median ~3e-4 rad / p99 ~5e-3 rad from the exact (float64) value; both restatements must be that close to it
+    ref = g["nmap0"]
+    exact = O.compute_normal_map(vm[0], 5, dtype=np.float64)
+    f32 = O.compute_normal_map(vm[0], 5)
+    valid = (np.abs(ref).max(axis=0) > 0) & (np.abs(exact).max(axis=0) > 0)
+    assert ((np.abs(ref).max(axis=0) > 0) == (np.abs(f32).max(axis=0) > 0)).mean() > 0.999
+    for cand in (exact, f32):
+        ang = np.linalg.norm(np.cross(cand.astype(np.float64), ref.astype(np.float64), axis=0), axis=0)[valid]
+        assert np.median(ang) < 1e-3 and np.percentile(ang, 99) < 2e-2
+
+
+@pytest.mark.parametrize("run", ["ls", "nbh"])
+def test_projective_icp_sequence_matches_reference(golden_projective, run):
+    """The projective-map odometry restatement against the reference's own run.  Tolerance 5e-3 m / 5e-4 rad: the
+    float32 normal-map noise above moves the reference itself by that much between two summation orders."""
+    g = golden_projective
+    h, w = (int(v) for v in g["hw"])
+    scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
+    cfg = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), scheme=scheme,
+                            sigma=float(sigma), height=h, width=w, local_map_size=4)
+    orc = O.ICPProjectiveOracle(cfg)
+    last = None
+    for f, vm in enumerate(g["vmaps"]):
+        pose = orc.process_next_frame(vm, last)
+        if pose is not None:
+            last = pose.astype(np.float64)
+            dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
+            assert dt < 5e-3 and dr < 5e-4, (f, dt, dr)
