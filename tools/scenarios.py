@@ -56,9 +56,40 @@ def s2():
     print(f"S2 C4-size, 1 GPU: {scans[6].shape[0]} pts vs 1M map, 20 iters: {min(ts)*1e3:.2f} ms (map build + registration), "
           f"normals computed {res.normals_computed}, |t-t_gt| {np.linalg.norm(rel[:3,3]-res.pose[:3,3])*1e3:.2f} mm")
 
+def s3(frames=30):
+    """The reference's published projective configuration (docs/results/KITTI/kitti_benchmark.md:12,21: 116.6 ms/frame on
+    an unnamed CUDA GPU): 64x720 range image, 15 iterations, local map of 20 maps, neighborhood sigma 0.2, CV init."""
+    cfg = SceneConfig(height=64, width=720)
+    scans, gt = make_sequence(cfg, frames)
+    oc = MI355XICPConfig(max_num_alignments=15, threshold_delta_pose=1e-4, data_key="vertex_map",
+                         local_map=dict(type="projective_local_map", local_map_size=20),
+                         alignment=dict(mode="point_to_plane_gauss_newton",
+                                        gauss_newton_config=dict(max_iters=1, scheme="neighborhood", sigma=0.2)))
+    proj = SphericalProjector(64, 720)
+    odo = MI355XICPFrameToModel(oc, projector=proj, device=torch.device("cuda:0"))
+    odo.init(); init = ConstantVelocityInitialization(); init.init()
+    times, errs = [], []
+    for f, s in enumerate(scans):
+        vm = odo.ctx.project(torch.from_numpy(s).cuda())   # the dataset's projection (kitti_dataset.py:249)
+        d = {"vertex_map": vm}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        init.next_frame(d); odo.process_next_frame(d)
+        times.append(time.perf_counter() - t0)
+        if f:
+            init.save_real_motion(d["odometry_pose"], d)
+            rel = np.linalg.inv(gt[f - 1]) @ gt[f]
+            errs.append(np.linalg.norm(rel[:3, 3] - d["odometry_pose"][:3, 3]))
+    t = np.array(times[5:])
+    print(f"S3 projective F2M (64x720, 15 iters max, 20 maps): median {np.median(t)*1e3:.2f} ms/frame "
+          f"({1/np.median(t):.0f} frames/s), maps {odo.ctx.pmap_num_maps()}, iters last {odo.last_result.iterations}, "
+          f"max |t-t_gt| {max(errs)*1e3:.2f} mm")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "s1"):
         s1()
     if which in ("all", "s2"):
         s2()
+    if which in ("all", "s3"):
+        s3()
