@@ -109,6 +109,11 @@ int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_
 int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
                        int out_mem);
 
+/* ---- dataset side: KITTIOdometrySequence.correct_scan (slam/dataset/kitti_dataset.py:202-231) ----------------------
+ * scan [n, stride] float32 rows (stride = 4 for KITTI's x, y, z, reflectance .bin records, 3 for plain xyz) ->
+ * corrected xyz [n,3] float64 (the reference's einsum promotes to float64). */
+int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int stride, int mem, double* xyz_out, int out_mem);
+
 /* ---- voxel grid sampling: voxelise / voxel_hashing / sample_from_hashes (slam/common/pointcloud.py:13-79,170-195),
  * GridSample.filter (slam/preprocessing.py:213-226) -----------------------------------------------------------------
  * indices_out [>= n] int64: original index of the first point of every distinct voxel hash, ordered by ascending

@@ -22,6 +22,7 @@ import numpy as np
 from scipy.spatial import cKDTree
 
 F32 = np.float32
+F64 = np.float64
 
 
 # ======================================================================================================================
@@ -119,6 +120,24 @@ def sample_from_hashes(pc: np.ndarray, hashes: np.ndarray):
 def grid_sample(pc: np.ndarray, voxel: float):
     """reference slam/common/pointcloud.py:182-195 and `GridSample.filter` slam/preprocessing.py:213-226."""
     return sample_from_hashes(pc, voxel_hashing(voxelise(pc, voxel)))
+
+
+def kitti_correct_scan(scan: np.ndarray) -> np.ndarray:
+    """`KITTIOdometrySequence.correct_scan` (slam/dataset/kitti_dataset.py:202-231): every point is rotated by 0.205 deg
+    about u = (p x e_z) / |p x e_z|.  u and the outer products u u^T are float32 as in the reference; cos/sin are float64
+    scalars, so (numpy >= 2 promotion, the stack this oracle is pinned on) the rotation and the result are float64."""
+    p = np.asarray(scan)[:, :3].astype(F32)
+    u = np.stack([p[:, 1], -p[:, 0], np.zeros(p.shape[0], F32)], axis=1)     # p x (0,0,1)
+    u = (u / np.sqrt((u * u).sum(axis=1, keepdims=True, dtype=F32))).astype(F32)
+    theta = 0.205 * np.pi / 180.0
+    c, s = np.float64(np.cos(theta)), np.float64(np.sin(theta))
+    outer = (u[:, :, None] * u[:, None, :]).astype(F32)                       # float32 products (:216)
+    skew = np.zeros((p.shape[0], 3, 3), F32)
+    skew[:, 0, 1], skew[:, 0, 2] = -u[:, 2], u[:, 1]
+    skew[:, 1, 0], skew[:, 1, 2] = u[:, 2], -u[:, 0]
+    skew[:, 2, 0], skew[:, 2, 1] = -u[:, 1], u[:, 0]
+    rot = c * np.eye(3)[None] + s * skew.astype(F64) + (1.0 - c) * outer.astype(F64)
+    return (rot * p.astype(F64)[:, None, :]).sum(axis=2)
 
 
 def distort(pc: np.ndarray, timestamps: np.ndarray, rpose: np.ndarray) -> np.ndarray:

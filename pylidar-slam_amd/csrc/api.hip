@@ -361,6 +361,20 @@ int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float
     return ICP_OK;
 }
 
+int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int stride, int mem, double* xyz_out,
+                           int out_mem) {
+    if (!ctx || n < 0 || stride < 3 || (n > 0 && (!scan || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
+    const void* in;
+    int rc = import_buffer(ctx, scan, (size_t)n * stride * 4, mem, ctx->stage_in, &in);
+    if (rc) return rc;
+    void* odev;
+    if ((rc = export_target(ctx, xyz_out, (size_t)n * 24, out_mem, ctx->stage_out, &odev))) return rc;
+    if ((rc = kitti_correct_device(ctx, (const float*)in, n, stride, (double*)odev))) return rc;
+    if ((rc = export_finish(ctx, xyz_out, odev, (size_t)n * 24, out_mem))) return rc;
+    if (out_mem == ICP_MEM_HOST || mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
 // ---- grid sampling --------------------------------------------------------------------------------------------------
 int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                    int64_t* hashes_out, int out_mem) {

@@ -226,6 +226,7 @@ int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const f
 // ---- projection.hip
 int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev);
 int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
+int kitti_correct_device(icp_ctx* ctx, const float* scan_dev, int64_t n, int stride, double* out_dev);
 
 // ---- projective.hip
 int normal_map_device(icp_ctx* ctx, const float* vmap_dev, int ks, float* nmap_dev);

@@ -84,6 +84,38 @@ __global__ void k_project_pixels(const float* __restrict__ xyz, int n, ProjParam
     cols[i] = col;
 }
 
+// KITTI HDL-64 calibration correction (`KITTIOdometrySequence.correct_scan`, slam/dataset/kitti_dataset.py:202-231):
+// every point is rotated by 0.205 degrees about the axis (p x z) / |p x z| (Rodrigues, float32 like the numpy code;
+// cos/sin of the angle are float64 scalars there, so the products promote to float64 and the einsum result is float64).
+__global__ void k_kitti_correct(const float* __restrict__ scan, int n, int stride, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = scan[(size_t)i * stride], y = scan[(size_t)i * stride + 1], z = scan[(size_t)i * stride + 2];
+    // axes = cross(xyz, [0,0,1]) = (y, -x, 0), normalised in float32 (:209-211)
+    const float nrm = sqrtf(__fadd_rn(__fmul_rn(y, y), __fmul_rn(x, x)));
+    const float ax = y / nrm, ay = -x / nrm;  // az = 0 (0/nrm; NaN only when x = y = 0, as in the reference)
+    const float az = 0.0f / nrm;
+    const double theta = 0.205 * 3.14159265358979323846 / 180.0;
+    const double c = cos(theta), s = sin(theta);
+    // rotations = c * eye + s * u_cross + (1 - c) * u_outer   (:216-228), row i of R times xyz
+    const double o00 = (double)__fmul_rn(ax, ax), o01 = (double)__fmul_rn(ax, ay), o02 = (double)__fmul_rn(ax, az);
+    const double o11 = (double)__fmul_rn(ay, ay), o12 = (double)__fmul_rn(ay, az), o22 = (double)__fmul_rn(az, az);
+    const double r00 = c + (1 - c) * o00, r01 = s * (double)(-az) + (1 - c) * o01, r02 = s * (double)ay + (1 - c) * o02;
+    const double r10 = s * (double)az + (1 - c) * o01, r11 = c + (1 - c) * o11, r12 = s * (double)(-ax) + (1 - c) * o12;
+    const double r20 = s * (double)(-ay) + (1 - c) * o02, r21 = s * (double)ax + (1 - c) * o12, r22 = c + (1 - c) * o22;
+    out[3 * (size_t)i] = r00 * x + r01 * y + r02 * z;
+    out[3 * (size_t)i + 1] = r10 * x + r11 * y + r12 * z;
+    out[3 * (size_t)i + 2] = r20 * x + r21 * y + r22 * z;
+}
+
+int kitti_correct_device(icp_ctx* ctx, const float* scan_dev, int64_t n, int stride, double* out_dev) {
+    if (n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_kitti_correct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, scan_dev, (int)n,
+                       stride, out_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
 static ProjParams proj_params(const icp_ctx* ctx) {
     ProjParams pp;
     pp.height = ctx->cfg.height;

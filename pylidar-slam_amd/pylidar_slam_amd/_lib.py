@@ -68,6 +68,7 @@ EXPORTED_SYMBOLS = {
     "icp_set_alignment": (_INT, [_P, C.c_int32, C.c_float, C.c_int32, C.c_float]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_project_pixels": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
+    "icp_kitti_correct_scan": (_INT, [_P, _P, _I64, _INT, _INT, _P, _INT]),
     "icp_grid_sample": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, C.POINTER(_I64), _INT]),
     "icp_voxel_hash": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, _INT]),
     "icp_grid_sample_f64": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, C.POINTER(_I64), _INT]),

@@ -141,6 +141,16 @@ class IcpContext:
         self._check(self._lib.icp_project_pixels(self._h, p, n, mem, rows.ctypes.data, cols.ctypes.data, MEM_HOST))
         return rows, cols
 
+    def kitti_correct_scan(self, scan: np.ndarray) -> np.ndarray:
+        """`KITTIOdometrySequence.correct_scan`: [N,4] (or [N,3]) float32 -> corrected xyz [N,3] float64."""
+        a = np.ascontiguousarray(scan, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise AssertionError(f"expected [N, >=3] rows, got {a.shape}")
+        out = np.empty((a.shape[0], 3), np.float64)
+        self._check(self._lib.icp_kitti_correct_scan(self._h, a.ctypes.data, int(a.shape[0]), int(a.shape[1]), MEM_HOST,
+                                                     out.ctypes.data, MEM_HOST))
+        return out
+
     # ---- grid sampling -----------------------------------------------------------------------------------------------
     def voxel_hash(self, points: np.ndarray, voxel_size: float):
         p, mem, keep = _ptr_mem(points)

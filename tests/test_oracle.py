@@ -213,3 +213,21 @@ def test_projective_icp_sequence_matches_reference(golden_projective, run):
             last = pose.astype(np.float64)
             dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
             assert dt < 5e-3 and dr < 5e-4, (f, dt, dr)
+
+
+# ---- dataset side ------------------------------------------------------------------------------
+def test_kitti_correct_scan_matches_reference():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kitti_correct.npz"))
+    with np.errstate(all="ignore"):
+        r = O.kitti_correct_scan(g["scan"])
+    assert r.dtype == np.float64
+    # the z-axis point has no rotation axis: NaN in the reference, NaN here
+    assert np.array_equal(np.isnan(r), np.isnan(g["corrected"])) and np.isnan(r).sum() == 3
+    np.testing.assert_allclose(r, g["corrected"], atol=1e-13, equal_nan=True)
+    # a rotation: norms are preserved, the angle to the original direction is 0.205 deg
+    ok = ~np.isnan(r).any(axis=1)
+    p = g["scan"][ok, :3].astype(np.float64)
+    np.testing.assert_allclose(np.linalg.norm(r[ok], axis=1), np.linalg.norm(p, axis=1), rtol=1e-6)
+    cosang = (r[ok] * p).sum(1) / (np.linalg.norm(r[ok], axis=1) * np.linalg.norm(p, axis=1))
+    np.testing.assert_allclose(np.degrees(np.arccos(np.clip(cosang, -1, 1))), 0.205, atol=1e-3)
