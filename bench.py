@@ -11,9 +11,13 @@ One step = one frame of the hot path, everything the reference does per frame on
   spherical projection of the scan (icp_odometry.py:333) -> 20 x [transform, exact 1-NN, lazy kNN normals,
   residual/Jacobian reduction, 6x6 solve, pose update] (:274-297) -> pose read back to the host -> local-map update
   (re-express the 100k map by inv(T), rebuild the search structure, clear the normal cache; local_map.py:346-369).
-The scans form a ping-pong sequence along a trajectory, so every step registers a genuinely moved scan from an
-constant-velocity initial guess (the reference's default initialisation; wrong by twice the motion at the two
-turn-arounds of the ping-pong); nothing is cached between steps.
+The scans form a ping-pong sequence along a trajectory (8 poses 0.4 m / 0.01 rad apart, visited 1..7,6..0,1..), so
+every step registers a genuinely moved scan from a constant-velocity initial guess (the reference's default
+initialisation; wrong by twice the motion at the two turn-arounds of the ping-pong); nothing is cached between steps.
+`--trajectory loop` drives a closed 96-pose circuit instead (steady twist, map made of 8 scans spread around the circuit).
+The host receives the pose of every frame inside its step; the map re-expression is enqueued behind the registration
+with the device-resident pose (icp_register_launch / icp_map_update(NULL) / icp_register_end), so it overlaps the host's
+wait for the pose instead of following a host round trip.
 
 N > 1: one process per GPU, every rank tracks its own independent scan sequence (replicated map, no data-path
 collective) -> weak scaling; `--mode sharded` instead splits every scan's points across the ranks and all-reduces the
@@ -53,26 +57,52 @@ def parse():
     ap.add_argument("--init", choices=["cv", "identity"], default="cv",
                     help="initial guess per frame: constant velocity = last relative pose (the reference's default, "
                          "config/slam.yaml: slam/initialization: CV) or identity (initialization: NI)")
+    ap.add_argument("--trajectory", choices=["pingpong", "loop"], default="pingpong",
+                    help="pingpong: 8 poses of a straight drive (0.4 m, 0.01 rad per frame) visited back and forth, the "
+                         "map made of those scans (the constant-velocity guess is wrong by twice the motion at both "
+                         "ends); loop: a closed 96-pose circuit driven at 0.4 m and 3.75 deg per frame with the map made "
+                         "of 8 scans spread around it (the guess is always right, but most scans are taken up to 2.4 m "
+                         "and 22 deg away from the nearest map scan: longer searches)")
     ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
     return ap.parse_args()
 
 
-def make_workload(rank: int):
-    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+LOOP_PERIOD = 96
+SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
+
+
+def make_workload(rank: int, trajectory: str, frames_needed: int):
+    """Scans (dict frame -> [N,3] f32), ground-truth poses, the fixed 100k-point map (in the frame of pose 0) and the
+    order in which the frames are visited (starting from frame 0's neighbour)."""
+    from pylidar_slam_amd.synthetic import (SceneConfig, loop_trajectory, make_fixed_map, make_sequence, ray_directions,
+                                            render_scan)
     cfg = SceneConfig(height=64, width=2048, seed=1234 + 1000 * rank)
-    scans, poses = make_sequence(cfg, 8)
-    model = make_fixed_map(cfg, scans, poses, ref_frame=0, num_points=100_000)
-    order = list(range(1, 8)) + list(range(6, -1, -1))  # 1..7,6..0 then repeats: consecutive frames are neighbours
+    if trajectory == "pingpong":
+        scans, poses = make_sequence(cfg, 8)
+        model = make_fixed_map(cfg, scans, poses, ref_frame=0, num_points=100_000)
+        order = list(range(1, 8)) + list(range(6, -1, -1))  # 1..7,6..0 then repeats: consecutive frames are neighbours
+        return cfg, dict(enumerate(scans)), poses, model, order
+    poses = loop_trajectory(cfg, LOOP_PERIOD)
+    order = list(range(1, LOOP_PERIOD)) + [0]
+    map_frames = list(range(0, LOOP_PERIOD, LOOP_PERIOD // 8))
+    dirs = ray_directions(cfg)
+    wanted = sorted(set(order[:min(frames_needed, LOOP_PERIOD)]) | set(map_frames))
+    scans = {f: render_scan(cfg, poses[f], f, dirs) for f in wanted}
+    model = make_fixed_map(cfg, [scans[f] for f in map_frames], poses[map_frames], ref_frame=0, num_points=100_000)
     return cfg, scans, poses, model, order
 
 
 def step_replica(ctx, scan_dev, vmap_out, init):
     ctx.project(scan_dev, out=vmap_out)
-    res = ctx.register(scan_dev, init)  # synchronises to return the pose
-    ctx.map_update(res.pose, None)
-    return res
+    if SYNC_STEP:
+        res = ctx.register(scan_dev, init)  # synchronises to return the pose
+        ctx.map_update(res.pose, None)
+        return res
+    ctx.register_launch(scan_dev, init)  # all iterations + the result copy enqueued
+    ctx.map_update(None, None)           # map re-expression by the device-resident result pose, behind the registration
+    return ctx.register_end()            # waits for the registration only: the host gets the pose while the map rebuilds
 
 
 def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, iters, init):
@@ -128,20 +158,20 @@ def main():
     from pylidar_slam_amd.engine import IcpContext
     sharded = args.mode == "sharded" and world > 1
     # replicas: every rank has its own sequence (seed offset); sharded: all ranks share sequence 0
-    cfg, scans, poses, model, order = make_workload(0 if sharded else rank)
-    n_pts = scans[0].shape[0]
+    cfg, scans, poses, model, order = make_workload(0 if sharded else rank, args.trajectory, args.warmup + args.steps)
+    n_pts = scans[order[0]].shape[0]
     ctx = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
                      scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size, device=local_rank)
     ctx.use_torch_stream()
     dev = torch.device("cuda", local_rank)
-    scans_dev = [torch.from_numpy(s).to(dev) for s in scans]
+    scans_dev = {f: torch.from_numpy(s).to(dev) for f, s in scans.items()}
     vmap = torch.empty((3, 64, 2048), dtype=torch.float32, device=dev)
     ctx.map_set(torch.from_numpy(model).to(dev))
     neq = ctx.normal_equations_tensor() if sharded else None
     if sharded:
         from pylidar_slam_amd.distributed import shard_bounds
         b, e = shard_bounds(n_pts, world, rank)
-        slices = [s[b:e].contiguous() for s in scans_dev]
+        slices = {f: s[b:e].contiguous() for f, s in scans_dev.items()}
 
     state = {"last": None, "prev_frame": 0, "max_err": 0.0}
 
@@ -201,12 +231,12 @@ def main():
                        "parallelism": ("points-sharded + RCCL all-reduce of 6x6 normal equations" if sharded else
                                        f"{world} independent sequences (replicated map, no collective)")},
             "last_pose_error_vs_ground_truth_m": gt_err,
-            "max_pose_error_vs_ground_truth_m": state["max_err"], "init": args.init,
+            "max_pose_error_vs_ground_truth_m": state["max_err"], "init": args.init, "trajectory": args.trajectory,
             "iterations_last_frame": int(res.iterations),
         }
         if prof and prof["search_launches"] > 0:
             avg_s = prof["search_ms"] * 1e-3 / prof["search_launches"]
-            n_local = slices[0].shape[0] if sharded else n_pts
+            n_local = slices[order[0]].shape[0] if sharded else n_pts
             achieved = BYTES_PER_POINT_ITER * n_local / avg_s
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_search_kernel.json")

@@ -141,7 +141,8 @@ int icp_map_init(icp_ctx* ctx);                                             /* i
 int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* set_map_pointcloud() :289-299 */
 /* update() :302-362 — move the map by inv(rel), append `new_xyz` (rows with NaN dropped; NULL / n = 0: pose-only
  * update), evict the oldest cloud beyond local_map_size, rebuild the search structure and clear the normal cache.
- * *inserted_out (optional) = number of rows appended. */
+ * *inserted_out (optional) = number of rows appended.  rel_pose = NULL: the pose of the last registration on this
+ * context, read on the device (no host round trip; valid after icp_register / icp_register_launch). */
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out);
 /* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */
@@ -198,6 +199,11 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
  * begin -> { accumulate -> [all-reduce the 32 doubles at icp_normal_equations_ptr over RCCL] -> solve } x iters -> end.
  * Every rank registers its own slice of the target points against a replicated map and applies the identical solve.*/
 int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]);
+/* begin + every iteration enqueued + the result copied to pinned host memory behind the last iteration, without waiting:
+ * work enqueued afterwards on the same context (icp_map_update with rel_pose = NULL: the pose-only branch of
+ * ICPFrameToModel.__update_map, icp_odometry.py:379) overlaps the host's wait in icp_register_end, which then blocks on
+ * the registration only.  With threshold_delta_pose > 0 the launches behind an early stop are device-side no-ops. */
+int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]);
 int icp_iteration_accumulate(icp_ctx* ctx); /* search + normals + reduce into the 32-double device vector */
 int icp_iteration_solve(icp_ctx* ctx);      /* 6x6 solve + pose update from the (possibly all-reduced) vector */
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);

@@ -86,16 +86,68 @@ __global__ void k_state_init(RegState* st, Pose16 init) {
     st->normals_computed = 0;
 }
 
+// general 4x4 inverse in f64 (np.linalg.inv(relative_pose), local_map.py:346); the same code on host and device
+__host__ __device__ inline bool invert4(const float* m, float* out) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = m[4 * r + c];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int k = 0; k < 8; ++k) {
+                const double t = a[c][k];
+                a[c][k] = a[piv][k];
+                a[piv][k] = t;
+            }
+        const double inv = 1.0 / a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+#if defined(__HIP_DEVICE_COMPILE__)
+                for (int k = 0; k < 8; ++k) a[r][k] = __dsub_rn(a[r][k], __dmul_rn(f, a[c][k]));  // no fma: host bits
+#else
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+#endif
+            }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = (float)a[r][4 + c];
+    return true;
+}
+
 // moved = R^-1 x + t^-1 over the kept part of the map (local_map.py:346-348)
-__global__ void k_map_move(const float* __restrict__ in, long long m, Pose16 inv, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+__device__ inline void move_point(const float* T, const float* __restrict__ in, long long i, float* __restrict__ out) {
     const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-    const float* T = inv.m;
     // np.einsum("ij,nj->ni", R, map) + t
     out[3 * i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
     out[3 * i + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
     out[3 * i + 2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
+}
+
+// The relative pose comes by value from the host or, st != nullptr, from the device-resident result of the last
+// registration (no host round trip).  Every block inverts the 4x4 once: one arithmetic for both sources, so the two
+// give the same map bit for bit.
+__global__ void k_map_move(const float* __restrict__ in, long long m, Pose16 rel, const RegState* __restrict__ st,
+                           float* __restrict__ out) {
+    __shared__ float T[16];
+    if (threadIdx.x == 0) {
+        float pose[16], inv[16];
+        for (int k = 0; k < 16; ++k) pose[k] = st ? st->pose[k] : rel.m[k];
+        if (!invert4(pose, inv))  // cannot happen for a pose built from Euler angles; the host path checks beforehand
+            for (int k = 0; k < 16; ++k) inv[k] = (k % 5 == 0) ? 1.f : 0.f;
+        for (int k = 0; k < 16; ++k) T[k] = inv[k];
+    }
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    move_point(T, in, i, out);
 }
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
@@ -167,34 +219,6 @@ static int export_finish(icp_ctx* ctx, void* dst, const void* dev, size_t n_byte
     if (!dst || n_bytes == 0 || out_mem == ICP_MEM_DEVICE) return ICP_OK;
     ICP_HIP(ctx, hipMemcpyAsync(dst, dev, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
     return ICP_OK;
-}
-
-static bool invert4(const float* m, float* out) {
-    // general 4x4 inverse in f64 (np.linalg.inv(relative_pose), local_map.py:346)
-    double a[4][8];
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            a[r][c] = m[4 * r + c];
-            a[r][4 + c] = r == c ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (a[piv][c] == 0.0) return false;
-        if (piv != c)
-            for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
-        const double inv = 1.0 / a[c][c];
-        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
-            }
-    }
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) out[4 * r + c] = (float)a[r][4 + c];
-    return true;
 }
 
 static int ensure_state(icp_ctx* ctx) {
@@ -295,6 +319,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp};
     for (DeviceBuffer* b : bufs) b->release();
+    if (ctx->host_result) (void)hipHostFree(ctx->host_result);
+    if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -501,7 +527,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         ctx->cloud_sizes.push_back(inserted);
     } else {
         float inv[16];
-        if (!invert4(rel_pose, inv)) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "singular relative pose");
+        if (rel_pose && !invert4(rel_pose, inv)) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "singular relative pose");
         // eviction is decided by the number of clouds only (local_map.py:356-360)
         int64_t evict = 0;
         const size_t clouds_after = ctx->cloud_sizes.size() + (has_cloud ? 1 : 0);
@@ -512,11 +538,14 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         DeviceBuffer& dst = ctx->map_xyz[next];
         ICP_HIP(ctx, dst.reserve((size_t)(keep + (has_cloud ? n : 0) + 1) * 12));
         const float* src = ctx->map_xyz[ctx->map_cur].as<float>() + 3 * evict;
-        Pose16 p;
-        memcpy(p.m, inv, sizeof(inv));
-        if (keep > 0)
+        if (keep > 0) {
+            Pose16 p;
+            memset(p.m, 0, sizeof(p.m));
+            if (rel_pose) memcpy(p.m, rel_pose, sizeof(p.m));
             hipLaunchKernelGGL(k_map_move, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, ctx->stream, src,
-                               (long long)keep, p, dst.as<float>());
+                               (long long)keep, p, rel_pose ? (const RegState*)nullptr : (const RegState*)reg_state(ctx),
+                               dst.as<float>());
+        }
         if (has_cloud) {
             int* count_dev = ctx->counter.as<int>();
             if ((rc = compact_rows(ctx, new_dev, flags_dev, n, 3, dst.as<float>() + 3 * keep, count_dev))) return rc;
@@ -537,7 +566,9 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
 
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out) {
-    if (!ctx || !rel_pose || n < 0) return ICP_ERR_INVALID_ARGUMENT;
+    if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
+    if (!rel_pose && !ctx->have_device_pose)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL needs a previous registration on this context");
     const bool has_cloud = new_xyz != nullptr;
     const void* in = nullptr;
     int rc;
@@ -835,6 +866,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
     if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, init_pose, ctx->sort_targets))) return rc;
     if ((rc = init_state(ctx, init_pose))) return rc;
+    ctx->have_device_pose = true;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
     if (!ctx->normals_ready && ctx->map_m <= 2 * n && (rc = launch_normals_all(ctx))) return rc;
@@ -864,19 +896,70 @@ int icp_iteration_solve(icp_ctx* ctx) {
     return launch_solve(ctx);
 }
 
+// layout of the pinned result block: RegState | int stats[4] | double loss[hist_cap] | float dx[6 * hist_cap]
+static size_t host_result_size(const icp_ctx* ctx) {
+    return sizeof(RegState) + 16 + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
+}
+
+// the grid statistics about to be read back belong to the current build; a later build starts a new pending set
+static void snapshot_stats(icp_ctx* ctx) {
+    ctx->stats_at_launch = ctx->stats_pending;
+    ctx->stats_m_at_launch = ctx->stats_m_pending;
+    ctx->stats_h_at_launch = ctx->stats_h_pending;
+    ctx->stats_pending = false;
+}
+
+static int enqueue_result_copy(icp_ctx* ctx) {
+    const size_t need = host_result_size(ctx);
+    if (need > ctx->host_result_bytes) {
+        if (ctx->host_result) (void)hipHostFree(ctx->host_result);
+        ctx->host_result = nullptr;
+        ctx->host_result_bytes = 0;
+        ICP_HIP(ctx, hipHostMalloc(&ctx->host_result, need, hipHostMallocDefault));
+        ctx->host_result_bytes = need;
+    }
+    if (!ctx->result_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->result_event, hipEventDisableTiming));
+    char* h = (char*)ctx->host_result;
+    ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sizeof(RegState), hipMemcpyDeviceToHost, ctx->stream));
+    snapshot_stats(ctx);
+    if (ctx->stats_at_launch)
+        ICP_HIP(ctx, hipMemcpyAsync(h + sizeof(RegState), ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->hist_cap > 0) {
+        char* lh = h + sizeof(RegState) + 16;
+        ICP_HIP(ctx, hipMemcpyAsync(lh, ctx->loss_hist.ptr, (size_t)ctx->hist_cap * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        ICP_HIP(ctx, hipMemcpyAsync(lh + (size_t)ctx->hist_cap * sizeof(double), ctx->dx_hist.ptr,
+                                    (size_t)ctx->hist_cap * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ICP_HIP(ctx, hipEventRecord(ctx->result_event, ctx->stream));
+    ctx->result_pending = true;
+    return ICP_OK;
+}
+
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     if (!ctx || !ctx->in_registration || !result) return ICP_ERR_INVALID_ARGUMENT;
     ctx->in_registration = false;
     RegState st;
     int stats[4] = {0, 0, 0, 0};
-    ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->stats_pending)
-        ICP_HIP(ctx, hipMemcpyAsync(stats, ctx->grid_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
-    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->stats_pending) {
+    const bool async = ctx->result_pending;
+    if (!async) snapshot_stats(ctx);
+    const bool had_stats = ctx->stats_at_launch;
+    if (async) {  // copies were enqueued right behind the last iteration: wait for those only
+        ctx->result_pending = false;
+        ICP_HIP(ctx, hipEventSynchronize(ctx->result_event));
+        memcpy(&st, ctx->host_result, sizeof(st));
+        memcpy(stats, (const char*)ctx->host_result + sizeof(RegState), sizeof(stats));
+    } else {
+        ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        if (had_stats)
+            ICP_HIP(ctx, hipMemcpyAsync(stats, ctx->grid_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
+        ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->stats_at_launch) {
         ctx->occupied_cells = stats[0];
-        ctx->stats_m = ctx->stats_m_pending;
-        ctx->stats_pending = false;
+        ctx->stats_m = ctx->stats_m_at_launch;
+        ctx->stats_h = ctx->stats_h_at_launch;
+        ctx->stats_at_launch = false;
     }
     if (ctx->search_stats) {
         int c[8];
@@ -896,24 +979,28 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     result->num_targets = st.n_targets;
     result->normals_computed = st.normals_computed;
     const int k = st.iter < ctx->hist_cap ? st.iter : ctx->hist_cap;
-    if (k > 0 && loss_per_iter_out)
-        ICP_HIP(ctx, hipMemcpy(loss_per_iter_out, ctx->loss_hist.ptr, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
-    if (k > 0 && dx_per_iter_out)
-        ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist.ptr, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    if (async) {
+        const char* lh = (const char*)ctx->host_result + sizeof(RegState) + 16;
+        if (k > 0 && loss_per_iter_out) memcpy(loss_per_iter_out, lh, (size_t)k * sizeof(double));
+        if (k > 0 && dx_per_iter_out)
+            memcpy(dx_per_iter_out, lh + (size_t)ctx->hist_cap * sizeof(double), (size_t)k * 6 * sizeof(float));
+    } else {
+        if (k > 0 && loss_per_iter_out)
+            ICP_HIP(ctx, hipMemcpy(loss_per_iter_out, ctx->loss_hist.ptr, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
+        if (k > 0 && dx_per_iter_out)
+            ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist.ptr, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    }
     if (ctx->prof.enabled) prof_collect(ctx);
     if (st.status == ICP_ERR_INVALID_JACOBIAN)
         return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
     return st.status;
 }
 
-int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
-                 icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
-    if (!ctx || !result) return ICP_ERR_INVALID_ARGUMENT;
-    int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
-    if (rc) return rc;
+static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
+    int rc = ICP_OK;
     const int iters = ctx->cfg.max_num_alignments;
     // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
-    const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
+    const int poll = (poll_allowed && ctx->cfg.threshold_delta_pose > 0.f) ? ctx->cfg.poll_every : 0;
     for (int it = 0; it < iters; ++it) {
         if (fused_path(ctx)) {
             int blocks = 0;
@@ -933,6 +1020,28 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
             if (done) break;
         }
     }
+    return ICP_OK;
+}
+
+int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]) {
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
+    if (rc) return rc;
+    // every iteration is enqueued; launches behind an early stop see `done` on the device and return immediately
+    if ((rc = enqueue_iterations(ctx, false))) return rc;
+    if ((rc = enqueue_result_copy(ctx))) {
+        ctx->in_registration = false;
+        return rc;
+    }
+    return ICP_OK;
+}
+
+int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
+                 icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    if (!ctx || !result) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
+    if (rc) return rc;
+    if ((rc = enqueue_iterations(ctx, true))) return rc;
     return icp_register_end(ctx, result, loss_per_iter_out, dx_per_iter_out);
 }
 

@@ -307,11 +307,15 @@ int build_grid(icp_ctx* ctx) {
     if (ctx->cfg.cell_size > 0.f) {
         ctx->cell_h = ctx->cfg.cell_size;
     } else if (ctx->occupied_cells > 0 && ctx->stats_m > 0) {
+        // the occupancy figure belongs to the build it was measured on (edge stats_h) — with the asynchronous result
+        // hand-off that may be the build before the previous one
         const double mean = (double)ctx->stats_m / (double)ctx->occupied_cells;
         double f = sqrt(ctx->target_occupancy / mean);
         if (f < 0.5) f = 0.5;
         if (f > 2.0) f = 2.0;
-        if (f < 0.85 || f > 1.18) ctx->cell_h = (float)fmin(fmax(ctx->cell_h * f, 0.05), 8.0);
+        const double wanted = fmin(fmax((double)ctx->stats_h * f, 0.05), 8.0);
+        const double change = wanted / (double)ctx->cell_h;
+        if (change < 0.85 || change > 1.18) ctx->cell_h = (float)wanted;
     }
     const float inv_h = 1.0f / ctx->cell_h;
     ICP_HIP(ctx, ctx->grid_stats.reserve(16));
@@ -319,6 +323,7 @@ int build_grid(icp_ctx* ctx) {
     ctx->normals_ready = false;
     ctx->stats_pending = true;
     ctx->stats_m_pending = m;
+    ctx->stats_h_pending = ctx->cell_h;
     const unsigned tb = (tsize + 255) / 256, mb = (unsigned)((m + 255) / 256);
     hipLaunchKernelGGL(k_grid_clear, dim3(tb), dim3(256), 0, ctx->stream, table, tsize);
     hipLaunchKernelGGL(k_grid_insert, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, table, tsize - 1,

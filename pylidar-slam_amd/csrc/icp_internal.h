@@ -151,6 +151,10 @@ struct icp_ctx {
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
+    float stats_h = 0.f, stats_h_pending = 0.f;  // cell edge of the build the figure was measured on
+    bool stats_at_launch = false;      // a grid-stats copy travels with the result being read back
+    int64_t stats_m_at_launch = 0;
+    float stats_h_at_launch = 0.f;
     // ---- registration
     icp::DeviceBuffer targets;         // staged copy of host targets
     const float* tgt_ptr = nullptr;    // device pointer of the current targets
@@ -175,6 +179,13 @@ struct icp_ctx {
     int hist_cap = 0;
     int reduce_blocks = 0;
     bool in_registration = false;
+    // asynchronous result hand-off (icp_register_launch): state + grid stats + histories copied to pinned host memory
+    // behind the last iteration, `result_event` recorded after the copies
+    bool have_device_pose = false;   // RegState holds the pose of a finished / enqueued registration
+    bool result_pending = false;
+    void* host_result = nullptr;
+    size_t host_result_bytes = 0;
+    hipEvent_t result_event = nullptr;
     // ---- scratch for projection / sampling / io
     icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
         vals_b, counter;

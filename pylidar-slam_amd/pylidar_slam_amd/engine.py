@@ -218,7 +218,8 @@ class IcpContext:
             p = keep.ctypes.data
             mem = MEM_HOST
         ins = C.c_int64(0)
-        self._check(self._lib.icp_map_update(self._h, _pose16(rel_pose), p, n, mem,
+        # rel_pose None: the device-resident pose of the last registration (no host round trip)
+        self._check(self._lib.icp_map_update(self._h, _pose16(rel_pose) if rel_pose is not None else None, p, n, mem,
                                              TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, C.byref(ins)))
         return int(ins.value)
 
@@ -406,6 +407,15 @@ class IcpContext:
         init = _pose16(init_pose if init_pose is not None else np.eye(4))
         self._check(self._lib.icp_register_begin(self._h, p, int(keep.shape[0]), mem,
                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init))
+
+    def register_launch(self, points: Array, init_pose=None, skip_null: bool = False):
+        """Enqueue a whole registration without waiting; `register_end()` later blocks on it alone, so work enqueued in
+        between (e.g. `map_update(None)`) overlaps the host's wait."""
+        p, mem, keep = _ptr_mem(points)
+        self._keep_targets = keep
+        init = _pose16(init_pose if init_pose is not None else np.eye(4))
+        self._check(self._lib.icp_register_launch(self._h, p, int(keep.shape[0]), mem,
+                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init))
 
     def iteration_accumulate(self):
         self._check(self._lib.icp_iteration_accumulate(self._h))

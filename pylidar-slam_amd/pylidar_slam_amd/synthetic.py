@@ -87,6 +87,23 @@ def trajectory(cfg: SceneConfig, num_frames: int) -> np.ndarray:
     return poses
 
 
+def loop_trajectory(cfg: SceneConfig, period: int = 96, centre=(1.5, -5.0)) -> np.ndarray:
+    """Closed circuit [period, 4, 4] float64 (world <- sensor): a circle driven at `cfg.step` m per frame (radius
+    step * period / 2 pi = 6.1 m for the defaults, 3.75 deg of yaw per frame, >= 3.9 m clear of every box) with
+    periodic wobble, so pose[period] == pose[0] and every consecutive relative motion is (nearly) the same twist: the
+    steady-driving regime in which a constant-velocity initial guess is right, for arbitrarily long runs."""
+    radius = cfg.step * period / (2.0 * np.pi)
+    poses = np.zeros((period, 4, 4))
+    for f in range(period):
+        a = 2.0 * np.pi * f / period
+        roll = 0.002 * np.sin(5.0 * a)
+        pitch = 0.002 * np.sin(3.0 * a + 1.0)
+        z = 0.02 * np.sin(4.0 * a)
+        poses[f] = pose_matrix(np.array([centre[0] + radius * np.sin(a), centre[1] - radius * np.cos(a), z,
+                                         roll, pitch, a]))
+    return poses
+
+
 def _ray_box_exit(o, d, box):
     """Distance at which rays starting INSIDE the box leave it (slab method)."""
     lo = np.array([box[0], box[2], box[4]])

@@ -358,6 +358,35 @@ def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_component
     np.testing.assert_allclose((parts[0] + parts[1]).cpu().numpy(), whole.cpu().numpy(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("threshold", [0.0, 1e-3])
+def test_async_register_and_device_pose_map_update_are_bit_identical(torch_cuda, golden_components, threshold):
+    """icp_register_launch + icp_map_update(rel_pose = NULL) + icp_register_end (no host round trip between the
+    registration and the map re-expression) against the synchronous sequence: same poses, losses and map, frame after
+    frame — including the early-stop case where the launches behind the stop are device-side no-ops."""
+    g = golden_components
+    q = g["nn_queries"]
+    rng = np.random.default_rng(5)
+    frames = [q, (q + rng.normal(0, 0.01, q.shape)).astype(np.float32), q[::2].copy()]
+    a = _ctx(max_num_alignments=8, threshold_delta_pose=threshold)
+    b = _ctx(max_num_alignments=8, threshold_delta_pose=threshold)
+    a.map_set(g["nn_map"])
+    b.map_set(g["nn_map"])
+    with pytest.raises(AssertionError):
+        b.map_update(None, None)  # no registration yet: nothing to take the pose from
+    init = None
+    for f in frames:
+        ra = a.register(f, init)
+        a.map_update(ra.pose, None)
+        b.register_launch(f, init)
+        b.map_update(None, None)
+        rb = b.register_end()
+        assert np.array_equal(ra.pose, rb.pose) and ra.iterations == rb.iterations
+        assert np.array_equal(ra.losses, rb.losses) and np.array_equal(ra.dx, rb.dx)
+        assert np.array_equal(a.map_points(), b.map_points())
+        init = ra.pose
+    assert ra.iterations == 8 if threshold == 0.0 else ra.iterations <= 8
+
+
 def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
     """BASELINE.json configs[1]: 64x2048 scan (131072 points) vs a 100k-point map, 20 forced iterations, for the three
     schemes of BASELINE.md; pose within 1e-4 m / 1e-4 rad of the oracle, plus exactness of the search on a sample."""
