@@ -616,20 +616,30 @@ __device__ inline void smallest_eigenvector(float a00, float a01, float a02, flo
             }
         }
     }
-    int m = 2;  // ties -> the last axis, like vh[2] of an already diagonal input
-    if (A[1][1] < A[m][m]) m = 1;
-    if (A[0][0] < A[m][m]) m = 0;
-    const float x = V[0][m], y = V[1][m], z = V[2][m];
+    // ties -> the last axis, like vh[2] of an already diagonal input (selects, not indexing: V stays in registers)
+    float lam = A[2][2], x = V[0][2], y = V[1][2], z = V[2][2];
+    if (A[1][1] < lam) {
+        lam = A[1][1];
+        x = V[0][1];
+        y = V[1][1];
+        z = V[2][1];
+    }
+    if (A[0][0] < lam) {
+        x = V[0][0];
+        y = V[1][0];
+        z = V[2][0];
+    }
     const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
     nx = x * inv;
     ny = y * inv;
     nz = z * inv;
 }
 
+// covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32:
+// cov = {c00, c01, c02, c11, c12, c22}
 template <int KN>
-__device__ inline void finish_normal(const GridView& g, int s, float px, float py, float pz, const TopK<KN>& t,
-                                     float4* __restrict__ normals, int* __restrict__ nflag) {
-    // covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32
+__device__ inline void neighbourhood_cov(const GridView& g, float px, float py, float pz, const TopK<KN>& t,
+                                         float* __restrict__ cov) {
     float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     int used = 0;
 #pragma unroll
@@ -646,11 +656,18 @@ __device__ inline void finish_normal(const GridView& g, int s, float px, float p
         ++used;
     }
     const float invk = used > 0 ? 1.0f / (float)used : 0.f;
+    cov[0] = c00 * invk;
+    cov[1] = c01 * invk;
+    cov[2] = c02 * invk;
+    cov[3] = c11 * invk;
+    cov[4] = c12 * invk;
+    cov[5] = c22 * invk;
+}
+
+__device__ inline void normal_from_cov(const float* __restrict__ cov, int s, float4* __restrict__ normals,
+                                       int* __restrict__ nflag) {
     float nx, ny, nz;
-    if (g_debug_flags & 1) {
-        nx = c00 * invk; ny = c01 * invk + c11; nz = c22 + c12 + c02;
-    } else
-    smallest_eigenvector(c00 * invk, c01 * invk, c02 * invk, c11 * invk, c12 * invk, c22 * invk, nx, ny, nz);
+    smallest_eigenvector(cov[0], cov[1], cov[2], cov[3], cov[4], cov[5], nx, ny, nz);
     normals[s] = make_float4(nx, ny, nz, 1.f);
     nflag[s] = 1;
 }
@@ -761,14 +778,15 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
     return false;
 }
 
-// Normal of one map point by FOUR lanes.  A map point always lies in an occupied cell, so its 27-neighbourhood comes
+// Neighbourhood covariance of one map point by FOUR lanes (lane 0 of the group writes cov[6]); the eigen-solve that turns
+// it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  A map point always lies in an occupied cell, so its 27-neighbourhood comes
 // from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
 // neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
 // pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
 // level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
 template <int KN>
-__device__ inline void estimate_normal(const GridView& g, int s, int sub, int max_rings, float4* __restrict__ normals,
-                                       int* __restrict__ nflag, int2* __restrict__ stack, int stride) {
+__device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
+                                    int2* __restrict__ stack, int stride) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     TopK<KN> t;
@@ -837,7 +855,7 @@ __device__ inline void estimate_normal(const GridView& g, int s, int sub, int ma
         }
     }
     if (sub != 0) return;
-    finish_normal<KN>(g, s, px, py, pz, m, normals, nflag);
+    neighbourhood_cov<KN>(g, px, py, pz, m, cov);
 }
 
 // merge of the four lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
@@ -861,29 +879,46 @@ __device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m) {
     }
 }
 
+// Block = NRM_POINTS map points x 4 lanes: the 4-lane groups leave their covariances in LDS, then the first
+// NRM_POINTS threads (whole waves, every lane busy) run the Jacobi eigen-solves — a 4-lane group would otherwise spend
+// the ~1.5k-instruction solve with one lane in four active.
+static constexpr int NRM_POINTS = 64;
+static constexpr int NRM_THREADS = 4 * NRM_POINTS;
+
 // lazy: the map points queued by the search of this iteration
 template <int KN>
-__global__ __launch_bounds__(128) void k_normals(GridView g, RegState* __restrict__ st,
-                                                 const int* __restrict__ worklist, int max_rings,
-                                                 float4* __restrict__ normals, int* __restrict__ nflag) {
+__global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
+                                                         const int* __restrict__ worklist, int max_rings,
+                                                         float4* __restrict__ normals, int* __restrict__ nflag) {
     if (st->done) return;
-    __shared__ int2 cellstack[7][128];
+    __shared__ int2 cellstack[7][NRM_THREADS];
+    __shared__ float covs[NRM_POINTS][7];
     const int nw = st->n_worklist;
-    const int sub = threadIdx.x & 3;
-    for (int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; w < nw; w += (gridDim.x * blockDim.x) >> 2)
-        estimate_normal<KN>(g, worklist[w], sub, max_rings, normals, nflag, &cellstack[0][threadIdx.x], 128);
+    const int sub = threadIdx.x & 3, lq = threadIdx.x >> 2;
+    for (int base = blockIdx.x * NRM_POINTS; base < nw; base += gridDim.x * NRM_POINTS) {  // block-uniform trip count
+        const int w = base + lq;
+        if (w < nw) estimate_cov<KN>(g, worklist[w], sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+        __syncthreads();
+        if (threadIdx.x < NRM_POINTS && base + (int)threadIdx.x < nw)
+            normal_from_cov(covs[threadIdx.x], worklist[base + threadIdx.x], normals, nflag);
+        __syncthreads();
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
 }
 
 // eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values
 // are the same either way: a normal depends on the map only)
 template <int KN>
-__global__ __launch_bounds__(128) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
-                                                     int* __restrict__ nflag) {
-    __shared__ int2 cellstack[7][128];
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = gid >> 2;
-    if (s < g.m) estimate_normal<KN>(g, s, gid & 3, max_rings, normals, nflag, &cellstack[0][threadIdx.x], 128);
+__global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
+                                                             int* __restrict__ nflag) {
+    __shared__ int2 cellstack[7][NRM_THREADS];
+    __shared__ float covs[NRM_POINTS][7];
+    const int lq = threadIdx.x >> 2;
+    const int s = blockIdx.x * NRM_POINTS + lq;
+    if (s < g.m) estimate_cov<KN>(g, s, threadIdx.x & 3, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+    __syncthreads();
+    const int s2 = blockIdx.x * NRM_POINTS + threadIdx.x;
+    if (threadIdx.x < NRM_POINTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -1029,17 +1064,17 @@ int launch_normals_all(icp_ctx* ctx) {
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
-    const int blocks = (int)((ctx->map_m * 4 + 127) / 128);
+    const int blocks = (int)((ctx->map_m + NRM_POINTS - 1) / NRM_POINTS);
     GridView g = make_view(ctx);
     const int tok = prof_begin(ctx, 2);
     if (kn == 11)
-        hipLaunchKernelGGL(k_normals_all<11>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+        hipLaunchKernelGGL(k_normals_all<11>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
                            ctx->normals.as<float4>(), ctx->nflag.as<int>());
     else if (kn == 6)
-        hipLaunchKernelGGL(k_normals_all<6>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+        hipLaunchKernelGGL(k_normals_all<6>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
                            ctx->normals.as<float4>(), ctx->nflag.as<int>());
     else
-        hipLaunchKernelGGL(k_normals_all<21>, dim3(blocks), dim3(128), 0, ctx->stream, g, ctx->cfg.max_rings,
+        hipLaunchKernelGGL(k_normals_all<21>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
                            ctx->normals.as<float4>(), ctx->nflag.as<int>());
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
@@ -1070,21 +1105,21 @@ int launch_normals(icp_ctx* ctx) {
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     // the worklist length lives on the device: launch a fixed grid and stride over it
     int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
-    int blocks = (int)((cap * 4 + 127) / 128);  // 4 lanes per queued map point
+    int blocks = (int)((cap + NRM_POINTS - 1) / NRM_POINTS);  // 4 lanes per queued map point
     if (blocks < 1) blocks = 1;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 4096) blocks = 4096;
     const int tok = prof_begin(ctx, 2);
     GridView g = make_view(ctx);
     if (kn == 11) {
-        hipLaunchKernelGGL(k_normals<11>, dim3(blocks), dim3(128), 0, ctx->stream, g, reg_state(ctx),
+        hipLaunchKernelGGL(k_normals<11>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
                            ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
                            ctx->nflag.as<int>());
     } else if (kn == 6) {
-        hipLaunchKernelGGL(k_normals<6>, dim3(blocks), dim3(128), 0, ctx->stream, g, reg_state(ctx),
+        hipLaunchKernelGGL(k_normals<6>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
                            ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
                            ctx->nflag.as<int>());
     } else if (kn == 21) {
-        hipLaunchKernelGGL(k_normals<21>, dim3(blocks), dim3(128), 0, ctx->stream, g, reg_state(ctx),
+        hipLaunchKernelGGL(k_normals<21>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
                            ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
                            ctx->nflag.as<int>());
     } else {
