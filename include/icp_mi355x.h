@@ -189,6 +189,18 @@ int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float*
                              int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
                              double* normal_eq_out);
 
+/* GaussNewtonPointToPointAlignment.align (slam/odometry/alignment.py:143-189) on given correspondences: one
+ * Gauss-Newton step of PointToPointCost (slam/common/optimization.py:458-560) linearised at x0 (NULL = zeros; with
+ * `initialize_with_svd` the caller passes from_pose_matrix(icp_weighted_procrustes(...))).  params_out = x0 + dx,
+ * pose_out = build_pose_matrix(params_out); loss_out / normal_eq_out as above. */
+int icp_align_point_to_point(icp_ctx* ctx, const float* ref_points, const float* tgt_points, int64_t n, int mem,
+                             const float x0[6], float params_out[6], float pose_out[16], double* loss_out,
+                             double* normal_eq_out);
+/* weighted_procrustes (slam/common/registration.py:15-74): closed-form rigid transform target -> reference.  weights
+ * [n] float32 or NULL (ones); as in the reference they enter the centroids only.  pose_out row-major 4x4 float64. */
+int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* ref_points, const float* weights,
+                            int64_t n, int mem, double pose_out[16]);
+
 /* ---- registration: ICPFrameToModel.register_new_frame (slam/odometry/icp_odometry.py:248-299) --------------------
  * All iterations run on the device without host round trips.  loss_per_iter_out / dx_per_iter_out (optional) receive
  * `iterations` entries ([.] double, [.,6] float). */

@@ -287,6 +287,70 @@ def gauss_newton_step(tgt: np.ndarray, ref: np.ndarray, normals: np.ndarray, sch
 
 
 # ======================================================================================================================
+# §8f-4  point-to-point Gauss-Newton step and weighted Procrustes
+# ======================================================================================================================
+def euler_jacobian(angles, dtype=F32) -> np.ndarray:
+    """reference slam/common/rotation.py:166-187: [3,3,3] = d(Rz Ry Rx)/d(ex, ey, ez)."""
+    ex, ey, ez = (dtype(a) for a in angles)
+    cx, sx, cy, sy, cz, sz = np.cos(ex), np.sin(ex), np.cos(ey), np.sin(ey), np.cos(ez), np.sin(ez)
+    z, o = dtype(0), dtype(1)
+    rx = np.array([[o, z, z], [z, cx, -sx], [z, sx, cx]], dtype)
+    ry = np.array([[cy, z, sy], [z, o, z], [-sy, z, cy]], dtype)
+    rz = np.array([[cz, -sz, z], [sz, cz, z], [z, z, o]], dtype)
+    jx = np.array([[z, z, z], [z, -sx, -cx], [z, cx, -sx]], dtype)
+    jy = np.array([[-sy, z, cy], [z, z, z], [-cy, z, -sy]], dtype)
+    jz = np.array([[-sz, -cz, z], [cz, -sz, z], [z, z, z]], dtype)
+    return np.stack([rz @ ry @ jx, rz @ jy @ rx, jz @ ry @ rx]).astype(dtype)
+
+
+def point_to_point_step(tgt: np.ndarray, ref: np.ndarray, x0=None, scheme: str = "default", sigma: float = 0.5,
+                        accumulate=F32):
+    """`GaussNewtonPointToPointAlignment.align` (slam/odometry/alignment.py:143-189) = one `GaussNewton.compute`
+    iteration (optimization.py:296-344) of `PointToPointCost` (:458-560) linearised at x0:
+    r_i = ||T(x0) p_i - q_i||, J_ik = (dT/dx_k p_i) . (T(x0) p_i - q_i) — the reference's own unnormalised form.
+    Returns (pose [4,4] f32, params [6] f32 = x0 + dx, loss)."""
+    x0 = np.zeros(6, F32) if x0 is None else np.asarray(x0, F32)
+    p, q = tgt.astype(F32), ref.astype(F32)
+    T0 = build_pose_matrix(x0)
+    d = (apply_transformation(p, T0) - q).astype(F32)
+    res = np.sqrt((d * d).sum(axis=-1, dtype=F32))
+    dR = euler_jacobian(x0[3:])
+    jac = np.concatenate([d, np.stack([((p @ dR[k].T).astype(F32) * d).sum(axis=-1, dtype=F32) for k in range(3)], 1)],
+                         axis=1).astype(F32)
+    if np.sqrt((res.astype(np.float64) ** 2).sum()) < 1.0e-7:
+        return T0, x0, float((res * res).sum())
+    w = ls_weights(scheme, sigma, res, p, q)  # neighborhood sees the raw target points (alignment.py:183)
+    res = (res * w).astype(F32)
+    jac = (jac * w.reshape(-1, 1)).astype(F32)
+    ja, ra = jac.astype(accumulate), res.astype(accumulate)
+    H = ja.T @ ja
+    if abs(np.linalg.det(H)) < 1.0e-7:
+        raise RuntimeError("Invalid Jacobian in Gauss Newton minimization")
+    dx = -(np.linalg.inv(H) @ (ja.T @ ra))
+    params = (x0 + dx.astype(F32)).astype(F32)
+    return build_pose_matrix(params), params, float((ra * ra).sum())
+
+
+def weighted_procrustes(tgt: np.ndarray, ref: np.ndarray, weights: Optional[np.ndarray] = None) -> np.ndarray:
+    """reference slam/common/registration.py:15-74 (numpy branch): weighted centroids in the dtype of the points, the
+    cross-covariance of the centred clouds in float64 WITHOUT the weights (as there), R = U S V^T, t = mu_ref - R mu_tgt."""
+    dt = tgt.dtype
+    w = np.ones((tgt.shape[0], 1), dt) if weights is None else np.asarray(weights, dt).reshape(-1, 1)
+    aw = w / w.sum(axis=0)
+    mu_t = (tgt * aw).sum(axis=0).reshape(1, 3)
+    mu_r = (ref * aw).sum(axis=0).reshape(1, 3)
+    C = (ref - mu_r).T.astype(np.float64) @ (tgt - mu_t).astype(np.float64)
+    U, _, Vt = np.linalg.svd(C)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[-1, -1] = -1
+    T = np.eye(4)
+    T[:3, :3] = U @ S @ Vt
+    T[:3, 3] = mu_r.astype(np.float64).reshape(3) - T[:3, :3] @ mu_t.astype(np.float64).reshape(3)
+    return T
+
+
+# ======================================================================================================================
 # a10-a12  kd-tree local map
 # ======================================================================================================================
 def knn_normals(model: np.ndarray, tree: cKDTree, idx: np.ndarray, k: int = 10) -> np.ndarray:

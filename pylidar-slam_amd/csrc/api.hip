@@ -823,6 +823,8 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
 }
 
 // ---- alignment on given correspondences -----------------------------------------------------------------------------
+static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], double* loss_out, double* normal_eq_out);
+
 int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
                              int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
                              double* normal_eq_out) {
@@ -834,13 +836,17 @@ int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float*
     if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
     if ((rc = import_buffer(ctx, ref_normals, (size_t)n * 12, mem, ctx->stage_out2, &nr))) return rc;
     if ((rc = launch_align_given(ctx, (const float*)r, (const float*)t, (const float*)nr, n))) return rc;
+    return finish_align(ctx, dx_out, pose_out, loss_out, normal_eq_out);
+}
+
+static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], double* loss_out, double* normal_eq_out) {
     char host[144];
     double neq[NEQ];
     ICP_HIP(ctx, hipMemcpyAsync(host, ctx->stage_out.ptr, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipMemcpyAsync(neq, ctx->neq, sizeof(neq), hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const float* f = (const float*)host;
-    if (dx_out) memcpy(dx_out, f, 6 * sizeof(float));
+    if (params_out) memcpy(params_out, f, 6 * sizeof(float));
     if (pose_out) memcpy(pose_out, f + 6, 16 * sizeof(float));
     if (loss_out) memcpy(loss_out, host + 128, sizeof(double));
     if (normal_eq_out) memcpy(normal_eq_out, neq, sizeof(neq));
@@ -849,6 +855,124 @@ int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float*
     if (status == ICP_ERR_INVALID_JACOBIAN)
         return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
     return status;
+}
+
+int icp_align_point_to_point(icp_ctx* ctx, const float* ref_points, const float* tgt_points, int64_t n, int mem,
+                             const float x0[6], float params_out[6], float pose_out[16], double* loss_out,
+                             double* normal_eq_out) {
+    if (!ctx || n <= 0 || !ref_points || !tgt_points) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void *r, *t;
+    if ((rc = import_buffer(ctx, ref_points, (size_t)n * 12, mem, ctx->stage_in, &r))) return rc;
+    if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
+    if ((rc = launch_align_p2p(ctx, (const float*)r, (const float*)t, n, x0))) return rc;
+    return finish_align(ctx, params_out, pose_out, loss_out, normal_eq_out);
+}
+
+// 3x3 SVD A = U diag(s) V^T in f64 by one-sided Jacobi, singular values sorted descending (LAPACK's order, which the
+// reflection fix of weighted_procrustes relies on); a vanishing direction is completed by a cross product
+static void svd3(const double A[9], double U[9], double sv[3], double V[9]) {
+    double B[9];
+    memcpy(B, A, sizeof(B));
+    for (int k = 0; k < 9; ++k) V[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int i = 0; i < 3; ++i) {
+                    a += B[3 * i + p] * B[3 * i + p];
+                    b += B[3 * i + q] * B[3 * i + q];
+                    c += B[3 * i + p] * B[3 * i + q];
+                }
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                off += fabs(c);
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double bp = B[3 * i + p], bq = B[3 * i + q];
+                    B[3 * i + p] = cs * bp - sn * bq;
+                    B[3 * i + q] = sn * bp + cs * bq;
+                    const double vp = V[3 * i + p], vq = V[3 * i + q];
+                    V[3 * i + p] = cs * vp - sn * vq;
+                    V[3 * i + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    int order[3] = {0, 1, 2};
+    double nrm[3];
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (nrm[order[b]] > nrm[order[a]]) std::swap(order[a], order[b]);
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        const int c = order[j];
+        sv[j] = nrm[c];
+        for (int i = 0; i < 3; ++i) {
+            Vs[3 * i + j] = V[3 * i + c];
+            U[3 * i + j] = nrm[c] > 0.0 ? B[3 * i + c] / nrm[c] : 0.0;
+        }
+    }
+    memcpy(V, Vs, sizeof(Vs));
+    const double tiny = 1e-14 * (sv[0] > 0.0 ? sv[0] : 1.0);
+    if (sv[1] <= tiny) {  // rank <= 1: any unit vector orthogonal to u0
+        const double ax = fabs(U[0]), ay = fabs(U[3]), az = fabs(U[6]);
+        double e[3] = {0, 0, 0};
+        e[(ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2)] = 1.0;
+        if (sv[0] <= 0.0) { U[0] = 1.0; U[3] = U[6] = 0.0; e[0] = 0.0; e[1] = 1.0; e[2] = 0.0; }
+        const double d = e[0] * U[0] + e[1] * U[3] + e[2] * U[6];
+        double w[3] = {e[0] - d * U[0], e[1] - d * U[3], e[2] - d * U[6]};
+        const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        U[1] = w[0] / wn; U[4] = w[1] / wn; U[7] = w[2] / wn;
+    }
+    if (sv[2] <= tiny) {  // u2 = u0 x u1
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+static double det3(const double* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* ref_points, const float* weights,
+                            int64_t n, int mem, double pose_out[16]) {
+    if (!ctx || n <= 0 || !ref_points || !tgt_points || !pose_out) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    const void *r, *t, *w = nullptr;
+    if ((rc = import_buffer(ctx, ref_points, (size_t)n * 12, mem, ctx->stage_in, &r))) return rc;
+    if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
+    if (weights && (rc = import_buffer(ctx, weights, (size_t)n * 4, mem, ctx->stage_out2, &w))) return rc;
+    double sums[NEQ];
+    if ((rc = launch_procrustes_pass(ctx, (const float*)t, (const float*)r, (const float*)w, n, nullptr, nullptr, sums)))
+        return rc;
+    if (!(sums[0] != 0.0)) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "the weights sum to zero");
+    float mu_t[3], mu_r[3];  // float32 means, as the reference forms them in the dtype of the points
+    for (int a = 0; a < 3; ++a) {
+        mu_t[a] = (float)(sums[1 + a] / sums[0]);
+        mu_r[a] = (float)(sums[4 + a] / sums[0]);
+    }
+    double cov[NEQ];
+    if ((rc = launch_procrustes_pass(ctx, (const float*)t, (const float*)r, nullptr, n, mu_t, mu_r, cov))) return rc;
+    double U[9], sv[3], V[9];
+    svd3(cov, U, sv, V);
+    const double sgn = det3(U) * det3(V) < 0.0 ? -1.0 : 1.0;  // S[-1,-1] = -1 (:49-51)
+    double R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + sgn * U[3 * i + 2] * V[3 * j + 2];
+    for (int k = 0; k < 16; ++k) pose_out[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) pose_out[4 * i + j] = R[3 * i + j];
+        pose_out[4 * i + 3] = (double)mu_r[i] - (R[3 * i] * mu_t[0] + R[3 * i + 1] * mu_t[1] + R[3 * i + 2] * mu_t[2]);
+    }
+    return ICP_OK;
 }
 
 // ---- registration ---------------------------------------------------------------------------------------------------

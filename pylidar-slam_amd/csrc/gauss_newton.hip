@@ -37,11 +37,14 @@ struct RowAcc {
         J[4] = __fsub_rn(__fmul_rn(pz, nx), __fmul_rn(px, nz));
         J[5] = __fsub_rn(__fmul_rn(px, ny), __fmul_rn(py, nx));
         const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        const float w = robust_weight(scheme, sigma, r, d2);
-        const float rw = __fmul_rn(r, w);  // res *= weights (:329)
+        add_row(J, r, robust_weight(scheme, sigma, r, d2));
+    }
+    // one residual r with Jacobian row J and weight w: res *= w, J *= w (optimization.py:329-330), f64 sums
+    __device__ inline void add_row(const float* J, float r, float w) {
+        const float rw = __fmul_rn(r, w);
         double Jw[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) Jw[a] = (double)__fmul_rn(J[a], w);  // J *= weights (:330)
+        for (int a = 0; a < 6; ++a) Jw[a] = (double)__fmul_rn(J[a], w);
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -117,6 +120,98 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_given(const float* __res
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         acc.add(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], ref[3 * i], ref[3 * i + 1], ref[3 * i + 2], nrm[3 * i],
                 nrm[3 * i + 1], nrm[3 * i + 2], ap.scheme, ap.sigma);
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// Point-to-point rows (`PointToPointCost`, slam/common/optimization.py:458-560) at the linearisation point x0:
+//   d = (R0 p + t0) - q,  r = ||d||                         residual  (:540-550)
+//   J_k = (dT/dx_k p) . d  with dT/dx_k = e_k for the translations and dR/de_k p for the Euler angles (:483-499) —
+//   the reference's own (unnormalised) form, reproduced as is
+//   w from the scheme on |r|; `neighborhood` sees the RAW target point (alignment.py:183: target_points=tgt_points)
+struct P2PLinearisation {
+    float T0[12];   // R0 (row-major 3x3) then t0
+    float dR[27];   // d R / d ex, ey, ez at x0 (rotation.py:166-187)
+};
+
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_p2p(const float* __restrict__ ref, const float* __restrict__ tgt,
+                                                            int n, P2PLinearisation L, AlignParams ap,
+                                                            double* __restrict__ partials) {
+    RowAcc acc;
+    acc.zero();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float px = tgt[3 * i], py = tgt[3 * i + 1], pz = tgt[3 * i + 2];
+        const float qx = ref[3 * i], qy = ref[3 * i + 1], qz = ref[3 * i + 2];
+        float d[3], J[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {  // apply_transformation: einsum over j, then + t (pose.py:169-186)
+            const float rp = __fadd_rn(__fadd_rn(__fmul_rn(L.T0[3 * a], px), __fmul_rn(L.T0[3 * a + 1], py)),
+                                       __fmul_rn(L.T0[3 * a + 2], pz));
+            d[a] = __fsub_rn(__fadd_rn(rp, L.T0[9 + a]), a == 0 ? qx : (a == 1 ? qy : qz));
+        }
+        const float r = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+        J[0] = d[0];
+        J[1] = d[1];
+        J[2] = d[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float* M = L.dR + 9 * k + 3 * a;
+                const float v = __fadd_rn(__fadd_rn(__fmul_rn(M[0], px), __fmul_rn(M[1], py)), __fmul_rn(M[2], pz));
+                s = __fadd_rn(s, __fmul_rn(v, d[a]));
+            }
+            J[3 + k] = s;
+        }
+        const float ex = __fsub_rn(px, qx), ey = __fsub_rn(py, qy), ez = __fsub_rn(pz, qz);
+        const float d2raw = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+        acc.add_row(J, r, robust_weight(ap.scheme, ap.sigma, r, d2raw));
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// weighted means and cross-covariance for `weighted_procrustes` (slam/common/registration.py:15-74): two passes.
+// pass 1: sum w, sum w p_tgt, sum w p_ref  -> partial rows (7 used columns)
+__global__ __launch_bounds__(RED_THREADS) void k_procrustes_means(const float* __restrict__ tgt,
+                                                                  const float* __restrict__ ref,
+                                                                  const float* __restrict__ w, int n,
+                                                                  double* __restrict__ partials) {
+    RowAcc acc;
+    acc.zero();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double wi = w ? (double)w[i] : 1.0;
+        acc.v[0] += wi;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            acc.v[1 + a] += wi * (double)tgt[3 * i + a];
+            acc.v[4 + a] += wi * (double)ref[3 * i + a];
+        }
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// pass 2: C[i][j] = sum (ref - mu_ref)_i (tgt - mu_tgt)_j, the centred differences formed in float32 (:41-44)
+struct ProcrustesMeans {
+    float mu_tgt[3], mu_ref[3];
+};
+
+__global__ __launch_bounds__(RED_THREADS) void k_procrustes_cov(const float* __restrict__ tgt,
+                                                                const float* __restrict__ ref, int n,
+                                                                ProcrustesMeans mu, double* __restrict__ partials) {
+    RowAcc acc;
+    acc.zero();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float dt[3], dr[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            dt[a] = __fsub_rn(tgt[3 * i + a], mu.mu_tgt[a]);
+            dr[a] = __fsub_rn(ref[3 * i + a], mu.mu_ref[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc.v[3 * a + b] += (double)dr[a] * (double)dt[b];
     }
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
@@ -348,16 +443,21 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     if (threadIdx.x == 0) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap);
 }
 
-// align() on given correspondences: writes dx[6], pose[16] (f32) and loss into `out` (device, 6 + 16 floats; loss double)
-__global__ void k_solve_given(const double* __restrict__ neq, float* __restrict__ out_f, double* __restrict__ out_loss,
-                              int* __restrict__ out_status) {
+// align() on given correspondences: writes params = x0 + dx [6], pose[16] = build_pose_matrix(params) (f32) and loss
+// into `out` (device, 6 + 16 floats; loss double)
+struct Params6 {
+    float v[6];
+};
+
+__global__ void k_solve_given(const double* __restrict__ neq, Params6 x0, float* __restrict__ out_f,
+                              double* __restrict__ out_loss, int* __restrict__ out_status) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float dx[6];
     double loss;
     int stopped;
     *out_status = gauss_newton_from_neq(neq, dx, &loss, &stopped);
-    for (int a = 0; a < 6; ++a) out_f[a] = dx[a];
-    build_pose_f32(dx, out_f + 6);
+    for (int a = 0; a < 6; ++a) out_f[a] = __fadd_rn(x0.v[a], dx[a]);  // x = x0 + dx (optimization.py:338-340)
+    build_pose_f32(out_f, out_f + 6);
     *out_loss = loss;
 }
 
@@ -431,19 +531,91 @@ int launch_solve(icp_ctx* ctx) {
     return ICP_OK;
 }
 
-// out layout in ctx->stage_out: [0..21] floats (dx, pose), then at byte 128 the loss (double), at byte 136 status (int)
+// out layout in ctx->stage_out: [0..21] floats (params, pose), then at byte 128 the loss (double), at byte 136 status (int)
+static int launch_solve_given(icp_ctx* ctx, int blocks, const float* x0) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                       reg_state(ctx), 0, ctx->neq);
+    Params6 p;
+    for (int a = 0; a < 6; ++a) p.v[a] = x0 ? x0[a] : 0.f;
+    char* out = ctx->stage_out.as<char>();
+    hipLaunchKernelGGL(k_solve_given, dim3(1), dim3(64), 0, ctx->stream, ctx->neq, p, (float*)out,
+                       (double*)(out + 128), (int*)(out + 136));
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n) {
     const int blocks = reduce_grid(n);
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     ICP_HIP(ctx, ctx->stage_out.reserve(256));
     hipLaunchKernelGGL(k_reduce_given, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, nrm, (int)n,
                        make_align_params(ctx), ctx->partials.as<double>());
+    return launch_solve_given(ctx, blocks, nullptr);
+}
+
+// R = Rz(ez) Ry(ey) Rx(ex) and its derivatives in float32, the products in the reference's order
+// (torch_euler_to_mat / torch_euler_jacobian, slam/common/rotation.py:144-187)
+static void mat3_mul(const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 3; ++k) s += A[3 * i + k] * B[3 * k + j];
+            C[3 * i + j] = s;
+        }
+}
+
+static P2PLinearisation linearise_euler(const float* x0) {
+    P2PLinearisation L;
+    const float z[6] = {0, 0, 0, 0, 0, 0};
+    if (!x0) x0 = z;
+    const float cx = cosf(x0[3]), sx = sinf(x0[3]), cy = cosf(x0[4]), sy = sinf(x0[4]), cz = cosf(x0[5]), sz = sinf(x0[5]);
+    const float Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy},
+                Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+    const float Jx[9] = {0, 0, 0, 0, -sx, -cx, 0, cx, -sx}, Jy[9] = {-sy, 0, cy, 0, 0, 0, -cy, 0, -sy},
+                Jz[9] = {-sz, -cz, 0, cz, -sz, 0, 0, 0, 0};
+    float zy[9], t[9];
+    mat3_mul(Rz, Ry, zy);
+    mat3_mul(zy, Rx, L.T0);            // (Rz @ Ry) @ Rx
+    mat3_mul(zy, Jx, L.dR);            // (Rz @ Ry) @ dRx
+    mat3_mul(Rz, Jy, t);
+    mat3_mul(t, Rx, L.dR + 9);         // (Rz @ dRy) @ Rx
+    mat3_mul(Jz, Ry, t);
+    mat3_mul(t, Rx, L.dR + 18);        // (dRz @ Ry) @ Rx
+    for (int a = 0; a < 3; ++a) L.T0[9 + a] = x0[a];
+    return L;
+}
+
+int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0) {
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    ICP_HIP(ctx, ctx->stage_out.reserve(256));
+    hipLaunchKernelGGL(k_reduce_p2p, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, (int)n,
+                       linearise_euler(x0), make_align_params(ctx), ctx->partials.as<double>());
+    return launch_solve_given(ctx, blocks, x0);
+}
+
+// sums for weighted_procrustes; host_out[NEQ] receives the fixed-order total of the pass (synchronises)
+int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, const float* w, int64_t n,
+                           const float* mu_tgt, const float* mu_ref, double* host_out) {
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    if (!mu_tgt) {
+        hipLaunchKernelGGL(k_procrustes_means, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, tgt, ref, w, (int)n,
+                           ctx->partials.as<double>());
+    } else {
+        ProcrustesMeans mu;
+        for (int a = 0; a < 3; ++a) {
+            mu.mu_tgt[a] = mu_tgt[a];
+            mu.mu_ref[a] = mu_ref[a];
+        }
+        hipLaunchKernelGGL(k_procrustes_cov, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, tgt, ref, (int)n, mu,
+                           ctx->partials.as<double>());
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                        reg_state(ctx), 0, ctx->neq);
-    char* out = ctx->stage_out.as<char>();
-    hipLaunchKernelGGL(k_solve_given, dim3(1), dim3(64), 0, ctx->stream, ctx->neq, (float*)out, (double*)(out + 128),
-                       (int*)(out + 136));
     ICP_HIP(ctx, hipGetLastError());
+    ICP_HIP(ctx, hipMemcpyAsync(host_out, ctx->neq, NEQ * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
 }
 

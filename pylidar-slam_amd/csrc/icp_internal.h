@@ -233,6 +233,9 @@ int launch_sum_partials(icp_ctx* ctx, int blocks);
 int launch_iterate_fused(icp_ctx* ctx, int* blocks_out);
 int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n);
+int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0);
+int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, const float* w, int64_t n,
+                           const float* mu_tgt, const float* mu_ref, double* host_out);
 
 // ---- projection.hip
 int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev);

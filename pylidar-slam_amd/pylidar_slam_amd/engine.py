@@ -373,6 +373,49 @@ class IcpContext:
         return (np.array(pose, np.float32).reshape(4, 4), np.array(dx, np.float32), float(loss.value),
                 np.array(neq, np.float64))
 
+    def align_point_to_point(self, ref_points: Array, tgt_points: Array, x0=None):
+        """One Gauss-Newton point-to-point step linearised at x0 ([6] or None = zeros):
+        (pose [4,4], params [6] = x0 + dx, loss, normal equations [32] f64)."""
+        r, mem_r, kr = _ptr_mem(ref_points)
+        t, mem_t, kt = _ptr_mem(tgt_points)
+        if mem_r != mem_t:
+            raise AssertionError("ref / tgt must live in the same memory space")
+        n = int(kr.shape[0])
+        if kt.shape[0] != n:
+            raise AssertionError("ref / tgt must have the same number of rows")
+        x = (C.c_float * 6)(*[float(v) for v in np.asarray(x0, np.float32).reshape(6)]) if x0 is not None else None
+        params = (C.c_float * 6)()
+        pose = (C.c_float * 16)()
+        loss = C.c_double(0)
+        neq = (C.c_double * 32)()
+        self._check(self._lib.icp_align_point_to_point(self._h, r, t, n, mem_r, x, params, pose, C.byref(loss), neq))
+        return (np.array(pose, np.float32).reshape(4, 4), np.array(params, np.float32), float(loss.value),
+                np.array(neq, np.float64))
+
+    def weighted_procrustes(self, tgt_points: Array, ref_points: Array, weights=None) -> np.ndarray:
+        """`weighted_procrustes` (slam/common/registration.py:15-74): [4,4] float64 transform target -> reference."""
+        t, mem_t, kt = _ptr_mem(tgt_points)
+        r, mem_r, kr = _ptr_mem(ref_points)
+        if mem_r != mem_t or kt.shape[0] != kr.shape[0]:
+            raise AssertionError("target / reference must have the same shape and memory space")
+        w, keep_w = None, None
+        if weights is not None:
+            if isinstance(weights, torch.Tensor):
+                keep_w = weights.reshape(-1).to(torch.float32).contiguous()
+                if (MEM_DEVICE if keep_w.is_cuda else MEM_HOST) != mem_t:
+                    raise AssertionError("weights must live where the points live")
+                w = keep_w.data_ptr()
+            else:
+                if mem_t != MEM_HOST:
+                    raise AssertionError("weights must live where the points live")
+                keep_w = np.ascontiguousarray(np.asarray(weights, np.float32).reshape(-1))
+                w = keep_w.ctypes.data
+            if keep_w.shape[0] != kt.shape[0]:
+                raise AssertionError("one weight per point")
+        out = (C.c_double * 16)()
+        self._check(self._lib.icp_weighted_procrustes(self._h, t, r, w, int(kt.shape[0]), mem_t, out))
+        return np.array(out, np.float64).reshape(4, 4)
+
     # ---- registration ------------------------------------------------------------------------------------------------
     def _result(self, res: IcpRegisterResult, losses, dxs) -> RegisterResult:
         k = int(res.iterations)

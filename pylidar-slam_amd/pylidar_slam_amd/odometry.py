@@ -31,7 +31,7 @@ from .engine import IcpContext, InvalidJacobianError, RegisterResult  # noqa: F4
 __all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap", "Distortion",
            "ProjectiveLocalMap",
            "DistortionConfig",
-           "PointToPlaneAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
+           "PointToPlaneAlignment", "PointToPointAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
            "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
 
 
@@ -367,6 +367,33 @@ class PointToPlaneAlignment:
         if is_torch:
             return torch.from_numpy(pose).unsqueeze(0), torch.from_numpy(dx).unsqueeze(0), loss
         return pose[None], dx[None], loss
+
+
+class PointToPointAlignment:
+    """Drop-in for `GaussNewtonPointToPointAlignment.align` (slam/odometry/alignment.py:143-189): one Gauss-Newton
+    point-to-point step on given correspondences, linearised at `initial_estimate` (zeros by default; the Procrustes
+    solution when `initialize_with_svd`); returns (pose [1,4,4], params [1,6], loss)."""
+
+    def __init__(self, ctx: IcpContext, initialize_with_svd: bool = False, **kwargs):
+        self.ctx = ctx
+        self.initialize_with_svd = initialize_with_svd
+
+    def align(self, ref_points, tgt_points, initial_estimate=None, **kwargs):
+        is_torch = isinstance(ref_points, torch.Tensor)
+        r = ref_points.reshape(-1, 3)
+        t = tgt_points.reshape(-1, 3)
+        x0 = None
+        if self.initialize_with_svd:  # alignment.py:170-171, arguments in the reference's order
+            x0 = from_pose_matrix(self.ctx.weighted_procrustes(r, t).astype(np.float32))
+        elif initial_estimate is not None:
+            est = initial_estimate.detach().cpu().numpy() if isinstance(initial_estimate, torch.Tensor) else \
+                np.asarray(initial_estimate)
+            x0 = from_pose_matrix(est.reshape(4, 4).astype(np.float32)) if est.size == 16 else \
+                est.reshape(6).astype(np.float32)
+        pose, params, loss, _ = self.ctx.align_point_to_point(r, t, x0)
+        if is_torch:
+            return torch.from_numpy(pose).unsqueeze(0), torch.from_numpy(params).unsqueeze(0), loss
+        return pose[None], params[None], loss
 
 
 # ----------------------------------------------------------------------------------------------------------------------

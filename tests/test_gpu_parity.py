@@ -526,3 +526,54 @@ def test_projective_icp_sequence(torch_cuda, O, golden_projective, run):
         if float(thr) == 0.0:  # the reference ran the same forced iteration count
             dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
             assert dt < 5e-3 and dr < 5e-4, ("reference", run, f, dt, dr)
+
+
+# ---- point-to-point alignment + weighted Procrustes --------------------------------------------
+@pytest.mark.parametrize("name", ["ls", "huber", "nbh", "gm_svd", "ls_svd"])
+def test_point_to_point_alignment(torch_cuda, O, name):
+    import os
+    from conftest import GOLDEN
+    from pylidar_slam_amd.odometry import PointToPointAlignment
+    g = np.load(os.path.join(GOLDEN, "alignment.npz"))
+    scheme, sigma, svd = g[f"{name}_cfg"]
+    ctx = _ctx(scheme=str(scheme), sigma=float(sigma))
+    algo = PointToPointAlignment(ctx, initialize_with_svd=bool(int(svd)))
+    pose, params, loss = algo.align(g["ref"], g["tgt"])
+    # vs the reference's own float32 result (its normal equations are float32, ours float64)
+    np.testing.assert_allclose(params[0], g[f"{name}_params"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(pose[0], g[f"{name}_pose"], atol=5e-5)
+    np.testing.assert_allclose(loss, float(g[f"{name}_loss"]), rtol=1e-4)
+    # vs the oracle accumulating in float64 like the device: tight
+    x0 = O.from_pose_matrix(O.weighted_procrustes(g["ref"], g["tgt"]).astype(np.float32)) if int(svd) else None
+    _, p64, l64 = O.point_to_point_step(g["tgt"], g["ref"], x0, str(scheme), float(sigma), accumulate=np.float64)
+    np.testing.assert_allclose(params[0], p64, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(loss, l64, rtol=1e-5)
+    # device-resident inputs give the same bits
+    r_t, t_t = torch_cuda.from_numpy(g["ref"]).cuda(), torch_cuda.from_numpy(g["tgt"]).cuda()
+    pose_d, params_d, _ = algo.align(r_t[None], t_t[None])
+    assert np.array_equal(params_d[0].numpy(), params[0])
+
+
+def test_weighted_procrustes(torch_cuda, O):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "alignment.npz"))
+    ctx = _ctx()
+    np.testing.assert_allclose(ctx.weighted_procrustes(g["tgt"], g["ref"]), g["procrustes_np"], atol=2e-6)
+    np.testing.assert_allclose(ctx.weighted_procrustes(g["tgt"], g["ref"], g["weights"]), g["procrustes_np_weighted"],
+                               atol=2e-6)
+    np.testing.assert_allclose(ctx.weighted_procrustes(g["flat_tgt"], g["flat_ref"]), g["procrustes_flat"], atol=2e-6)
+    T = ctx.weighted_procrustes(g["tgt"], g["ref"])
+    assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-12
+    # degenerate inputs: all points equal (rank 0) -> a proper rotation and the centroid shift; mirrored cloud -> still
+    # a rotation (the reflection fix), never a reflection
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (50, 1))
+    T0 = ctx.weighted_procrustes(same, same + np.float32(0.5))
+    assert abs(np.linalg.det(T0[:3, :3]) - 1.0) < 1e-9
+    np.testing.assert_allclose(T0[:3, :3] @ same[0] + T0[:3, 3], same[0] + 0.5, atol=1e-5)
+    mirrored = g["ref"] * np.array([1, 1, -1], np.float32)
+    Tm = ctx.weighted_procrustes(mirrored, g["ref"])
+    assert abs(np.linalg.det(Tm[:3, :3]) - 1.0) < 1e-9
+    np.testing.assert_allclose(Tm, O.weighted_procrustes(mirrored, g["ref"]), atol=1e-5)
+    with pytest.raises(AssertionError):
+        ctx.weighted_procrustes(g["tgt"], g["ref"], np.zeros(g["ref"].shape[0], np.float32))

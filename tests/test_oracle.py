@@ -231,3 +231,38 @@ def test_kitti_correct_scan_matches_reference():
     np.testing.assert_allclose(np.linalg.norm(r[ok], axis=1), np.linalg.norm(p, axis=1), rtol=1e-6)
     cosang = (r[ok] * p).sum(1) / (np.linalg.norm(r[ok], axis=1) * np.linalg.norm(p, axis=1))
     np.testing.assert_allclose(np.degrees(np.arccos(np.clip(cosang, -1, 1))), 0.205, atol=1e-3)
+
+
+# ---- point-to-point alignment + weighted Procrustes --------------------------------------------
+@pytest.fixture(scope="module")
+def golden_alignment():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "alignment.npz"))
+
+
+@pytest.mark.parametrize("name", ["ls", "huber", "nbh", "gm_svd", "ls_svd"])
+def test_point_to_point_step_matches_reference(golden_alignment, name):
+    g = golden_alignment
+    scheme, sigma, svd = g[f"{name}_cfg"]
+    x0 = None
+    if int(svd):  # alignment.py:170-171: weighted_procrustes(ref_points, tgt_points) — in that argument order
+        x0 = O.from_pose_matrix(O.weighted_procrustes(g["ref"], g["tgt"]).astype(np.float32))
+    pose, params, loss = O.point_to_point_step(g["tgt"], g["ref"], x0, str(scheme), float(sigma))
+    np.testing.assert_allclose(params, g[f"{name}_params"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(pose, g[f"{name}_pose"], atol=5e-5)
+    np.testing.assert_allclose(loss, float(g[f"{name}_loss"]), rtol=1e-4)
+    # the float64-accumulating variant (what the HIP path does) stays within the same band
+    _, p64, _ = O.point_to_point_step(g["tgt"], g["ref"], x0, str(scheme), float(sigma), accumulate=np.float64)
+    np.testing.assert_allclose(p64, g[f"{name}_params"], rtol=2e-4, atol=2e-5)
+
+
+def test_weighted_procrustes_matches_reference(golden_alignment):
+    g = golden_alignment
+    np.testing.assert_allclose(O.weighted_procrustes(g["tgt"], g["ref"]), g["procrustes_np"], atol=1e-12)
+    np.testing.assert_allclose(O.weighted_procrustes(g["tgt"], g["ref"], g["weights"]), g["procrustes_np_weighted"],
+                               atol=1e-12)
+    np.testing.assert_allclose(O.weighted_procrustes(g["tgt"], g["ref"]), g["procrustes_torch"], atol=5e-6)
+    np.testing.assert_allclose(O.weighted_procrustes(g["flat_tgt"], g["flat_ref"]), g["procrustes_flat"], atol=1e-10)
+    T = O.weighted_procrustes(g["tgt"], g["ref"])
+    assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-12
+    np.testing.assert_allclose(T, g["true_pose"], atol=1e-3)
