@@ -129,6 +129,15 @@ int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double vo
 int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                         double* points_out, int64_t* count_out, int out_mem);
 
+/* Voxelization.filter / voxel_normal_distribution (slam/preprocessing.py:63-98, slam/common/pointcloud.py:83-167):
+ * voxel coordinates [n,3] and hashes [n] (optional), voxel_ids_out [n] = rank of the point's hash among the distinct
+ * hashes, *num_voxels_out = V, and (all three or none) sizes_out [V] int64 point counts, means_out [V,3] float32,
+ * covs_out [V,3,3] float32 = sum (p - mean)(p - mean)^T (unnormalised, as in the reference), voxels ordered by
+ * ascending int64 hash.  Per-voxel outputs must hold n entries (V <= n). */
+int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
+                         int64_t* hashes_out, int64_t* voxel_ids_out, int64_t* num_voxels_out, int64_t* sizes_out,
+                         float* means_out, float* covs_out, int out_mem);
+
 /* ---- de-skew: Distortion.filter (slam/preprocessing.py:144-191) --------------------------------------------------
  * Every point moves by the fraction alpha = (t - t_min) / (t_max - t_min) of the initial motion estimate `rel_pose`:
  * out = slerp(I, R, alpha) p + alpha t  (alpha = 0 when all timestamps are equal).  xyz [n,3] float32, timestamps [n]

@@ -117,6 +117,25 @@ def sample_from_hashes(pc: np.ndarray, hashes: np.ndarray):
     return pc[idx], idx
 
 
+def voxel_normal_distribution(pc: np.ndarray, hashes: np.ndarray):
+    """reference slam/common/pointcloud.py:83-167: voxels = runs of equal hash in sorted order; per voxel the point
+    count, the mean and the UNNORMALISED covariance sum (p - mean)(p - mean)^T in the dtype of the points; voxel id of
+    a point = rank of its hash among the distinct hashes.  (The order of the points inside a voxel — the reference's
+    argsort is not stable — only moves the float32 sums by rounding.)"""
+    uniq, inv, counts = np.unique(hashes, return_inverse=True, return_counts=True)
+    order = np.argsort(hashes, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    means = np.zeros((uniq.shape[0], 3), pc.dtype)
+    covs = np.zeros((uniq.shape[0], 3, 3), pc.dtype)
+    for v, (b, c) in enumerate(zip(starts, counts)):
+        pts = pc[order[b:b + c]]
+        mean = (pts.sum(axis=0).reshape(1, 3) / c).astype(pc.dtype)
+        cen = (pts - mean).astype(pc.dtype)
+        means[v] = mean[0]
+        covs[v] = (cen.reshape(-1, 3, 1) * cen.reshape(-1, 1, 3)).sum(axis=0)
+    return counts.astype(np.int64), means, covs, inv.astype(np.int64)
+
+
 def grid_sample(pc: np.ndarray, voxel: float):
     """reference slam/common/pointcloud.py:182-195 and `GridSample.filter` slam/preprocessing.py:213-226."""
     return sample_from_hashes(pc, voxel_hashing(voxelise(pc, voxel)))

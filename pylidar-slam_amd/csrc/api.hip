@@ -317,7 +317,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->ctable,
                             &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
-                            &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp};
+                            &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
+                            &ctx->vox_out};
     for (DeviceBuffer* b : bufs) b->release();
     if (ctx->host_result) (void)hipHostFree(ctx->host_result);
     if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
@@ -437,6 +438,55 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
     *count_out = count;
     if ((rc = export_finish(ctx, indices_out, idev, (size_t)count * 8, out_mem))) return rc;
     if ((rc = export_finish(ctx, points_out, pdev, (size_t)count * 12, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
+                         int64_t* hashes_out, int64_t* voxel_ids_out, int64_t* num_voxels_out, int64_t* sizes_out,
+                         float* means_out, float* covs_out, int out_mem) {
+    if (!ctx || n < 0 || !(voxel_size > 0) || !num_voxels_out || !voxel_ids_out) return ICP_ERR_INVALID_ARGUMENT;
+    const bool stats = sizes_out || means_out || covs_out;
+    if (stats && !(sizes_out && means_out && covs_out)) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    *num_voxels_out = 0;
+    if (n == 0) return ICP_OK;
+    const void* in;
+    if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in))) return rc;
+    // device side of every output: the caller's buffers (device) or one staging block (host)
+    const size_t off_vox = 0, off_hash = off_vox + (size_t)n * 24, off_ids = off_hash + (size_t)n * 8,
+                 off_sizes = off_ids + (size_t)n * 8, off_means = off_sizes + (size_t)n * 8,
+                 off_covs = off_means + (size_t)n * 12, total = off_covs + (size_t)n * 36;
+    char* base = nullptr;
+    if (out_mem != ICP_MEM_DEVICE) {
+        ICP_HIP(ctx, ctx->vox_out.reserve(total));
+        base = ctx->vox_out.as<char>();
+    }
+    auto dev = [&](void* user, size_t off) -> void* {
+        if (!user) return nullptr;
+        return out_mem == ICP_MEM_DEVICE ? user : (void*)(base + off);
+    };
+    long long* d_vox = (long long*)dev(voxels_out, off_vox);
+    long long* d_hash = (long long*)dev(hashes_out, off_hash);
+    long long* d_ids = (long long*)dev(voxel_ids_out, off_ids);
+    long long* d_sizes = (long long*)dev(sizes_out, off_sizes);
+    float* d_means = (float*)dev(means_out, off_means);
+    float* d_covs = (float*)dev(covs_out, off_covs);
+    int* count_dev = ctx->counter.as<int>();
+    if ((rc = voxel_statistics_device(ctx, (const float*)in, n, voxel_size, d_vox, d_hash, d_ids, d_sizes, d_means,
+                                      d_covs, count_dev)))
+        return rc;
+    int count = 0;
+    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *num_voxels_out = count;
+    if ((rc = export_finish(ctx, voxels_out, d_vox, (size_t)n * 24, out_mem))) return rc;
+    if ((rc = export_finish(ctx, hashes_out, d_hash, (size_t)n * 8, out_mem))) return rc;
+    if ((rc = export_finish(ctx, voxel_ids_out, d_ids, (size_t)n * 8, out_mem))) return rc;
+    if ((rc = export_finish(ctx, sizes_out, d_sizes, (size_t)count * 8, out_mem))) return rc;
+    if ((rc = export_finish(ctx, means_out, d_means, (size_t)count * 12, out_mem))) return rc;
+    if ((rc = export_finish(ctx, covs_out, d_covs, (size_t)count * 36, out_mem))) return rc;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
 }

@@ -126,6 +126,98 @@ int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Per-voxel normal distribution (`voxel_normal_distribution`, slam/common/pointcloud.py:83-167; `Voxelization.filter`,
+// slam/preprocessing.py:63-98): the points are ordered by voxel hash (same stable radix sort), every run of equal
+// hashes is one voxel; voxel id = rank of the hash; per voxel the point count, the float32 mean and the float32
+// UNNORMALISED covariance sum (p - mean)(p - mean)^T, accumulated in the sorted order like the numba loop.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_voxel_ids(const int* __restrict__ vals, const int* __restrict__ flags, const int* __restrict__ offs,
+                            int n, long long* __restrict__ ids, int* __restrict__ starts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int id = offs[i] + flags[i] - 1;  // heads before i, plus this one if it is a head
+    ids[vals[i]] = id;
+    if (flags[i]) starts[id] = i;
+}
+
+__global__ void k_voxel_stats(const float* __restrict__ xyz, const int* __restrict__ vals,
+                              const int* __restrict__ starts, const int* __restrict__ count_dev, int n,
+                              long long* __restrict__ sizes, float* __restrict__ means, float* __restrict__ covs) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nv = *count_dev;
+    if (v >= nv) return;
+    const int b = starts[v], e = (v + 1 < nv) ? starts[v + 1] : n;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = b; k < e; ++k) {
+        const int i = vals[k];
+        sx = __fadd_rn(sx, xyz[3 * i]);
+        sy = __fadd_rn(sy, xyz[3 * i + 1]);
+        sz = __fadd_rn(sz, xyz[3 * i + 2]);
+    }
+    const float cnt = (float)(e - b);
+    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = b; k < e; ++k) {
+        const int i = vals[k];
+        const float dx = __fsub_rn(xyz[3 * i], mx), dy = __fsub_rn(xyz[3 * i + 1], my), dz = __fsub_rn(xyz[3 * i + 2], mz);
+        c[0] = __fadd_rn(c[0], __fmul_rn(dx, dx));
+        c[1] = __fadd_rn(c[1], __fmul_rn(dx, dy));
+        c[2] = __fadd_rn(c[2], __fmul_rn(dx, dz));
+        c[3] = __fadd_rn(c[3], __fmul_rn(dy, dy));
+        c[4] = __fadd_rn(c[4], __fmul_rn(dy, dz));
+        c[5] = __fadd_rn(c[5], __fmul_rn(dz, dz));
+    }
+    sizes[v] = e - b;
+    means[3 * v] = mx;
+    means[3 * v + 1] = my;
+    means[3 * v + 2] = mz;
+    float* C = covs + 9 * (size_t)v;
+    C[0] = c[0]; C[1] = c[1]; C[2] = c[2];
+    C[3] = c[1]; C[4] = c[3]; C[5] = c[4];
+    C[6] = c[2]; C[7] = c[4]; C[8] = c[5];
+}
+
+int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
+                            long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
+                            float* covs_dev, int* count_dev) {
+    if (n <= 0) {
+        ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
+        return ICP_OK;
+    }
+    ICP_HIP(ctx, ctx->keys_a.reserve((size_t)n * 8));
+    ICP_HIP(ctx, ctx->keys_b.reserve((size_t)n * 8));
+    ICP_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->vals_b.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->scan_a.reserve((size_t)n * 4));
+    ICP_HIP(ctx, ctx->scan_b.reserve((size_t)n * 4));
+    unsigned long long* ka = ctx->keys_a.as<unsigned long long>();
+    unsigned long long* kb = ctx->keys_b.as<unsigned long long>();
+    int* va = ctx->vals_a.as<int>();
+    int* vb = ctx->vals_b.as<int>();
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_voxel_hash<float>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, voxels_dev,
+                       hashes_dev, ka, va);
+    size_t tmp_bytes = 0;
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64, ctx->stream));
+    ICP_HIP(ctx, ctx->sort_tmp.reserve(tmp_bytes));
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64,
+                                           ctx->stream));
+    int* flags = ctx->flags.as<int>();
+    int* offs = ctx->scan_a.as<int>();
+    int* starts = ctx->scan_b.as<int>();
+    hipLaunchKernelGGL(k_run_heads, dim3(nb), dim3(256), 0, ctx->stream, kb, (int)n, flags);
+    int rc = exclusive_scan_i32(ctx, flags, offs, n, count_dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_voxel_ids, dim3(nb), dim3(256), 0, ctx->stream, vb, flags, offs, (int)n, ids_dev, starts);
+    if (sizes_dev)
+        hipLaunchKernelGGL(k_voxel_stats, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, vb, starts, count_dev, (int)n,
+                           sizes_dev, means_dev, covs_dev);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // De-skew (`Distortion.filter`, slam/preprocessing.py:144-191): timestamp range by a two-level f64 min/max reduction,
 // then per point the Rodrigues rotation by alpha * theta about the axis of the initial motion + alpha * translation,
 // all in float64 like the reference (scipy Slerp + a float64 einsum).

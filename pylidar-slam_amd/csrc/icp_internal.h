@@ -171,6 +171,7 @@ struct icp_ctx {
     int fuse_iteration = 1;            // search + rows + partial sums in one kernel when normals are ready (env ICP_FUSE_ITERATION)
     int sort_targets = 0;              // Morton-sort the targets of a registration (env ICP_SORT_TARGETS)
     icp::DeviceBuffer partials;        // double[blocks][NEQ]
+    icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
     icp::DeviceBuffer loss_hist;       // double[max_iters]
     icp::DeviceBuffer dx_hist;         // float[max_iters][6]
@@ -260,6 +261,9 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
                    double* out_dev);
 // targets -> float4 rows in ctx->tgt4; sorted along a Morton curve of the map's cells under `pose` when sort != 0
 int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const float* pose16_host, int sort);
+int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
+                            long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
+                            float* covs_dev, int* count_dev);
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
                        float* points_dev, int* count_dev);
 

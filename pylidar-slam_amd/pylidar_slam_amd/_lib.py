@@ -90,6 +90,7 @@ EXPORTED_SYMBOLS = {
     "icp_pmap_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, C.POINTER(_I64), _INT]),
     "icp_pmap_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_align_point_to_plane": (_INT, [_P, _P, _P, _P, _I64, _INT, _P, _P, _P, _P]),
+    "icp_voxel_statistics": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, _P, _P, _P, _P, _P, _INT]),
     "icp_align_point_to_point": (_INT, [_P, _P, _P, _I64, _INT, _P, _P, _P, _P, _P]),
     "icp_weighted_procrustes": (_INT, [_P, _P, _P, _P, _I64, _INT, _P]),
     "icp_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),

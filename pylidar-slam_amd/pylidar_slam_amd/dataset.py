@@ -21,6 +21,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from . import eval as _eval
 from .engine import IcpContext
 from .odometry import SphericalProjector, assert_debug
 from .synthetic import SceneConfig, ray_directions, render_scan, trajectory
@@ -31,7 +32,8 @@ __all__ = ["DatasetLoader", "SyntheticDatasetConfig", "SyntheticSequence", "Synt
 
 
 def compute_relative_poses(absolute: np.ndarray) -> np.ndarray:
-    """slam/eval/eval_odometry.py: relative[0] = I, relative[i] = inv(abs[i-1]) @ abs[i]."""
+    """relative[0] = I, relative[i] = inv(abs[i-1]) @ abs[i] (trajectory expressed from its first frame; the
+    reference's `eval_odometry.compute_relative_poses` keeps abs[0] as the first entry — see `eval.py`)."""
     rel = np.zeros_like(absolute)
     rel[0] = np.eye(4)
     for i in range(1, absolute.shape[0]):
@@ -254,7 +256,7 @@ class KITTIDatasetLoader(DatasetLoader):
         tr = np.eye(4, dtype=np.float64)
         tr[:3, :4] = calib["Tr"].reshape(3, 4)
         right = np.einsum("...ij,...jk->...ik", np.einsum("...ij,...jk->...ik", np.linalg.inv(tr), poses), tr)
-        return compute_relative_poses(right)
+        return _eval.compute_relative_poses(right)  # the reference's own convention: rel[0] = abs[0]
 
     def sequences(self):  # :349-400
         c = self.config

@@ -177,6 +177,29 @@ class IcpContext:
                                               pts.ctypes.data, C.byref(count), MEM_HOST))
         return pts[:count.value].copy(), idx[:count.value].copy()
 
+    def voxel_statistics(self, points: np.ndarray, voxel_size: float, with_normal_distribution: bool = True):
+        """`Voxelization.filter` (slam/preprocessing.py:63-98): dict with voxel_coordinates [n,3] i64, voxel_hashes [n]
+        i64, voxel_indices [n] i64 and — with_normal_distribution — voxel_sizes [V] i64, voxel_means [V,3] f32,
+        voxel_covariances [V,3,3] f32 (voxels by ascending hash)."""
+        p, mem, keep = _ptr_mem(points)
+        if mem != MEM_HOST:
+            raise AssertionError("voxel_statistics takes a host array (the reference filter is numpy-only)")
+        n = int(keep.shape[0])
+        vox, hashes, ids = np.empty((n, 3), np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
+        nv = C.c_int64(0)
+        sizes = means = covs = None
+        if with_normal_distribution:
+            sizes, means, covs = np.empty(n, np.int64), np.empty((n, 3), np.float32), np.empty((n, 3, 3), np.float32)
+        self._check(self._lib.icp_voxel_statistics(
+            self._h, p, n, mem, float(voxel_size), vox.ctypes.data, hashes.ctypes.data, ids.ctypes.data, C.byref(nv),
+            sizes.ctypes.data if sizes is not None else None, means.ctypes.data if means is not None else None,
+            covs.ctypes.data if covs is not None else None, MEM_HOST))
+        out = {"voxel_coordinates": vox, "voxel_hashes": hashes, "voxel_indices": ids, "num_voxels": int(nv.value)}
+        if with_normal_distribution:
+            v = int(nv.value)
+            out.update(voxel_sizes=sizes[:v].copy(), voxel_means=means[:v].copy(), voxel_covariances=covs[:v].copy())
+        return out
+
     def grid_sample_f64(self, points: np.ndarray, voxel_size: float):
         """float64 cloud (the output of `distort`) -> (sample points [V,3] f64, indices [V] int64)."""
         pts64 = np.ascontiguousarray(points, dtype=np.float64)

@@ -32,6 +32,7 @@ __all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "Has
            "ProjectiveLocalMap",
            "DistortionConfig",
            "PointToPlaneAlignment", "PointToPointAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
+           "Voxelization", "VoxelizationConfig",
            "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
 
 
@@ -147,6 +148,45 @@ def _shared_context() -> IcpContext:
     if _SHARED is None:
         _SHARED = IcpContext()
     return _SHARED
+
+
+@dataclass
+class VoxelizationConfig:
+    """slam/preprocessing.py:43-59."""
+    filter_name: str = "voxelization"
+    input_channel: str = "numpy_pc"
+    voxel_covariances_key: str = "voxel_covariances"
+    voxel_means_key: str = "voxel_means"
+    voxel_size_key: str = "voxel_sizes"
+    voxel_indices_key: str = "voxel_indices"
+    voxel_hashes_key: str = "voxel_hashes"
+    voxel_coordinates_key: str = "voxel_coordinates"
+    with_normal_distribution: bool = True
+    voxel_size: float = 0.2
+
+
+class Voxelization:
+    """slam/preprocessing.py:63-98 (`Filter.filter(data_dict)` seam): voxel coordinates / hashes and the per-voxel
+    point count, mean and covariance, computed on the GPU."""
+
+    def __init__(self, config: VoxelizationConfig, ctx: Optional[IcpContext] = None, **kwargs):
+        self.config = config
+        self._ctx = ctx
+
+    def filter(self, data_dict: dict):
+        c = self.config
+        assert_debug(c.input_channel in data_dict, f"The input channel {c.input_channel} was not in the input channel")
+        pc = data_dict[c.input_channel]
+        assert_debug(isinstance(pc, np.ndarray))
+        assert_debug(pc.ndim == 2 and pc.shape[1] == 3, f"expected [N, 3], got {pc.shape}")
+        out = (self._ctx or _shared_context()).voxel_statistics(pc, c.voxel_size, c.with_normal_distribution)
+        data_dict[c.voxel_hashes_key] = out["voxel_hashes"]
+        data_dict[c.voxel_coordinates_key] = out["voxel_coordinates"]
+        if c.with_normal_distribution:
+            data_dict[c.voxel_means_key] = out["voxel_means"]
+            data_dict[c.voxel_covariances_key] = out["voxel_covariances"]
+            data_dict[c.voxel_size_key] = out["voxel_sizes"]
+            data_dict[c.voxel_indices_key] = out["voxel_indices"]
 
 
 @dataclass

@@ -88,7 +88,8 @@ def test_kitti_correct_scan_gpu_matches_reference():
 def test_kitti_sequence_round_trip(tmp_path):
     import torch
     import icp_oracle as O
-    from pylidar_slam_amd.dataset import KITTIConfig, KITTIDatasetLoader, compute_relative_poses
+    from pylidar_slam_amd.dataset import KITTIConfig, KITTIDatasetLoader
+    from pylidar_slam_amd.eval import compute_relative_poses
     scans4, gt, tr = _kitti_fixture(tmp_path)
     loader = KITTIDatasetLoader(KITTIConfig(kitti_sequence_dir=str(tmp_path), lidar_height=16, lidar_width=256,
                                             train_sequences=["00"], eval_sequences=[], test_sequences=["00", "17"]))

@@ -577,3 +577,39 @@ def test_weighted_procrustes(torch_cuda, O):
     np.testing.assert_allclose(Tm, O.weighted_procrustes(mirrored, g["ref"]), atol=1e-5)
     with pytest.raises(AssertionError):
         ctx.weighted_procrustes(g["tgt"], g["ref"], np.zeros(g["ref"].shape[0], np.float32))
+
+
+# ---- Voxelization statistics --------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["v02", "v10"])
+def test_voxelization_filter(torch_cuda, O, name):
+    import os
+    from conftest import GOLDEN
+    from pylidar_slam_amd.odometry import Voxelization, VoxelizationConfig
+    g = np.load(os.path.join(GOLDEN, "voxelization.npz"))
+    d = {"numpy_pc": g["pc"]}
+    Voxelization(VoxelizationConfig(voxel_size=float(g[f"{name}_size"]))).filter(d)
+    # integer work bit-exact; the float32 sums follow the sorted order (the reference's own order inside a voxel is
+    # unspecified: its argsort is not stable), so they agree to rounding
+    for k in ("voxel_hashes", "voxel_coordinates", "voxel_sizes", "voxel_indices"):
+        assert d[k].dtype == np.int64
+        np.testing.assert_array_equal(d[k], g[f"{name}_{k}"])
+    assert d["voxel_means"].dtype == np.float32 and d["voxel_covariances"].shape == g[f"{name}_voxel_covariances"].shape
+    np.testing.assert_allclose(d["voxel_means"], g[f"{name}_voxel_means"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(d["voxel_covariances"], g[f"{name}_voxel_covariances"], rtol=1e-4, atol=1e-5)
+    # and bit-exact against the oracle, which sums in the same (stable) order
+    sizes, means, covs, ids = O.voxel_normal_distribution(g["pc"], d["voxel_hashes"])
+    np.testing.assert_allclose(d["voxel_means"], means, rtol=0, atol=2e-6)
+    # without statistics: only coordinates and hashes are written (preprocessing.py:89-92)
+    d2 = {"numpy_pc": g["pc"]}
+    Voxelization(VoxelizationConfig(voxel_size=0.2, with_normal_distribution=False)).filter(d2)
+    assert set(d2) == {"numpy_pc", "voxel_hashes", "voxel_coordinates"}
+    # edge cases: empty cloud, a single point, all points in one voxel
+    ctx = _ctx()
+    e = ctx.voxel_statistics(np.zeros((0, 3), np.float32), 0.2)
+    assert e["num_voxels"] == 0 and e["voxel_sizes"].shape == (0,)
+    one = ctx.voxel_statistics(np.array([[1.0, 2.0, 3.0]], np.float32), 0.2)
+    assert one["num_voxels"] == 1 and one["voxel_sizes"][0] == 1 and np.all(one["voxel_covariances"] == 0)
+    blob = np.random.default_rng(0).uniform(-0.05, 0.05, (500, 3)).astype(np.float32)
+    b = ctx.voxel_statistics(blob, 1.0)
+    assert b["num_voxels"] == 1 and b["voxel_sizes"][0] == 500 and np.all(b["voxel_indices"] == 0)
+    np.testing.assert_allclose(b["voxel_means"][0], blob.mean(axis=0), atol=1e-6)

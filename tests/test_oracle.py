@@ -266,3 +266,20 @@ def test_weighted_procrustes_matches_reference(golden_alignment):
     T = O.weighted_procrustes(g["tgt"], g["ref"])
     assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-12
     np.testing.assert_allclose(T, g["true_pose"], atol=1e-3)
+
+
+# ---- Voxelization statistics --------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["v02", "v10"])
+def test_voxel_normal_distribution_matches_reference(name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "voxelization.npz"))
+    vs = float(g[f"{name}_size"])
+    vox = O.voxelise(g["pc"], vs)
+    hashes = O.voxel_hashing(vox)
+    np.testing.assert_array_equal(vox, g[f"{name}_voxel_coordinates"])
+    np.testing.assert_array_equal(hashes, g[f"{name}_voxel_hashes"])
+    sizes, means, covs, ids = O.voxel_normal_distribution(g["pc"], hashes)
+    np.testing.assert_array_equal(sizes, g[f"{name}_voxel_sizes"])
+    np.testing.assert_array_equal(ids, g[f"{name}_voxel_indices"])
+    np.testing.assert_allclose(means, g[f"{name}_voxel_means"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(covs, g[f"{name}_voxel_covariances"], rtol=1e-4, atol=1e-5)
