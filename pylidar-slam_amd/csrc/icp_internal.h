@@ -163,7 +163,7 @@ struct icp_ctx {
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer nn_cache;        // int2[N]: (NN position, bits(L)) — L = lower bound on the distance to every other map point
     int iter_in_registration = 0;
-    int use_nn_cache = 1;              // env ICP_NN_CACHE
+    int use_nn_cache = 2;              // env ICP_NN_CACHE: 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
     icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row
     int search_stats = 0;              // env ICP_SEARCH_STATS: count which path resolved each query (dev)

@@ -286,12 +286,16 @@ __device__ inline bool coop_rings(const GridView& lv, float px, float py, float 
 // `stack` = this lane's column of an LDS array [7][blockDim] (stride = blockDim): the neighbour cells it still has to
 // scan.  Scanning them from a per-lane list lets every lane walk ITS cells back to back; looping over the 7 row entries
 // in lockstep instead makes the whole wave pay one pass (probe of the predicate + 4 loads + wait) per entry.
+// `seed_*` (optional, seed_pos < 0: none): a map point already known to be a candidate — the neighbour cached by the
+// previous iteration.  It only tightens the starting upper bound (neighbour cells farther than it are pruned before
+// they are read); the (distance, index) minimum over the map is the same with or without it.
 __device__ inline Best search_rows_group(const GridView& g, float px, float py, float pz, int sub, int max_rings,
-                                         int2* __restrict__ stack, int stride) {
+                                         int2* __restrict__ stack, int stride, float seed_d2 = INFINITY,
+                                         int seed_idx = 0x7fffffff, int seed_pos = -1) {
     Best b;
-    b.d2 = INFINITY;
-    b.idx = 0x7fffffff;
-    b.pos = -1;
+    b.d2 = seed_d2;
+    b.idx = seed_idx;
+    b.pos = seed_pos;
     b.second = INFINITY;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
@@ -473,6 +477,8 @@ __global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const f
         int pos = -1;
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         bool hit = false;
+        float seed_d2 = INFINITY;
+        int seed_idx = 0x7fffffff, seed_pos = -1;
         if (use_cache) {
             const int2 c = nn_cache[qi];
             if (c.x >= 0) {
@@ -488,11 +494,16 @@ __global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const f
                 if (hit) {
                     pos = c.x;
                     if (sub == 0) nn_cache[qi] = make_int2(c.x, __float_as_int(L));
+                } else if (use_cache > 1) {  // not provably still the nearest, but a candidate: seed the search with it
+                    seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    seed_idx = __float_as_int(q.w);
+                    seed_pos = c.x;
                 }
             }
         }
         if (!hit) {  // group-uniform: the 4 lanes read the same cache entry
-            const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS);
+            const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS,
+                                             seed_d2, seed_idx, seed_pos);
             if (sub == 0) {
                 pos = b.pos;
                 if (pos >= 0) q = g.pts[pos];
@@ -1092,7 +1103,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
                        ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings, ctx->normals.as<float4>(),
                        make_align_params(ctx), ctx->partials.as<double>(), ctx->nn_cache.as<int2>(),
-                       (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? 1 : 0);
+                       (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;
