@@ -222,12 +222,15 @@ static int export_finish(icp_ctx* ctx, void* dst, const void* dev, size_t n_byte
 }
 
 static int ensure_state(icp_ctx* ctx) {
-    ICP_HIP(ctx, ctx->state.reserve(sizeof(RegState)));
+    static_assert(sizeof(RegState) <= STATE_BLOCK, "RegState outgrew its slot");
     const int cap = ctx->cfg.max_num_alignments > 1 ? ctx->cfg.max_num_alignments : 1;
-    if (cap > ctx->hist_cap) {
-        ICP_HIP(ctx, ctx->loss_hist.reserve((size_t)cap * sizeof(double)));
-        ICP_HIP(ctx, ctx->dx_hist.reserve((size_t)cap * 6 * sizeof(float)));
-        ctx->hist_cap = cap;
+    if (cap > ctx->hist_cap || !ctx->state.ptr) {
+        const int newcap = cap > ctx->hist_cap ? cap : ctx->hist_cap;
+        ICP_HIP(ctx, ctx->state.reserve(STATE_BLOCK + (size_t)newcap * (sizeof(double) + 6 * sizeof(float))));
+        ctx->hist_cap = newcap;
+        ctx->have_device_pose = false;  // a fresh allocation holds no registration result
+        ctx->loss_hist = (double*)(ctx->state.as<char>() + STATE_BLOCK);
+        ctx->dx_hist = (float*)(ctx->state.as<char>() + STATE_BLOCK + (size_t)newcap * sizeof(double));
     }
     ICP_HIP(ctx, ctx->neq_own.reserve(NEQ * sizeof(double)));
     if (!ctx->neq) ctx->neq = ctx->neq_own.as<double>();
@@ -310,13 +313,13 @@ void icp_destroy(icp_ctx* ctx) {
     (void)hipDeviceSynchronize();
     DeviceBuffer* bufs[] = {&ctx->map_xyz[0], &ctx->map_xyz[1], &ctx->table,   &ctx->sorted_pts, &ctx->normals,
                             &ctx->nflag,      &ctx->slot_of,    &ctx->rank_of, &ctx->scan_tmp,   &ctx->worklist,
-                            &ctx->targets,    &ctx->nn_pos,     &ctx->partials, &ctx->state,     &ctx->loss_hist,
-                            &ctx->dx_hist,    &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
+                            &ctx->targets,    &ctx->nn_pos,     &ctx->partials, &ctx->state,
+                            &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
                             &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
                             &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
-                            &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->ctable,
-                            &ctx->csorted,    &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
+                            &ctx->rows,       &ctx->row_of_pos, &ctx->cell_flags, &ctx->cell_ids,  &ctx->cslot_of,
+                            &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out};
     for (DeviceBuffer* b : bufs) b->release();
@@ -1070,9 +1073,10 @@ int icp_iteration_solve(icp_ctx* ctx) {
     return launch_solve(ctx);
 }
 
-// layout of the pinned result block: RegState | int stats[4] | double loss[hist_cap] | float dx[6 * hist_cap]
-static size_t host_result_size(const icp_ctx* ctx) {
-    return sizeof(RegState) + 16 + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
+// layout of the pinned result block: the device state allocation verbatim (RegState | pad | loss[hist_cap] |
+// dx[6 * hist_cap]) followed by int stats[4]
+static size_t state_bytes(const icp_ctx* ctx) {
+    return STATE_BLOCK + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
 }
 
 // the grid statistics about to be read back belong to the current build; a later build starts a new pending set
@@ -1084,7 +1088,7 @@ static void snapshot_stats(icp_ctx* ctx) {
 }
 
 static int enqueue_result_copy(icp_ctx* ctx) {
-    const size_t need = host_result_size(ctx);
+    const size_t sb = state_bytes(ctx), need = sb + 16;
     if (need > ctx->host_result_bytes) {
         if (ctx->host_result) (void)hipHostFree(ctx->host_result);
         ctx->host_result = nullptr;
@@ -1094,17 +1098,10 @@ static int enqueue_result_copy(icp_ctx* ctx) {
     }
     if (!ctx->result_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->result_event, hipEventDisableTiming));
     char* h = (char*)ctx->host_result;
-    ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sizeof(RegState), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));  // state + histories
     snapshot_stats(ctx);
     if (ctx->stats_at_launch)
-        ICP_HIP(ctx, hipMemcpyAsync(h + sizeof(RegState), ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->hist_cap > 0) {
-        char* lh = h + sizeof(RegState) + 16;
-        ICP_HIP(ctx, hipMemcpyAsync(lh, ctx->loss_hist.ptr, (size_t)ctx->hist_cap * sizeof(double),
-                                    hipMemcpyDeviceToHost, ctx->stream));
-        ICP_HIP(ctx, hipMemcpyAsync(lh + (size_t)ctx->hist_cap * sizeof(double), ctx->dx_hist.ptr,
-                                    (size_t)ctx->hist_cap * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    }
+        ICP_HIP(ctx, hipMemcpyAsync(h + sb, ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipEventRecord(ctx->result_event, ctx->stream));
     ctx->result_pending = true;
     return ICP_OK;
@@ -1122,7 +1119,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         ctx->result_pending = false;
         ICP_HIP(ctx, hipEventSynchronize(ctx->result_event));
         memcpy(&st, ctx->host_result, sizeof(st));
-        memcpy(stats, (const char*)ctx->host_result + sizeof(RegState), sizeof(stats));
+        memcpy(stats, (const char*)ctx->host_result + state_bytes(ctx), sizeof(stats));
     } else {
         ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         if (had_stats)
@@ -1154,15 +1151,15 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     result->normals_computed = st.normals_computed;
     const int k = st.iter < ctx->hist_cap ? st.iter : ctx->hist_cap;
     if (async) {
-        const char* lh = (const char*)ctx->host_result + sizeof(RegState) + 16;
+        const char* lh = (const char*)ctx->host_result + STATE_BLOCK;
         if (k > 0 && loss_per_iter_out) memcpy(loss_per_iter_out, lh, (size_t)k * sizeof(double));
         if (k > 0 && dx_per_iter_out)
             memcpy(dx_per_iter_out, lh + (size_t)ctx->hist_cap * sizeof(double), (size_t)k * 6 * sizeof(float));
     } else {
         if (k > 0 && loss_per_iter_out)
-            ICP_HIP(ctx, hipMemcpy(loss_per_iter_out, ctx->loss_hist.ptr, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
+            ICP_HIP(ctx, hipMemcpy(loss_per_iter_out, ctx->loss_hist, (size_t)k * sizeof(double), hipMemcpyDeviceToHost));
         if (k > 0 && dx_per_iter_out)
-            ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist.ptr, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
+            ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
     }
     if (ctx->prof.enabled) prof_collect(ctx);
     if (st.status == ICP_ERR_INVALID_JACOBIAN)

@@ -223,6 +223,23 @@ __device__ inline void sum_partials_block(const double* __restrict__ partials, i
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     int b = grp;
+    if (nblocks == 1024) {  // the 131072-point scan: all 32 loads of a thread in flight at once, same order of additions
+        double v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = partials[(size_t)(grp + 32 * j) * NEQ + col];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            s0 += v[8 * pass];
+            s1 += v[8 * pass + 1];
+            s2 += v[8 * pass + 2];
+            s3 += v[8 * pass + 3];
+            s4 += v[8 * pass + 4];
+            s5 += v[8 * pass + 5];
+            s6 += v[8 * pass + 6];
+            s7 += v[8 * pass + 7];
+        }
+        b = nblocks + grp;  // nothing left for the loops below
+    }
     for (; b + 224 < nblocks; b += 256) {  // eight independent loads in flight
         s0 += partials[(size_t)b * NEQ + col];
         s1 += partials[(size_t)(b + 32) * NEQ + col];
@@ -302,7 +319,7 @@ __device__ inline void from_pose_f32(const float* T, float* p) {  // pose.py:188
 // (0 if a pivot is not positive: H = J^T J is PSD, so that only happens for a numerically singular system) and solves
 // H x = b.
 __device__ inline double solve6(double A[6][6], double* b, double* x) {
-    double L[6][6];
+    double L[6][6], rinv[6];
     double det = 1.0;
     bool ok = true;
 #pragma unroll
@@ -316,6 +333,7 @@ __device__ inline double solve6(double A[6][6], double* b, double* x) {
         L[j][j] = ljj;
         det *= d;
         const double inv = 1.0 / ljj;
+        rinv[j] = inv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i > j) {
@@ -334,7 +352,7 @@ __device__ inline double solve6(double A[6][6], double* b, double* x) {
 #pragma unroll
         for (int k = 0; k < 6; ++k)
             if (k < i) v -= L[i][k] * y[k];
-        y[i] = v / L[i][i];
+        y[i] = v * rinv[i];  // 1 / L[i][i], already formed for the column scaling
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
@@ -342,7 +360,7 @@ __device__ inline double solve6(double A[6][6], double* b, double* x) {
 #pragma unroll
         for (int k = 0; k < 6; ++k)
             if (k > i) v -= L[k][i] * x[k];
-        x[i] = v / L[i][i];
+        x[i] = v * rinv[i];
     }
     return ok ? det : 0.0;
 }
@@ -379,9 +397,11 @@ __device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double
     return ICP_OK;
 }
 
+// `it` / `pose_in`: st->iter and st->pose as read by the caller (k_sum_solve fetches them while the partial rows are
+// still in flight; the other callers read them on the spot)
 __device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
-                                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
-    const int it = st->iter;
+                                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
+                                        int it, const float* pose_in) {
     st->n_worklist = 0;
     st->n_targets = (int)neq[29];
     float dx[6];
@@ -408,12 +428,12 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
     }
     // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
     float D[16], P[16];
-    for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = st->pose[k2];
+    for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = pose_in[k2];
     build_pose_f32(dx, D);
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 4; ++c) {
             float s = 0.f;
-            for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * st->pose[4 * k2 + c];
+            for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * pose_in[4 * k2 + c];
             P[4 * r + c] = s;
         }
     float prm[6];
@@ -427,7 +447,9 @@ __global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ ne
                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->done) return;
-    solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap);
+    float pose_in[16];
+    for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+    solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap, st->iter, pose_in);
 }
 
 // single-GPU path: final sum of the partial rows + solve + pose update in one launch
@@ -435,12 +457,21 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
                                                     RegState* __restrict__ st, AlignParams ap,
                                                     double* __restrict__ neq, double* __restrict__ loss_hist,
                                                     float* __restrict__ dx_hist, int hist_cap) {
-    if (st->done) return;
+    // the state words are requested first and consumed last: their latency hides behind the partial-row loads
+    const int done = st->done;
+    int it = 0;
+    float pose_in[16];
+    if (threadIdx.x == 0) {
+        it = st->iter;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+    }
     __shared__ double total[NEQ];
     sum_partials_block(partials, nblocks, total);
     __syncthreads();
+    if (done) return;
     if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
-    if (threadIdx.x == 0) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap);
+    if (threadIdx.x == 0) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
 }
 
 // align() on given correspondences: writes params = x0 + dx [6], pose[16] = build_pose_matrix(params) (f32) and loss
@@ -495,8 +526,8 @@ int launch_reduce(icp_ctx* ctx) {
 // final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
 int launch_sum_solve(icp_ctx* ctx, int blocks) {
     hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
-                       ctx->dx_hist.as<float>(), ctx->hist_cap);
+                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
+                       ctx->dx_hist, ctx->hist_cap);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -517,8 +548,8 @@ int launch_reduce_solve(icp_ctx* ctx) {
                        ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        make_align_params(ctx), ctx->partials.as<double>());
     hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist.as<double>(),
-                       ctx->dx_hist.as<float>(), ctx->hist_cap);
+                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
+                       ctx->dx_hist, ctx->hist_cap);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -526,7 +557,7 @@ int launch_reduce_solve(icp_ctx* ctx) {
 
 int launch_solve(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), ctx->neq, make_align_params(ctx),
-                       ctx->loss_hist.as<double>(), ctx->dx_hist.as<float>(), ctx->hist_cap);
+                       ctx->loss_hist, ctx->dx_hist, ctx->hist_cap);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -87,6 +87,8 @@ struct RegState {
     long long normals_computed;
 };
 
+static constexpr size_t STATE_BLOCK = 256;  // bytes reserved for the RegState at the head of the state allocation
+
 struct AlignParams {
     int scheme;
     float sigma;
@@ -135,7 +137,8 @@ struct icp_ctx {
     icp::DeviceBuffer nflag;           // int[M]: 0 none, 2 queued, 1 ready
     icp::DeviceBuffer slot_of, rank_of;  // int[M] temporaries of the build
     icp::DeviceBuffer row_of_slot, slot_of_cell, rows, row_of_pos, cell_flags, cell_ids;
-    icp::DeviceBuffer ctable, csorted, pos_of_orig;  // coarse level
+    icp::DeviceBuffer csorted, pos_of_orig, cslot_of, crank_of;  // coarse level (its table follows the fine one)
+    icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
     icp::DeviceBuffer worklist;        // int[M]
@@ -173,8 +176,10 @@ struct icp_ctx {
     icp::DeviceBuffer partials;        // double[blocks][NEQ]
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
-    icp::DeviceBuffer loss_hist;       // double[max_iters]
-    icp::DeviceBuffer dx_hist;         // float[max_iters][6]
+    // per-iteration histories live behind the RegState in the same allocation (one D2H copy brings back everything):
+    // [RegState, padded to STATE_BLOCK bytes | double loss[hist_cap] | float dx[hist_cap][6]]
+    double* loss_hist = nullptr;
+    float* dx_hist = nullptr;
     icp::DeviceBuffer neq_own;         // double[NEQ]
     double* neq = nullptr;             // active normal-equation vector (own or caller supplied)
     int hist_cap = 0;

@@ -1029,7 +1029,7 @@ static GridView make_view(icp_ctx* ctx) {
     g.row_of_slot = ctx->row_of_slot.as<int>();
     g.rows = ctx->rows.as<int2>();
     g.row_of_pos = ctx->row_of_pos.as<int>();
-    g.ctable = ctx->ctable.as<GridEntry>();
+    g.ctable = ctx->ctable_ptr;
     g.cmask = ctx->ctable_size ? ctx->ctable_size - 1 : 0;
     g.ch = ctx->cell_h * COARSE_FACTOR;
     g.cinv_h = 1.0f / g.ch;
