@@ -64,6 +64,7 @@ def parse():
                          "of 8 scans spread around it (the guess is always right, but most scans are taken up to 2.4 m "
                          "and 22 deg away from the nearest map scan: longer searches)")
     ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
+    ap.add_argument("--max-rings", type=int, default=2, help="fine-level rings searched before the coarse level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
     return ap.parse_args()
@@ -161,7 +162,8 @@ def main():
     cfg, scans, poses, model, order = make_workload(0 if sharded else rank, args.trajectory, args.warmup + args.steps)
     n_pts = scans[order[0]].shape[0]
     ctx = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
-                     scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size, device=local_rank)
+                     scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size, max_rings=args.max_rings,
+                     device=local_rank)
     ctx.use_torch_stream()
     dev = torch.device("cuda", local_rank)
     scans_dev = {f: torch.from_numpy(s).to(dev) for f, s in scans.items()}
@@ -192,7 +194,7 @@ def main():
 
     run(args.warmup, 0)
     if not args.no_profile:
-        ctx.profile_enable(1)
+        ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4 adds the normals
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -251,6 +253,8 @@ def main():
                                "frac": achieved / HBM_PEAK, "traffic": traffic,
                                "avg_launch_us": avg_s * 1e6, "launches": prof["search_launches"],
                                "algorithmic_bytes_per_launch": BYTES_PER_POINT_ITER * n_local}
+        if prof and prof.get("normals_ms", 0.0) > 0.0:
+            out["normals_ms_per_step"] = prof["normals_ms"] / args.steps
         if not args.no_cpu_baseline and world == 1:
             f = order[(args.warmup + args.steps - 1) % len(order)]
             cb, _ = cpu_baseline(scans[f], model, args)

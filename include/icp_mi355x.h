@@ -72,7 +72,7 @@ typedef struct {
     /* MI355X-side knobs (no reference counterpart) */
     float cell_size;   /* voxel-hash cell edge in metres; <= 0: auto-tuned towards ~6 map points per occupied cell.
                           Search results never depend on it (the search is exact), only speed does */
-    int32_t max_rings; /* ring expansion limit before the exhaustive fallback (exactness is kept either way) */
+    int32_t max_rings; /* fine-level rings searched before the coarse level / exhaustive fallback (default 2; exactness is kept either way) */
     int32_t device;    /* HIP device ordinal */
     int32_t poll_every; /* host polls the device-side `done` flag every N iterations (0: never; implied by threshold <= 0) */
 } icp_config;

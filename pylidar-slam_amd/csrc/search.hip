@@ -737,14 +737,14 @@ __device__ inline void knn_rings(const GridView& g, float px, float py, float pz
     scan_cell_knn<KN>(g, 0, g.m, px, py, pz, t);
 }
 
-template <int KN>
-__device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m);
+template <int KN, int NL>
+__device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m);
 
 // kNN counterpart of `coop_rings`: rings r_begin..r_end of one level by the 4 lanes of a map point.  `m` is the merged
 // list so far (identical in the 4 lanes); per ring lane 0 continues from it, the others from empty lists, every lane
 // inserts its share of the ring, and the lists are merged again.  Keys carry original indices, so fine and coarse
 // levels mix freely.  Returns true when the k-th neighbour is provably exact on this level.
-template <int KN>
+template <int KN, int NL>
 __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end,
                                       TopK<KN>& m) {
     const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
@@ -764,7 +764,7 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
         int start, count;
         if (r == 0) {
             if (grid_lookup(lv, cx, cy, cz, start, count)) {
-                for (int k = start + sub; k < start + count; k += 4) {
+                for (int k = start + sub; k < start + count; k += NL) {
                     const float4 q = lv.pts[k];
                     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
                     t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
@@ -772,7 +772,7 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
             }
         } else {
             const int side = 2 * r + 1, total = side * side * side;
-            for (int c = sub; c < total; c += 4) {
+            for (int c = sub; c < total; c += NL) {
                 const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
                 const int mx = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
                 if (mx < r) continue;
@@ -782,20 +782,20 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
                     scan_cell_knn<KN>(lv, start, count, px, py, pz, t);
             }
         }
-        merge_group4<KN>(t, m);
+        merge_group<KN, NL>(t, m);
         const float bound = (float)r * h + edge;
         if (m.kth() <= bound * bound * 0.999999f) return true;
     }
     return false;
 }
 
-// Neighbourhood covariance of one map point by FOUR lanes (lane 0 of the group writes cov[6]); the eigen-solve that turns
+// Neighbourhood covariance of one map point by NL (4 or 2) lanes (lane 0 of the group writes cov[6]); the eigen-solve that turns
 // it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  A map point always lies in an occupied cell, so its 27-neighbourhood comes
 // from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
 // neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
 // pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
 // level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
-template <int KN>
+template <int KN, int NL>
 __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
                                     int2* __restrict__ stack, int stride) {
     const float4 P = g.pts[s];
@@ -810,10 +810,11 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
     const int2* __restrict__ r = g.rows + (size_t)g.row_of_pos[s] * ROW_STRIDE;
     const int2 own = r[13];
-    int2 cell[7];
+    constexpr int CPL = ROW_STRIDE / NL;  // row entries per lane (entry 27 is padding)
+    int2 cell[CPL];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
-    for (int k = own.x + sub; k < own.x + own.y; k += 4) {
+    for (int k = 0; k < CPL; ++k) cell[k] = r[sub * CPL + k];
+    for (int k = own.x + sub; k < own.x + own.y; k += NL) {
         const float4 q = g.pts[k];
         const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
         t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
@@ -822,8 +823,8 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
     // walking the 7 row entries in lockstep would make the wave pay every lane's longest cell 7 times over)
     int nl = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int c = sub * 7 + k;
+    for (int k = 0; k < CPL; ++k) {
+        const int c = sub * CPL + k;
         if (c == 13 || c >= 27 || cell[k].y <= 0) continue;
         stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
         ++nl;
@@ -850,15 +851,15 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
         }
     }
     TopK<KN> m;
-    merge_group4<KN>(t, m);
+    merge_group<KN, NL>(t, m);
     const float bound1 = h + edge;
     bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
     if (!exact && !(g_debug_flags & 4)) {
         // fine rings 2..max_rings, then the coarse level, each ring split over the 4 lanes
-        exact = max_rings >= 2 && coop_knn_rings<KN>(g, px, py, pz, sub, 2, max_rings, m);
+        exact = max_rings >= 2 && coop_knn_rings<KN, NL>(g, px, py, pz, sub, 2, max_rings, m);
         if (!exact && g.ctable) {
             m.init();  // the coarse rings start at ring 0 and re-find the fine results: starting empty avoids duplicates
-            exact = coop_knn_rings<KN>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, m);
+            exact = coop_knn_rings<KN, NL>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, m);
         }
         if (!exact && sub == 0) {  // farther than COARSE_RINGS coarse cells from k map points: exhaustive
             m.init();
@@ -869,14 +870,14 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
     neighbourhood_cov<KN>(g, px, py, pz, m, cov);
 }
 
-// merge of the four lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
-template <int KN>
-__device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m) {
+// merge of the NL lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
+template <int KN, int NL>
+__device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 #pragma unroll
     for (int round = 0; round < KN; ++round) {
         unsigned long long best = t.key[0];
 #pragma unroll
-        for (int o = 1; o <= 2; o <<= 1) {
+        for (int o = 1; o < NL; o <<= 1) {
             const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
             const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
             const unsigned long long other = ((unsigned long long)hi << 32) | lo;
@@ -890,27 +891,28 @@ __device__ inline void merge_group4(TopK<KN>& t, TopK<KN>& m) {
     }
 }
 
-// Block = NRM_POINTS map points x 4 lanes: the 4-lane groups leave their covariances in LDS, then the first
-// NRM_POINTS threads (whole waves, every lane busy) run the Jacobi eigen-solves — a 4-lane group would otherwise spend
-// the ~1.5k-instruction solve with one lane in four active.
-static constexpr int NRM_POINTS = 64;
-static constexpr int NRM_THREADS = 4 * NRM_POINTS;
+// Block = NRM_THREADS / NL map points x NL lanes: the groups leave their covariances in LDS, then the first threads
+// (whole waves, every lane busy) run the Jacobi eigen-solves — a group would otherwise spend the ~1.5k-instruction solve
+// with one lane in NL active.
+static constexpr int NRM_THREADS = 256;
 
 // lazy: the map points queued by the search of this iteration
-template <int KN>
+template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
                                                          const int* __restrict__ worklist, int max_rings,
                                                          float4* __restrict__ normals, int* __restrict__ nflag) {
+    constexpr int PTS = NRM_THREADS / NL;
     if (st->done) return;
-    __shared__ int2 cellstack[7][NRM_THREADS];
-    __shared__ float covs[NRM_POINTS][7];
+    __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
+    __shared__ float covs[PTS][7];
     const int nw = st->n_worklist;
-    const int sub = threadIdx.x & 3, lq = threadIdx.x >> 2;
-    for (int base = blockIdx.x * NRM_POINTS; base < nw; base += gridDim.x * NRM_POINTS) {  // block-uniform trip count
+    const int sub = threadIdx.x % NL, lq = threadIdx.x / NL;
+    for (int base = blockIdx.x * PTS; base < nw; base += gridDim.x * PTS) {  // block-uniform trip count
         const int w = base + lq;
-        if (w < nw) estimate_cov<KN>(g, worklist[w], sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+        if (w < nw)
+            estimate_cov<KN, NL>(g, worklist[w], sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
         __syncthreads();
-        if (threadIdx.x < NRM_POINTS && base + (int)threadIdx.x < nw)
+        if (threadIdx.x < PTS && base + (int)threadIdx.x < nw)
             normal_from_cov(covs[threadIdx.x], worklist[base + threadIdx.x], normals, nflag);
         __syncthreads();
     }
@@ -919,17 +921,19 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
 
 // eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values
 // are the same either way: a normal depends on the map only)
-template <int KN>
+template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
-    __shared__ int2 cellstack[7][NRM_THREADS];
-    __shared__ float covs[NRM_POINTS][7];
-    const int lq = threadIdx.x >> 2;
-    const int s = blockIdx.x * NRM_POINTS + lq;
-    if (s < g.m) estimate_cov<KN>(g, s, threadIdx.x & 3, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+    constexpr int PTS = NRM_THREADS / NL;
+    __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
+    __shared__ float covs[PTS][7];
+    const int lq = threadIdx.x / NL;
+    const int s = blockIdx.x * PTS + lq;
+    if (s < g.m)
+        estimate_cov<KN, NL>(g, s, threadIdx.x % NL, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
     __syncthreads();
-    const int s2 = blockIdx.x * NRM_POINTS + threadIdx.x;
-    if (threadIdx.x < NRM_POINTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+    const int s2 = blockIdx.x * PTS + threadIdx.x;
+    if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -1062,7 +1066,44 @@ int launch_search(icp_ctx* ctx) {
     return ICP_OK;
 }
 
+// fine rings tried by the kNN before it moves to the coarse level: ring 3 means 218 hashed probes for a handful of extra
+// candidates, the coarse level reaches the same points through a few 4x larger cells (measured: 233 -> 199 us per
+// 100k-point map with 2 instead of 3).  env ICP_KNN_RINGS overrides.
+static int knn_fine_rings(const icp_ctx* ctx) {
+    static int env = -2;
+    if (env == -2) {
+        const char* v = getenv("ICP_KNN_RINGS");
+        env = v ? atoi(v) : -1;
+    }
+    if (env >= 0) return env;
+    return ctx->cfg.max_rings < 2 ? ctx->cfg.max_rings : 2;
+}
+
 // eager estimation of every map normal (only for the k with a register-resident top-k list)
+// lanes per map point in the kNN kernels (env ICP_KNN_LANES = 2 or 4)
+static int knn_lanes() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("ICP_KNN_LANES");
+        v = (e && atoi(e) == 2) ? 2 : 4;
+    }
+    return v;
+}
+
+template <int NL>
+static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
+    const int blocks = (int)((ctx->map_m + NRM_THREADS / NL - 1) / (NRM_THREADS / NL));
+    const int rings = knn_fine_rings(ctx);
+    float4* nrm = ctx->normals.as<float4>();
+    int* nf = ctx->nflag.as<int>();
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+    else
+        hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+}
+
 int launch_normals_all(icp_ctx* ctx) {
     static int dbg_init = 0;
     if (!dbg_init) {
@@ -1075,18 +1116,12 @@ int launch_normals_all(icp_ctx* ctx) {
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
-    const int blocks = (int)((ctx->map_m + NRM_POINTS - 1) / NRM_POINTS);
     GridView g = make_view(ctx);
     const int tok = prof_begin(ctx, 2);
-    if (kn == 11)
-        hipLaunchKernelGGL(k_normals_all<11>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
-                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
-    else if (kn == 6)
-        hipLaunchKernelGGL(k_normals_all<6>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
-                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
+    if (knn_lanes() == 2)
+        launch_normals_all_t<2>(ctx, kn, g);
     else
-        hipLaunchKernelGGL(k_normals_all<21>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, ctx->cfg.max_rings,
-                           ctx->normals.as<float4>(), ctx->nflag.as<int>());
+        launch_normals_all_t<4>(ctx, kn, g);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->normals_ready = true;
@@ -1111,29 +1146,41 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     return ICP_OK;
 }
 
+template <int NL>
+static void launch_normals_t(icp_ctx* ctx, int kn, const GridView& g, int64_t cap) {
+    constexpr int PTS = NRM_THREADS / NL;
+    int blocks = (int)((cap + PTS - 1) / PTS);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    const int rings = knn_fine_rings(ctx);
+    RegState* st = reg_state(ctx);
+    const int* wl = ctx->worklist.as<int>();
+    float4* nrm = ctx->normals.as<float4>();
+    int* nf = ctx->nflag.as<int>();
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
+    else
+        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
+}
+
 int launch_normals(icp_ctx* ctx) {
     if (ctx->normals_ready) return ICP_OK;
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     // the worklist length lives on the device: launch a fixed grid and stride over it
-    int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
-    int blocks = (int)((cap + NRM_POINTS - 1) / NRM_POINTS);  // 4 lanes per queued map point
-    if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
+    const int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
     const int tok = prof_begin(ctx, 2);
     GridView g = make_view(ctx);
-    if (kn == 11) {
-        hipLaunchKernelGGL(k_normals<11>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
-                           ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
-                           ctx->nflag.as<int>());
-    } else if (kn == 6) {
-        hipLaunchKernelGGL(k_normals<6>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
-                           ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
-                           ctx->nflag.as<int>());
-    } else if (kn == 21) {
-        hipLaunchKernelGGL(k_normals<21>, dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, reg_state(ctx),
-                           ctx->worklist.as<int>(), ctx->cfg.max_rings, ctx->normals.as<float4>(),
-                           ctx->nflag.as<int>());
+    if (kn == 11 || kn == 6 || kn == 21) {
+        if (knn_lanes() == 2)
+            launch_normals_t<2>(ctx, kn, g, cap);
+        else
+            launch_normals_t<4>(ctx, kn, g, cap);
     } else {
+        int blocks = (int)((cap + 127) / 128);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_normals_generic, dim3(blocks), dim3(128), 0, ctx->stream, g, reg_state(ctx),
                            ctx->worklist.as<int>(), kn, ctx->normals.as<float4>(), ctx->nflag.as<int>());
     }

@@ -59,7 +59,7 @@ class IcpContext:
     def __init__(self, height: int = 64, width: int = 1024, up_fov: float = 3.0, down_fov: float = -24.0,
                  max_num_alignments: int = 100, threshold_delta_pose: float = 1.0e-4, scheme: str = "default",
                  sigma: float = 0.5, local_map_size: int = 20, num_neighbors_normals: int = 10,
-                 cell_size: float = 0.0, max_rings: int = 3, device: int = 0, poll_every: int = 4):
+                 cell_size: float = 0.0, max_rings: int = 2, device: int = 0, poll_every: int = 4):
         self._lib = _lib.load_library()
         cfg = IcpConfig()
         self._lib.icp_default_config(C.byref(cfg))

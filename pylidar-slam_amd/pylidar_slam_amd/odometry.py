@@ -459,7 +459,7 @@ class MI355XICPConfig:
     viz_debug: bool = False
     # MI355X-side knobs
     cell_size: float = 0.0  # <= 0: auto-tuned
-    max_rings: int = 3
+    max_rings: int = 2
 
 
 def _get(obj, key, default=None):
