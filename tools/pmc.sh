@@ -4,7 +4,7 @@
 R=$PWD; K=${1:-k_search}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_$C.log 2>&1
+  timeout 100 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_$C.log 2>&1
 done
 cd $R && python - <<PY
 import csv, glob, json
