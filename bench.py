@@ -23,6 +23,9 @@ N > 1: one process per GPU, every rank tracks its own independent scan sequence 
 collective) -> weak scaling; `--mode sharded` instead splits every scan's points across the ranks and all-reduces the
 packed 6x6 normal equations (32 doubles) over RCCL once per ICP iteration (strong scaling of one sequence).
 
+`--sequences-per-gpu S` (throughput mode, default 1): S independent sequences per GPU on S contexts / HIP streams / host
+threads; one sequence is a chain of dependent, latency-bound kernels and leaves most of the GPU idle.
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-iteration fused search + rows kernel),
 timed with HIP events on the library's stream inside the timed region; `cpu_baseline` times the numpy/cKDTree oracle
 (oracle/icp_oracle.py, a restatement of the reference's CPU path) on one frame of the same workload.
@@ -65,6 +68,10 @@ def parse():
                          "and 22 deg away from the nearest map scan: longer searches)")
     ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
     ap.add_argument("--max-rings", type=int, default=2, help="fine-level rings searched before the coarse level")
+    ap.add_argument("--sequences-per-gpu", type=int, default=1,
+                    help="throughput mode: S independent sequences per GPU, each with its own context and HIP stream, "
+                         "driven by S host threads (one sequence cannot fill the GPU: its kernels are latency-bound and "
+                         "serially dependent).  `value` then counts all sequences; ms_per_step stays the per-frame latency")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
     return ap.parse_args()
@@ -192,14 +199,76 @@ def main():
             state["prev_frame"] = f
         return res
 
+    # ---- throughput mode: S - 1 more sequences on their own contexts / streams / host threads
+    extra = []
+    S = max(1, args.sequences_per_gpu)
+    if S > 1:
+        assert not sharded, "--sequences-per-gpu applies to independent sequences"
+        import threading
+
+        class Sequence(threading.Thread):
+            def __init__(self, j):
+                super().__init__(daemon=True)
+                self.j = j
+                self.go = threading.Event()
+                self.done = threading.Event()
+                self.phase = None
+                self.max_err = 0.0
+                self.stream = torch.cuda.Stream(device=dev)
+
+            def run(self):
+                torch.cuda.set_device(local_rank)
+                with torch.cuda.stream(self.stream):
+                    _, sc, ps, mdl, od = make_workload(rank * S + self.j + 100, args.trajectory, args.warmup + args.steps)
+                    c = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
+                                   scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size,
+                                   max_rings=args.max_rings, device=local_rank)
+                    c.use_torch_stream()
+                    sd = {f: torch.from_numpy(x).to(dev) for f, x in sc.items()}
+                    vm = torch.empty((3, 64, 2048), dtype=torch.float32, device=dev)
+                    c.map_set(torch.from_numpy(mdl).to(dev))
+                    last, prev, first = None, 0, 0
+                    while True:
+                        self.go.wait()
+                        self.go.clear()
+                        if self.phase is None:
+                            c.close()
+                            return
+                        for i in range(self.phase):
+                            f = od[(first + i) % len(od)]
+                            r = step_replica(c, sd[f], vm, last if args.init == "cv" else None)
+                            last = r.pose
+                            gt = np.linalg.inv(ps[prev]) @ ps[f]
+                            self.max_err = max(self.max_err, float(np.linalg.norm(gt[:3, 3] - r.pose[:3, 3])))
+                            prev = f
+                        first += self.phase
+                        self.stream.synchronize()
+                        self.done.set()
+
+            def start_phase(self, k):
+                self.phase = k
+                self.done.clear()
+                self.go.set()
+
+        extra = [Sequence(j) for j in range(1, S)]
+        for t_ in extra:
+            t_.start()
+        for t_ in extra:
+            t_.start_phase(args.warmup)
     run(args.warmup, 0)
+    for t_ in extra:
+        t_.done.wait()
     if not args.no_profile:
         ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4 adds the normals
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for t_ in extra:
+        t_.start_phase(args.steps)
     res = run(args.steps, args.warmup)
+    for t_ in extra:
+        t_.done.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -218,7 +287,7 @@ def main():
     gt_err = float(np.linalg.norm(gt_rel[:3, 3] - res.pose[:3, 3]))
 
     if rank == 0:
-        scans_total = args.steps * (1 if sharded else world)
+        scans_total = args.steps * (1 if sharded else world) * S
         value = scans_total / elapsed
         ms_step = elapsed * 1e3 / args.steps
         out = {
@@ -231,9 +300,10 @@ def main():
                                    "+ map re-expression/rebuild",
                        "scheme": args.scheme, "sigma": args.sigma, "cell_size_m": args.cell_size,
                        "parallelism": ("points-sharded + RCCL all-reduce of 6x6 normal equations" if sharded else
-                                       f"{world} independent sequences (replicated map, no collective)")},
+                                       f"{world * S} independent sequences, {S} per GPU (replicated map, no collective)")},
             "last_pose_error_vs_ground_truth_m": gt_err,
-            "max_pose_error_vs_ground_truth_m": state["max_err"], "init": args.init, "trajectory": args.trajectory,
+            "max_pose_error_vs_ground_truth_m": max([state["max_err"]] + [t_.max_err for t_ in extra]),
+            "init": args.init, "trajectory": args.trajectory, "sequences_per_gpu": S,
             "iterations_last_frame": int(res.iterations),
         }
         if prof and prof["search_launches"] > 0:
@@ -260,6 +330,11 @@ def main():
             cb, _ = cpu_baseline(scans[f], model, args)
             out["cpu_baseline"] = cb
         print(json.dumps(out))
+    for t_ in extra:
+        t_.phase = None
+        t_.go.set()
+    for t_ in extra:
+        t_.join(timeout=30)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
