@@ -291,6 +291,8 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
     if (const char* v = getenv("ICP_SEARCH_VARIANT")) ctx->search_variant = atoi(v);
     if (const char* v = getenv("ICP_SORT_TARGETS")) ctx->sort_targets = atoi(v);
     if (const char* v = getenv("ICP_NN_CACHE")) ctx->use_nn_cache = atoi(v);
+    if (const char* v = getenv("ICP_KNN_RINGS")) ctx->knn_rings = atoi(v);
+    if (const char* v = getenv("ICP_KNN_LANES")) ctx->knn_lanes = atoi(v) == 2 ? 2 : 4;
     if (const char* v = getenv("ICP_SEARCH_STATS")) ctx->search_stats = atoi(v);
     if (ctx->search_stats) {
         if (ctx->dbg_counts.reserve(64) != hipSuccess) ctx->search_stats = 0;

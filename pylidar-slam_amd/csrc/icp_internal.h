@@ -166,6 +166,8 @@ struct icp_ctx {
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer nn_cache;        // int2[N]: (NN position, bits(L)) — L = lower bound on the distance to every other map point
     int iter_in_registration = 0;
+    int knn_rings = -1;                // env ICP_KNN_RINGS: fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
+    int knn_lanes = 4;                 // env ICP_KNN_LANES: lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // env ICP_NN_CACHE: 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
     icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row

@@ -11,6 +11,8 @@
 // Distance ties are broken on the smaller original map index (the kd-tree's tie order is unspecified).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "gn_device.h"
 #include "icp_internal.h"
 #include "search_device.h"
@@ -1068,26 +1070,10 @@ int launch_search(icp_ctx* ctx) {
 
 // fine rings tried by the kNN before it moves to the coarse level: ring 3 means 218 hashed probes for a handful of extra
 // candidates, the coarse level reaches the same points through a few 4x larger cells (measured: 233 -> 199 us per
-// 100k-point map with 2 instead of 3).  env ICP_KNN_RINGS overrides.
+// 100k-point map with 2 instead of 3).  env ICP_KNN_RINGS (read in icp_create) overrides.
 static int knn_fine_rings(const icp_ctx* ctx) {
-    static int env = -2;
-    if (env == -2) {
-        const char* v = getenv("ICP_KNN_RINGS");
-        env = v ? atoi(v) : -1;
-    }
-    if (env >= 0) return env;
+    if (ctx->knn_rings >= 0) return ctx->knn_rings;
     return ctx->cfg.max_rings < 2 ? ctx->cfg.max_rings : 2;
-}
-
-// eager estimation of every map normal (only for the k with a register-resident top-k list)
-// lanes per map point in the kNN kernels (env ICP_KNN_LANES = 2 or 4)
-static int knn_lanes() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("ICP_KNN_LANES");
-        v = (e && atoi(e) == 2) ? 2 : 4;
-    }
-    return v;
 }
 
 template <int NL>
@@ -1105,20 +1091,19 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
 }
 
 int launch_normals_all(icp_ctx* ctx) {
-    static int dbg_init = 0;
-    if (!dbg_init) {
-        dbg_init = 1;
+    static std::once_flag dbg_once;  // dev-only ablation switches
+    std::call_once(dbg_once, [] {
         if (const char* v = getenv("ICP_DEBUG_FLAGS")) {
             int f = atoi(v);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_flags), &f, sizeof(int));
         }
-    }
+    });
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
     GridView g = make_view(ctx);
     const int tok = prof_begin(ctx, 2);
-    if (knn_lanes() == 2)
+    if (ctx->knn_lanes == 2)
         launch_normals_all_t<2>(ctx, kn, g);
     else
         launch_normals_all_t<4>(ctx, kn, g);
@@ -1173,7 +1158,7 @@ int launch_normals(icp_ctx* ctx) {
     const int tok = prof_begin(ctx, 2);
     GridView g = make_view(ctx);
     if (kn == 11 || kn == 6 || kn == 21) {
-        if (knn_lanes() == 2)
+        if (ctx->knn_lanes == 2)
             launch_normals_t<2>(ctx, kn, g, cap);
         else
             launch_normals_t<4>(ctx, kn, g, cap);
