@@ -1,0 +1,120 @@
+"""CPU test of the HOST logic of the odometry plugin (`MI355XICPFrameToModel.do_process_next_frame`: input dispatch,
+first-frame map, key-frame thresholds, pose chain, outputs written to the data_dict) with the numpy oracle standing in for
+the HIP context — the same loop runs on the real `IcpContext` in tests/test_gpu_parity.py.  The stand-in implements the
+handful of `IcpContext` calls the plugin makes; it is test infrastructure and lives here, not in the package."""
+import numpy as np
+import pytest
+import torch
+
+import icp_oracle as O
+
+
+class OracleContext:
+    """`IcpContext` protocol used by MI355XICPFrameToModel / HashGridLocalMap, computed by oracle/icp_oracle.py."""
+    device = torch.device("cpu")
+
+    def __init__(self, height, width, up_fov, down_fov, max_num_alignments, threshold_delta_pose, scheme, sigma,
+                 local_map_size, num_neighbors_normals, **kwargs):
+        self.hw = (int(height), int(width), float(up_fov), float(down_fov))
+        self.lm = O.KdTreeLocalMapOracle(local_map_size, num_neighbors_normals, workers=1)
+        self.reg = O.ICPFrameToModelOracle(O.ICPOracleConfig(
+            max_num_alignments=max_num_alignments, threshold_delta_pose=threshold_delta_pose, scheme=scheme, sigma=sigma,
+            height=height, width=width, local_map_size=local_map_size))
+        self.reg.local_map = self.lm
+        self.calls = []
+
+    def use_torch_stream(self):
+        pass
+
+    @staticmethod
+    def _np(a):
+        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+    def project(self, pc, **kwargs):
+        h, w, up, down = self.hw
+        return torch.from_numpy(O.build_projection_map(self._np(pc).reshape(-1, 3).astype(np.float32), h, w, up, down))
+
+    def map_init(self):
+        self.lm.init()
+
+    def map_update(self, rel_pose, new_points=None, skip_null=False):
+        self.calls.append("insert" if new_points is not None else "move")
+        pts = None if new_points is None else self._np(new_points).reshape(-1, 3)
+        if pts is not None and skip_null:
+            pts = pts[np.abs(pts).max(axis=1) > 0]
+        self.lm.update(np.asarray(rel_pose, np.float32), pts)
+        return 0 if pts is None else int(pts.shape[0])
+
+    def map_update_vertex_map(self, rel_pose, vmap):
+        self.calls.append("insert_vmap")
+        self.lm.update(np.asarray(rel_pose, np.float32), None, self._np(vmap))
+        return int(self.lm.num_elements[-1])
+
+    def register(self, points, init_pose=None, skip_null=False):
+        from pylidar_slam_amd.engine import RegisterResult
+        pts = self._np(points).reshape(-1, 3).astype(np.float32)
+        pts = pts[~np.isnan(pts).any(axis=1)]
+        if skip_null:
+            pts = pts[np.abs(pts).max(axis=1) > 0]
+        init = np.eye(4, dtype=np.float32) if init_pose is None else np.asarray(init_pose, np.float32)
+        params, pose = self.reg.register_new_frame(pts, init)
+        tr = self.reg.traces[-1]
+        return RegisterResult(pose, params, len(tr.dx), False, pts.shape[0], 0, np.array(tr.loss), np.array(tr.dx))
+
+
+@pytest.mark.parametrize("run", ["A_numpy_ls", "B_tensor_gm"])
+def test_frame_loop_host_logic_matches_reference(monkeypatch, golden_c1, c1_scans, run):
+    import pylidar_slam_amd.odometry as odo_mod
+    monkeypatch.setattr(odo_mod, "IcpContext", OracleContext)
+    g = golden_c1
+    scans, _ = c1_scans
+    mode, scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
+    h, w = (int(v) for v in g["hw"])
+    cfg = odo_mod.MI355XICPConfig(
+        max_num_alignments=int(iters), threshold_delta_pose=float(thr), data_key="input_data",
+        alignment=dict(mode="point_to_plane_gauss_newton",
+                       gauss_newton_config=dict(max_iters=1, scheme=scheme, sigma=float(sigma))))
+    odo = odo_mod.MI355XICPFrameToModel(cfg, projector=odo_mod.SphericalProjector(h, w), device=torch.device("cpu"))
+    odo.init()
+    cv = O.ConstantVelocityOracle()
+    for f, s in enumerate(scans):
+        pts, _ = O.grid_sample(s, 0.3)
+        d = {"input_data": pts if mode == "numpy" else torch.from_numpy(pts), "init_rpose": cv.next_initial_pose()}
+        odo.process_next_frame(d)
+        if f == 0:  # frame 0 writes nothing (icp_odometry.py:171-181)
+            assert "odometry_pose" not in d and "odometry_pc" not in d
+            continue
+        pose = d["odometry_pose"]
+        assert pose.shape == (4, 4) and pose.dtype == np.float32 and d["odometry_pc"].shape[1] == 3
+        cv.save_real_motion(pose)
+        dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
+        assert dt < 2e-5 and dr < 2e-5, (f, dt, dr)
+    rel = odo.get_relative_poses()
+    assert rel.shape == (len(scans), 4, 4) and np.array_equal(rel[0], np.eye(4, dtype=np.float32))
+    np.testing.assert_allclose(np.stack(odo.absolute_poses), g[f"{run}_abs"], atol=1e-4)
+    # the first frame goes in as a vertex map, 0.4 m per frame is above the 0.1 m key-frame threshold: every later
+    # frame is inserted as a cloud; the map ends with the reference's size
+    calls = odo.ctx.calls
+    assert calls[0] == "insert_vmap" and set(calls[1:]) == {"insert"} and len(calls) == len(scans)
+    assert odo.ctx.lm.local_map.shape[0] == int(g[f"{run}_map_size"])
+    assert len(odo.elapsed) == len(scans) and odo.get_elapsed() > 0
+
+
+def test_small_motion_is_a_pose_only_update(monkeypatch):
+    """Below both key-frame thresholds (0.1 m / 0.3 deg) the map is only re-expressed; the deltas accumulate until the
+    threshold is crossed (icp_odometry.py:360-380)."""
+    import pylidar_slam_amd.odometry as odo_mod
+    monkeypatch.setattr(odo_mod, "IcpContext", OracleContext)
+    from pylidar_slam_amd.synthetic import SceneConfig, ray_directions, render_scan, pose_matrix
+    sc = SceneConfig(height=16, width=256)
+    dirs = ray_directions(sc)
+    poses = [pose_matrix(np.array([0.04 * k, 0, 0, 0, 0, 0.0])) for k in range(5)]  # 4 cm per frame
+    cfg = odo_mod.MI355XICPConfig(max_num_alignments=10, threshold_delta_pose=1e-4, data_key="numpy_pc")
+    odo = odo_mod.MI355XICPFrameToModel(cfg, projector=odo_mod.SphericalProjector(16, 256), device=torch.device("cpu"))
+    odo.init()
+    for k, p in enumerate(poses):
+        odo.process_next_frame({"numpy_pc": render_scan(sc, p, k, dirs)})
+    # frames 1, 2: 4 and 8 cm since the last insertion -> pose-only; frame 3: 12 cm -> insertion; frame 4: 4 cm again
+    assert odo.ctx.calls == ["insert_vmap", "move", "move", "insert", "move"]
+    with pytest.raises(AssertionError):
+        odo.process_next_frame({"wrong_key": None})
