@@ -118,3 +118,53 @@ def test_small_motion_is_a_pose_only_update(monkeypatch):
     assert odo.ctx.calls == ["insert_vmap", "move", "move", "insert", "move"]
     with pytest.raises(AssertionError):
         odo.process_next_frame({"wrong_key": None})
+
+
+# ---- filters: the pass-through / error logic around the GPU calls --------------------------------------------------
+class _FilterContext:
+    """distort / grid_sample of the `IcpContext` protocol by the oracle."""
+
+    def distort(self, pc, ts, rpose):
+        return O.distort(np.asarray(pc, np.float32), np.asarray(ts, np.float64).reshape(-1), np.asarray(rpose, np.float64))
+
+    def grid_sample(self, pc, voxel):
+        pts, idx = O.grid_sample(np.asarray(pc), voxel)
+        return pts, idx
+
+    def grid_sample_f64(self, pc, voxel):
+        return self.grid_sample(pc, voxel)
+
+
+def test_distortion_filter_pass_through_rules():
+    from pylidar_slam_amd.odometry import Distortion, DistortionConfig, GridSample, GridSampleConfig
+    from pylidar_slam_amd.synthetic import pose_matrix
+    rng = np.random.default_rng(0)
+    pc = rng.normal(size=(50, 3)).astype(np.float32)
+    ts = np.linspace(0.0, 0.1, 50)
+    rpose = pose_matrix(np.array([0.5, 0, 0, 0, 0, 0.02]))
+    ctx = _FilterContext()
+    f = Distortion(DistortionConfig(), ctx=ctx)
+    # no timestamps / no initial pose / deactivated: the SAME array object goes through (preprocessing.py:157-162)
+    for d in ({"numpy_pc": pc, "init_rpose": rpose},
+              {"numpy_pc": pc, "numpy_pc_timestamps": ts, "init_rpose": None}):
+        f.filter(d)
+        assert d["input_data"] is pc
+    d = {"numpy_pc": pc, "numpy_pc_timestamps": ts, "init_rpose": rpose}
+    Distortion(DistortionConfig(activate=False), ctx=ctx).filter(d)
+    assert d["input_data"] is pc
+    # active: float64 de-skewed cloud, first point (alpha = 0) untouched, last point moved by the whole motion
+    d = {"numpy_pc": pc, "numpy_pc_timestamps": ts, "init_rpose": rpose}
+    f.filter(d)
+    out = d["input_data"]
+    assert out.dtype == np.float64 and out.shape == pc.shape
+    np.testing.assert_allclose(out[0], pc[0], atol=1e-7)
+    np.testing.assert_allclose(out[-1], rpose[:3, :3] @ pc[-1] + rpose[:3, 3], atol=1e-6)
+    with pytest.raises(AssertionError):
+        f.filter({"numpy_pc": torch.from_numpy(pc), "numpy_pc_timestamps": ts, "init_rpose": rpose})
+    # GridSample on the float64 output keeps float64 samples and int64 indices
+    g = GridSample(GridSampleConfig(voxel_size=0.5, pointcloud_key="input_data"), ctx=ctx)
+    g.filter(d)
+    assert d["sample_points"].dtype == np.float64 and d["sample_indices"].dtype == np.int64
+    np.testing.assert_array_equal(d["sample_points"], out[d["sample_indices"]])
+    with pytest.raises(AssertionError):
+        g.filter({"input_data": np.zeros((5, 2), np.float32)})
