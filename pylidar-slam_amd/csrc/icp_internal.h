@@ -136,7 +136,7 @@ struct icp_ctx {
     icp::DeviceBuffer normals;         // float4[M] (by cell-sorted position)
     icp::DeviceBuffer nflag;           // int[M]: 0 none, 2 queued, 1 ready
     icp::DeviceBuffer slot_of, rank_of;  // int[M] temporaries of the build
-    icp::DeviceBuffer row_of_slot, slot_of_cell, rows, row_of_pos, cell_flags, cell_ids;
+    icp::DeviceBuffer row_of_slot, slot_of_cell, rows, row_of_pos;
     icp::DeviceBuffer csorted, pos_of_orig, cslot_of, crank_of;  // coarse level (its table follows the fine one)
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
