@@ -151,7 +151,9 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* s
 /* update() :302-362 — move the map by inv(rel), append `new_xyz` (rows with NaN dropped; NULL / n = 0: pose-only
  * update), evict the oldest cloud beyond local_map_size, rebuild the search structure and clear the normal cache.
  * *inserted_out (optional) = number of rows appended.  rel_pose = NULL: the pose of the last registration on this
- * context, read on the device (no host round trip; valid after icp_register / icp_register_launch). */
+ * context, read on the device (no host round trip; valid after icp_register / icp_register_launch).  If that
+ * registration stopped on ICP_ERR_INVALID_JACOBIAN the pose is its last valid iterate (the reference raises before it
+ * would touch the map: a caller that wants that order calls icp_register_end first and passes the pose). */
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out);
 /* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */
