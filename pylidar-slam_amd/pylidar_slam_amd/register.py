@@ -1,43 +1,73 @@
-"""Registers the MI355X odometry inside an importable pyLiDAR-SLAM checkout, without editing it.
+"""Registers the MI355X plugins inside an importable pyLiDAR-SLAM checkout, without editing it.
 
-The reference resolves `slam.odometry.algorithm` through the `ODOMETRY` enum of `(class, config dataclass)` pairs
-(slam/odometry/__init__.py:23-32, loader slam/common/utils.py:266-302) and hydra's ConfigStore
-(slam/odometry/icp_odometry.py:67-68).  An Enum cannot be extended in place, so `register_with_reference()` builds
-a new enum with the same members plus `icp_F2M_mi355x` and swaps it in wherever the reference imported it.
-A maintainer would instead add the two lines shown in INTEGRATION.md to slam/odometry/__init__.py.
+The reference resolves its plugins through enums of `(class, config dataclass)` pairs:
+  ODOMETRY  selector `algorithm`    slam/odometry/__init__.py:23-32   (loader slam/common/utils.py:266-302)
+  DATASET   selector `dataset`      slam/dataset/__init__.py:15-38
+  FILTER    selector `filter_name`  slam/preprocessing.py:230-252
+and hydra's ConfigStore (slam/odometry/icp_odometry.py:67-68).  An Enum cannot be extended in place, so
+`register_with_reference()` builds new enums with the same members plus the MI355X ones and swaps them in wherever
+the reference imported them.  A maintainer would instead add the lines shown in INTEGRATION.md to those modules.
 """
+import sys
 from enum import Enum
 
 ALGORITHM_NAME = "icp_F2M_mi355x"
+DATASET_NAMES = ("synthetic_mi355x", "kitti_mi355x")
+FILTER_NAMES = ("grid_sample_mi355x", "distortion_mi355x", "voxelization_mi355x")
+
+
+def _swap_enum(owner, attr: str, extra: dict, mixins: tuple, namespace: dict):
+    """New enum = members of `owner.attr` + `extra`, installed in every loaded slam.* module that holds the old one."""
+    current = getattr(owner, attr)
+    if all(name in current.__members__ for name in extra):
+        return current
+    members = {m.name: m.value for m in current}
+    members.update(extra)
+    base = type(f"_{attr}Base", mixins, dict(namespace)) if (mixins or namespace) else None
+    patched = Enum(attr, members, type=base) if base is not None else Enum(attr, members)
+    patched.__doc__ = current.__doc__
+    for name, mod in list(sys.modules.items()):
+        if name.startswith("slam") and getattr(mod, attr, None) is current:
+            setattr(mod, attr, patched)
+    return patched
 
 
 def register_with_reference():
-    """Call once, before `SLAM.init()` / `run.py`'s hydra main builds the odometry. Returns the patched enum."""
+    """Call once, before `SLAM.init()` / `run.py`'s hydra main builds the pipeline. Returns the patched ODOMETRY enum
+    (`icp_F2M_mi355x`); DATASET gains `synthetic_mi355x` / `kitti_mi355x`, FILTER gains `grid_sample_mi355x` /
+    `distortion_mi355x` / `voxelization_mi355x`."""
+    import slam.dataset as ref_dataset
     import slam.odometry as ref_odometry
+    import slam.preprocessing as ref_pre
     from slam.common.utils import ObjectLoaderEnum
-    from .odometry import MI355XICPConfig, MI355XICPFrameToModel
 
-    current = ref_odometry.ODOMETRY
-    if ALGORITHM_NAME in current.__members__:
-        return current
-    members = {m.name: m.value for m in current}
-    members[ALGORITHM_NAME] = (MI355XICPFrameToModel, MI355XICPConfig)
+    from .dataset import KITTIConfig, KITTIDatasetLoader, SyntheticDatasetConfig, SyntheticDatasetLoader
+    from .odometry import (Distortion, DistortionConfig, GridSample, GridSampleConfig, MI355XICPConfig,
+                           MI355XICPFrameToModel, Voxelization, VoxelizationConfig)
 
-    class _Base(ObjectLoaderEnum):
-        @classmethod
-        def type_name(cls):
-            return "algorithm"
+    odometry = _swap_enum(ref_odometry, "ODOMETRY", {ALGORITHM_NAME: (MI355XICPFrameToModel, MI355XICPConfig)},
+                          (ObjectLoaderEnum,), {"type_name": classmethod(lambda cls: "algorithm")})
+    _swap_enum(ref_dataset, "DATASET", {DATASET_NAMES[0]: (SyntheticDatasetLoader, SyntheticDatasetConfig),
+                                         DATASET_NAMES[1]: (KITTIDatasetLoader, KITTIConfig)},
+               (ObjectLoaderEnum,), {"type_name": classmethod(lambda cls: "dataset")})
 
-    patched = Enum("ODOMETRY", members, type=_Base)
-    patched.__doc__ = current.__doc__
-    ref_odometry.ODOMETRY = patched
-    import sys
-    for name, mod in list(sys.modules.items()):
-        if name.startswith("slam.") and getattr(mod, "ODOMETRY", None) is current:
-            setattr(mod, "ODOMETRY", patched)
-    try:  # hydra group entry, so `slam/odometry=icp_odometry_mi355x` resolves
+    def _load_filter(config, **kwargs):  # slam/preprocessing.py:243-252, against the patched enum
+        name = config.filter_name
+        flt = ref_pre.FILTER
+        assert name in flt.__members__, f"unknown filter {name}"
+        _class, _config = flt[name].value
+        return _class(_config(**config), **kwargs)
+
+    _swap_enum(ref_pre, "FILTER", {FILTER_NAMES[0]: (GridSample, GridSampleConfig),
+                                   FILTER_NAMES[1]: (Distortion, DistortionConfig),
+                                   FILTER_NAMES[2]: (Voxelization, VoxelizationConfig)},
+               (), {"load": staticmethod(_load_filter)})
+    try:  # hydra group entries, so `slam/odometry=icp_odometry_mi355x` / `dataset=synthetic_mi355x` resolve
         from hydra.core.config_store import ConfigStore
-        ConfigStore.instance().store(name="icp_odometry_mi355x", group="slam/odometry", node=MI355XICPConfig)
-    except Exception:  # hydra absent: the enum patch is all `ODOMETRY.load` needs
+        cs = ConfigStore.instance()
+        cs.store(name="icp_odometry_mi355x", group="slam/odometry", node=MI355XICPConfig)
+        cs.store(name=DATASET_NAMES[0], group="dataset", node=SyntheticDatasetConfig)
+        cs.store(name=DATASET_NAMES[1], group="dataset", node=KITTIConfig)
+    except Exception:  # hydra absent: the enum patches are all the loaders need
         pass
-    return patched
+    return odometry

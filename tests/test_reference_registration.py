@@ -51,3 +51,49 @@ def test_registers_in_reference_enum_and_dispatches(reference_on_path):
     else:
         with pytest.raises(IcpLibraryError):  # no GPU here: loud failure, not a CPU fallback
             patched.load(cfg, **kwargs)
+
+
+def test_dataset_and_filter_registries(reference_on_path, monkeypatch):
+    """DATASET gains the synthetic and the MI355X KITTI loader, FILTER the GPU filters; the reference's own loaders
+    (`DATASET.load`, `FILTER.load`, `Preprocessing`) reach our constructors with their usual arguments."""
+    import logging
+    logging.disable(logging.WARNING)
+    import numpy as np
+    import slam.dataset as ref_dataset
+    import slam.preprocessing as ref_pre
+    import slam.odometry.odometry_runner as ref_runner
+    from omegaconf import DictConfig, OmegaConf
+    from pylidar_slam_amd import dataset as our_dataset, odometry as our_odometry
+    from pylidar_slam_amd.register import DATASET_NAMES, FILTER_NAMES, register_with_reference
+
+    register_with_reference()
+    ds, flt = ref_dataset.DATASET, ref_pre.FILTER
+    assert set(DATASET_NAMES) <= set(ds.__members__) and "kitti" in ds.__members__ and ref_runner.DATASET is ds
+    assert set(FILTER_NAMES) <= set(flt.__members__) and "grid_sample" in flt.__members__
+
+    # a stand-in context: the loaders / filters are constructed by the reference's code, the GPU is not needed for that
+    class _Ctx:
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def grid_sample(self, pc, voxel):
+            return pc[:3], np.arange(3)
+
+    monkeypatch.setattr(our_dataset, "IcpContext", _Ctx)
+    loader = ds.load(DictConfig({"dataset": DATASET_NAMES[0], "lidar_height": 16, "lidar_width": 128, "num_frames": 3}))
+    assert isinstance(loader, our_dataset.SyntheticDatasetLoader) and loader.config.lidar_width == 128
+    proj = loader.projector()
+    assert (proj.height, proj.width) == (16, 128)
+    (train, names), _, _, _ = loader.sequences()
+    assert len(train[0]) == 3 and loader.get_ground_truth(names[0]).shape == (3, 4, 4)
+
+    f = flt.load(OmegaConf.create({"filter_name": FILTER_NAMES[0], "voxel_size": 0.5}), ctx=_Ctx())
+    assert isinstance(f, our_odometry.GridSample) and f.config.voxel_size == 0.5
+    # through the reference's own Preprocessing pipeline (filters applied in key order, slam/preprocessing.py:269-291)
+    pre = ref_pre.Preprocessing(ref_pre.PreprocessingConfig(filters=OmegaConf.create(
+        {"1": {"filter_name": FILTER_NAMES[0], "voxel_size": 0.5, "pointcloud_key": "numpy_pc"}})), ctx=_Ctx())
+    d = {"numpy_pc": np.zeros((10, 3), np.float32)}
+    pre.forward(d)
+    assert d["sample_points"].shape == (3, 3) and d["sample_indices"].shape == (3,)
+    # the reference's own members still load
+    assert isinstance(flt.load(OmegaConf.create({"filter_name": "grid_sample"})), ref_pre.GridSample)
