@@ -387,14 +387,29 @@ def test_async_register_and_device_pose_map_update_are_bit_identical(torch_cuda,
     assert ra.iterations == 8 if threshold == 0.0 else ra.iterations <= 8
 
 
-def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
-    """BASELINE.json configs[1]: 64x2048 scan (131072 points) vs a 100k-point map, 20 forced iterations, for the three
-    schemes of BASELINE.md; pose within 1e-4 m / 1e-4 rad of the oracle, plus exactness of the search on a sample."""
+def _c2_inputs():
+    """Scan / map pair of the C2 parity tests (the inputs oracle/make_golden_c2.py ran the reference on)."""
     from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
     cfg = SceneConfig(height=64, width=2048)
     scans, poses = make_sequence(cfg, 9)
     model = make_fixed_map(cfg, scans[:8], poses[:8], ref_frame=7, num_points=100_000)
-    scan = scans[8]
+    return scans[8], model
+
+
+def test_c2_full_size_registration_vs_reference_and_oracle(torch_cuda, O):
+    """BASELINE.json configs[1] (the headline configuration): 64x2048 scan (131072 points) vs a 100k-point map, 20
+    forced iterations, the three schemes of BASELINE.md.  Pinned on the REFERENCE's own run at this size
+    (tests/golden/c2_reference.npz, oracle/make_golden_c2.py: `ICPFrameToModel.register_new_frame` on the same inputs):
+    pose within 1e-4 m / 1e-4 rad, per-iteration loss and delta pose; also against the oracle, plus exactness of the
+    search on a sample."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "c2_reference.npz"))
+    scan, model = _c2_inputs()
+    assert hashlib.sha1(np.ascontiguousarray(scan).tobytes()).hexdigest() == str(g["scan_sha"]), \
+        "the seeded generator no longer reproduces the scan the reference was run on"
+    assert hashlib.sha1(np.ascontiguousarray(model).tobytes()).hexdigest() == str(g["model_sha"])
     ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0)
     ctx.map_set(model)
     dscan = torch_cuda.from_numpy(scan).cuda()
@@ -405,11 +420,20 @@ def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
     d2 = ((sample.astype(np.float64) - model[ix].astype(np.float64)) ** 2).sum(axis=1)
     assert (ix == bi).mean() > 0.999
     np.testing.assert_allclose(d2, bd2, rtol=2e-6, atol=1e-12)
-    for scheme, sigma in (("least_square", 0.5), ("geman_mcclure", 0.3), ("neighborhood", 0.2)):
-        ctx.set_alignment(scheme, sigma, 20, 0.0)
+    for scheme, sigma in zip((str(v) for v in g["schemes"]), (float(v) for v in g["sigmas"])):
+        ctx.set_alignment(scheme, sigma, int(g["iters"]), 0.0)
         ctx.map_set(model)  # clears the normal cache, like every map update
         res = ctx.register(dscan)
         assert res.iterations == 20 and res.num_targets == scan.shape[0]
+        # ---- the reference itself
+        dt, dr = O.pose_error(res.pose, g[f"{scheme}_pose"])
+        print(f"C2 {scheme} vs REFERENCE: |dt| = {dt:.2e} m |dr| = {dr:.2e} rad, loss {res.losses[-1]:.4f} vs "
+              f"{g[scheme + '_loss'][-1]:.4f}")
+        assert dt < 1e-4 and dr < 1e-4, ("reference", scheme, dt, dr)
+        np.testing.assert_allclose(res.params, g[f"{scheme}_params"], atol=1e-4)
+        np.testing.assert_allclose(res.losses, g[f"{scheme}_loss"], rtol=2e-3)
+        np.testing.assert_allclose(res.dx, g[f"{scheme}_dx"], atol=2e-5)
+        # ---- the oracle (f64 accumulation like the device)
         lm = O.KdTreeLocalMapOracle()
         lm.set_map_pointcloud(model)
         oc = O.ICPOracleConfig(max_num_alignments=20, threshold_delta_pose=0.0, scheme=scheme, sigma=sigma,
@@ -418,8 +442,7 @@ def test_c2_full_size_registration_vs_oracle(torch_cuda, O):
         orc.local_map = lm
         _, opose = orc.register_new_frame(scan, np.eye(4, dtype=np.float32))
         dt, dr = O.pose_error(res.pose, opose)
-        print(f"C2 {scheme}: |dt| = {dt:.2e} m |dr| = {dr:.2e} rad, loss {res.losses[-1]:.4f} vs "
-              f"{orc.traces[-1].loss[-1]:.4f}, normals computed {res.normals_computed}")
+        print(f"C2 {scheme} vs oracle: |dt| = {dt:.2e} m |dr| = {dr:.2e} rad, normals computed {res.normals_computed}")
         assert dt < 1e-4 and dr < 1e-4, (scheme, dt, dr)
         np.testing.assert_allclose(res.losses[-1], orc.traces[-1].loss[-1], rtol=1e-3)
 
@@ -496,23 +519,31 @@ def test_projective_map_model_and_search(torch_cuda, O, golden_projective):
 
 @pytest.mark.parametrize("run", ["ls", "nbh"])
 def test_projective_icp_sequence(torch_cuda, O, golden_projective, run):
-    """Row a19 end to end behind the plugin surface: `local_map.type = projective_local_map`, vertex-map input.
-    vs the oracle with exact (float64) normals: 1e-4 m / 1e-4 rad; vs the reference's own run: its float32 normal-map
-    noise floor (5e-3 m / 5e-4 rad, see tests/test_oracle.py)."""
+    """Row a19 end to end behind the plugin surface: `local_map.type = projective_local_map`, vertex-map input, the
+    configuration (scheme, iteration cap, stop threshold) the reference was run with.  Per frame within 1e-4 m /
+    1e-4 rad of the REFERENCE's own run (tests/golden/projective.npz) and of the reference with its two box-filter
+    convolutions carried out in float64 (tests/golden/projective_spread.npz, oracle/make_golden_projective_spread.py),
+    and of the oracle with float64 window sums.  The reference's float32 box filter is bistable at this precision: its
+    own runs on a mirrored image land 1.9e-3 m away on the `ls` sequence (same fixture) — the HIP path sits with the
+    baseline."""
+    import os
+    from conftest import GOLDEN
     from pylidar_slam_amd.odometry import MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector
     g = golden_projective
+    sp = np.load(os.path.join(GOLDEN, "projective_spread.npz"))
     h, w = (int(v) for v in g["hw"])
     scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
-    cfg = MI355XICPConfig(max_num_alignments=int(iters), threshold_delta_pose=0.0, data_key="vertex_map",
+    cfg = MI355XICPConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), data_key="vertex_map",
                           local_map=dict(type="projective_local_map", local_map_size=4),
                           alignment=dict(mode="point_to_plane_gauss_newton",
                                          gauss_newton_config=dict(max_iters=1, scheme=scheme, sigma=float(sigma))))
     odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(h, w), device=torch_cuda.device("cuda:0"))
     odo.init()
-    oc = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=0.0, scheme=scheme, sigma=float(sigma),
-                           height=h, width=w, local_map_size=4, accumulate=np.float64)
+    oc = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), scheme=scheme,
+                           sigma=float(sigma), height=h, width=w, local_map_size=4, accumulate=np.float64)
     orc = O.ICPProjectiveOracle(oc, normals_dtype=np.float64)
     last = None
+    worst = {"reference": (0.0, 0.0), "reference_f64conv": (0.0, 0.0), "oracle": (0.0, 0.0)}
     for f, vm in enumerate(g["vmaps"]):
         d = {"vertex_map": torch_cuda.from_numpy(vm), "init_rpose": last}
         odo.process_next_frame(d)
@@ -521,11 +552,13 @@ def test_projective_icp_sequence(torch_cuda, O, golden_projective, run):
             continue
         pose = d["odometry_pose"]
         last = pose.astype(np.float64)
-        dt, dr = O.pose_error(pose, opose)
-        assert dt < 1e-4 and dr < 1e-4, ("oracle", run, f, dt, dr)
-        if float(thr) == 0.0:  # the reference ran the same forced iteration count
-            dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
-            assert dt < 5e-3 and dr < 5e-4, ("reference", run, f, dt, dr)
+        assert odo.last_result.iterations == int(g[f"{run}_iters"][f]), (run, f, odo.last_result.iterations)
+        for name, ref in (("reference", g[f"{run}_rel"][f]), ("reference_f64conv", sp[f"{run}_float64_rel"][f]),
+                          ("oracle", opose)):
+            dt, dr = O.pose_error(pose, ref)
+            worst[name] = (max(worst[name][0], dt), max(worst[name][1], dr))
+            assert dt < 1e-4 and dr < 1e-4, (name, run, f, dt, dr)
+    print(f"projective {run}: " + ", ".join(f"{k} {v[0]:.1e} m / {v[1]:.1e} rad" for k, v in worst.items()))
 
 
 # ---- point-to-point alignment + weighted Procrustes --------------------------------------------

@@ -198,21 +198,66 @@ def test_projective_components_match_reference(golden_projective):
 
 @pytest.mark.parametrize("run", ["ls", "nbh"])
 def test_projective_icp_sequence_matches_reference(golden_projective, run):
-    """The projective-map odometry restatement against the reference's own run.  Tolerance 5e-3 m / 5e-4 rad: the
-    float32 normal-map noise above moves the reference itself by that much between two summation orders."""
+    """The projective-map odometry restatement against the reference's own run.
+
+    With float64 window sums in `compute_normal_map` (what the HIP kernel computes) the restatement follows the
+    reference's run to 1e-4 m / 1e-4 rad per frame.  With float32 sums in numpy's order it lands in the OTHER of the two
+    basins the reference's own float32 box filter has on this data: the reference re-run on a vertically mirrored image
+    (a mathematical no-op; tests/golden/projective_spread.npz, oracle/make_golden_projective_spread.py) moves 1.9e-3 m on
+    the `ls` sequence.  Both facts are pinned here."""
+    import os
+    from conftest import GOLDEN
     g = golden_projective
+    sp = np.load(os.path.join(GOLDEN, "projective_spread.npz"))
+    np.testing.assert_array_equal(sp[f"{run}_baseline_rel"], g[f"{run}_rel"])
     h, w = (int(v) for v in g["hw"])
     scheme, sigma, iters, thr = (str(v) for v in g[f"{run}_cfg"])
-    cfg = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), scheme=scheme,
-                            sigma=float(sigma), height=h, width=w, local_map_size=4)
-    orc = O.ICPProjectiveOracle(cfg)
-    last = None
-    for f, vm in enumerate(g["vmaps"]):
-        pose = orc.process_next_frame(vm, last)
-        if pose is not None:
-            last = pose.astype(np.float64)
-            dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
-            assert dt < 5e-3 and dr < 5e-4, (f, dt, dr)
+    for normals_dtype, tol_t, tol_r in ((np.float64, 1e-4, 1e-4), (np.float32, 5e-3, 5e-4)):
+        cfg = O.ICPOracleConfig(max_num_alignments=int(iters), threshold_delta_pose=float(thr), scheme=scheme,
+                                sigma=float(sigma), height=h, width=w, local_map_size=4, accumulate=np.float64)
+        orc = O.ICPProjectiveOracle(cfg, normals_dtype=normals_dtype)
+        last = None
+        for f, vm in enumerate(g["vmaps"]):
+            pose = orc.process_next_frame(vm, last)
+            if pose is not None:
+                last = pose.astype(np.float64)
+                dt, dr = O.pose_error(pose, g[f"{run}_rel"][f])
+                assert dt < tol_t and dr < tol_r, (normals_dtype.__name__, f, dt, dr)
+                if normals_dtype is np.float64:  # and the reference with its convolutions carried out in float64
+                    dt, dr = O.pose_error(pose, sp[f"{run}_float64_rel"][f])
+                    assert dt < 1e-4 and dr < 1e-4, ("f64conv", f, dt, dr)
+    if run == "ls":  # the reference's own spread between two float32 summation orders
+        spread = max(O.pose_error(sp["ls_mirror_h_rel"][f], g["ls_rel"][f])[0] for f in range(1, len(g["vmaps"])))
+        assert 1e-3 < spread < 5e-3, spread
+
+
+def test_oracle_c2_matches_reference():
+    """The headline configuration (BASELINE.json configs[1]) at full size: the restatement against the reference's own
+    `register_new_frame` run on 131 072 points vs the 100 000-point map, 20 forced iterations, three schemes
+    (tests/golden/c2_reference.npz, oracle/make_golden_c2.py)."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    g = np.load(os.path.join(GOLDEN, "c2_reference.npz"))
+    cfg = SceneConfig(height=64, width=2048)
+    scans, poses = make_sequence(cfg, 9)
+    model = make_fixed_map(cfg, scans[:8], poses[:8], ref_frame=7, num_points=100_000)
+    scan = scans[8]
+    assert hashlib.sha1(np.ascontiguousarray(scan).tobytes()).hexdigest() == str(g["scan_sha"])
+    assert hashlib.sha1(np.ascontiguousarray(model).tobytes()).hexdigest() == str(g["model_sha"])
+    for scheme, sigma in zip((str(v) for v in g["schemes"]), (float(v) for v in g["sigmas"])):
+        lm = O.KdTreeLocalMapOracle()
+        lm.set_map_pointcloud(model)
+        orc = O.ICPFrameToModelOracle(O.ICPOracleConfig(max_num_alignments=int(g["iters"]), threshold_delta_pose=0.0,
+                                                        scheme=scheme, sigma=sigma, height=64, width=2048,
+                                                        accumulate=np.float64))
+        orc.local_map = lm
+        _, pose = orc.register_new_frame(scan, np.eye(4, dtype=np.float32))
+        dt, dr = O.pose_error(pose, g[f"{scheme}_pose"])
+        assert dt < 1e-5 and dr < 1e-6, (scheme, dt, dr)
+        np.testing.assert_allclose(np.array(orc.traces[-1].dx), g[f"{scheme}_dx"], atol=2e-5)
+        np.testing.assert_allclose(np.array(orc.traces[-1].loss), g[f"{scheme}_loss"], rtol=1e-3)
 
 
 # ---- dataset side (SURVEY §8f rank 3) ------------------------------------------------------------------------------
