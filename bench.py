@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X ICP odometry hot path on BASELINE.json's metric configuration.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 60 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,29 +11,38 @@ One step = one frame of the hot path, everything the reference does per frame on
   spherical projection of the scan (icp_odometry.py:333) -> 20 x [transform, exact 1-NN, lazy kNN normals,
   residual/Jacobian reduction, 6x6 solve, pose update] (:274-297) -> pose read back to the host -> local-map update
   (re-express the 100k map by inv(T), rebuild the search structure, clear the normal cache; local_map.py:346-369).
-The scans form a ping-pong sequence along a trajectory (8 poses 0.4 m / 0.01 rad apart, visited 1..7,6..0,1..), so
-every step registers a genuinely moved scan from a constant-velocity initial guess (the reference's default
-initialisation; wrong by twice the motion at the two turn-arounds of the ping-pong); nothing is cached between steps.
-`--trajectory loop` drives a closed 96-pose circuit instead (steady twist, map made of 8 scans spread around the circuit).
+The map is the union of 8 EARLIER scans, none of which is ever tracked ("union of the previous >= 5
+scans"): a straight drive is sampled every 0.2 m / 0.005 rad (16 poses); the 8 even poses (0.4 m apart) are the mapping
+pass, the 8 odd poses (0.4 m apart, 0.2 m from the nearest map scan) are tracked back and forth (3,5,..,15,13,..,1,..),
+so every step registers a genuinely moved scan, never seen by the map, from a constant-velocity initial guess (the
+reference's default initialisation; wrong by twice the motion at the two turn-arounds); nothing is cached between steps.
+`--trajectory loop` drives a closed circuit instead (96 tracked poses 0.4 m / 3.75 deg apart, steady twist; the map is
+made of 8 scans taken between tracked poses, spread around the circuit, so most tracked scans are up to 2.4 m / 22 deg
+from the nearest map scan: longer searches); a short run of it is reported next to the headline (`"loop"` in the JSON
+line).  `--trajectory pingpong_r01` is round 1's sequence (map built from the very scans being tracked).
 The host receives the pose of every frame inside its step; the map re-expression is enqueued behind the registration
 with the device-resident pose (icp_register_launch / icp_map_update(NULL) / icp_register_end), so it overlaps the host's
 wait for the pose instead of following a host round trip.
 
 N > 1: one process per GPU, every rank tracks its own independent scan sequence (replicated map, no data-path
-collective) -> weak scaling; `--mode sharded` instead splits every scan's points across the ranks and all-reduces the
-packed 6x6 normal equations (32 doubles) over RCCL once per ICP iteration (strong scaling of one sequence).
+collective) -> weak scaling; `--mode sharded` instead splits every scan's points across the ranks and exchanges the
+packed 6x6 normal equations (32 doubles) once per ICP iteration (strong scaling of one sequence).
 
 `--sequences-per-gpu S` (throughput mode, default 1): S independent sequences per GPU on S contexts / HIP streams / host
 threads; one sequence is a chain of dependent, latency-bound kernels and leaves most of the GPU idle.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-iteration fused search + rows kernel),
-timed with HIP events on the library's stream inside the timed region; `cpu_baseline` times the numpy/cKDTree oracle
-(oracle/icp_oracle.py, a restatement of the reference's CPU path) on one frame of the same workload.
+timed with HIP events on the library's stream inside the timed region (`traffic` = the PMC figure of the committed
+rocprofv3 counter run, tagged with its source file and the commit it was measured at: counters cannot be collected
+from inside this process); `cpu_baseline` times the numpy/cKDTree oracle (oracle/icp_oracle.py, a restatement of the
+reference's CPU path — the reference itself does not exist on the GPU box) on the same workload: median of 3 frames
+after one warm-up frame, the kd-tree build timed separately.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -46,12 +55,15 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_POINT_ITER = 36  # 12 target xyz + 12 matched map xyz + 12 matched normal
+MIN_STEPS_FOR_HEADLINE = 50  # >= 50 timed frames
+LOOP_PERIOD = 96
+SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scheme", default="geman_mcclure")
     ap.add_argument("--sigma", type=float, default=0.3)
@@ -60,85 +72,230 @@ def parse():
     ap.add_argument("--init", choices=["cv", "identity"], default="cv",
                     help="initial guess per frame: constant velocity = last relative pose (the reference's default, "
                          "config/slam.yaml: slam/initialization: CV) or identity (initialization: NI)")
-    ap.add_argument("--trajectory", choices=["pingpong", "loop"], default="pingpong",
+    ap.add_argument("--trajectory", choices=["pingpong", "loop", "pingpong_r01"], default="pingpong",
                     help="pingpong: 8 poses of a straight drive (0.4 m, 0.01 rad per frame) visited back and forth, the "
-                         "map made of those scans (the constant-velocity guess is wrong by twice the motion at both "
-                         "ends); loop: a closed 96-pose circuit driven at 0.4 m and 3.75 deg per frame with the map made "
-                         "of 8 scans spread around it (the guess is always right, but most scans are taken up to 2.4 m "
-                         "and 22 deg away from the nearest map scan: longer searches)")
+                         "map made of 8 OTHER scans taken half a step away from them (the constant-velocity guess is "
+                         "wrong by twice the motion at both ends); loop: a closed 96-pose circuit driven at 0.4 m and "
+                         "3.75 deg per frame, the map made of 8 untracked scans spread around it (the guess is always "
+                         "right, but most scans are taken up to 2.4 m and 22 deg away from the nearest map scan: longer "
+                         "searches); pingpong_r01: round 1's sequence, whose map was built from the tracked scans")
+    ap.add_argument("--loop-steps", type=int, default=24,
+                    help="timed steps of the loop trajectory reported next to the headline (0: skip)")
     ap.add_argument("--cell-size", type=float, default=0.0, help="voxel-hash cell edge (m); <= 0: auto-tuned")
     ap.add_argument("--max-rings", type=int, default=2, help="fine-level rings searched before the coarse level")
     ap.add_argument("--sequences-per-gpu", type=int, default=1,
                     help="throughput mode: S independent sequences per GPU, each with its own context and HIP stream, "
                          "driven by S host threads (one sequence cannot fill the GPU: its kernels are latency-bound and "
                          "serially dependent).  `value` then counts all sequences; ms_per_step stays the per-frame latency")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning option (icp_set_option), repeatable — for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the search kernel")
     return ap.parse_args()
 
 
-LOOP_PERIOD = 96
-SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
-
-
-def make_workload(rank: int, trajectory: str, frames_needed: int):
-    """Scans (dict frame -> [N,3] f32), ground-truth poses, the fixed 100k-point map (in the frame of pose 0) and the
-    order in which the frames are visited (starting from frame 0's neighbour)."""
+def make_workload(seq: int, trajectory: str, frames_needed: int):
+    """(scans: dict frame -> [N,3] f32, ground-truth poses, the fixed 100k-point map in the frame of `start`, the order
+    in which the frames are visited, start).  No tracked scan contributes to the map (except `pingpong_r01`)."""
     from pylidar_slam_amd.synthetic import (SceneConfig, loop_trajectory, make_fixed_map, make_sequence, ray_directions,
                                             render_scan)
-    cfg = SceneConfig(height=64, width=2048, seed=1234 + 1000 * rank)
+    seed = 1234 + 1000 * seq
+
+    def into_frame(model, poses, src, dst):
+        rel = np.linalg.inv(poses[dst]) @ poses[src]
+        return (model.astype(np.float64) @ rel[:3, :3].T + rel[:3, 3]).astype(np.float32)
+
     if trajectory == "pingpong":
+        # half-steps: even poses = the mapping pass (never tracked), odd poses = the tracked sequence
+        cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2, yaw_rate=0.005)
+        scans, poses = make_sequence(cfg, 16)
+        even = list(range(0, 16, 2))
+        model = make_fixed_map(cfg, [scans[f] for f in even], poses[even], ref_frame=0, num_points=100_000)
+        order = list(range(3, 16, 2)) + list(range(13, 0, -2))  # 3,5,..,15,13,..,1 then repeats
+        return {f: scans[f] for f in range(1, 16, 2)}, poses, into_frame(model, poses, 0, 1), order, 1
+    if trajectory == "pingpong_r01":
+        cfg = SceneConfig(height=64, width=2048, seed=seed)
         scans, poses = make_sequence(cfg, 8)
         model = make_fixed_map(cfg, scans, poses, ref_frame=0, num_points=100_000)
-        order = list(range(1, 8)) + list(range(6, -1, -1))  # 1..7,6..0 then repeats: consecutive frames are neighbours
-        return cfg, dict(enumerate(scans)), poses, model, order
-    poses = loop_trajectory(cfg, LOOP_PERIOD)
-    order = list(range(1, LOOP_PERIOD)) + [0]
-    map_frames = list(range(0, LOOP_PERIOD, LOOP_PERIOD // 8))
+        return dict(enumerate(scans)), poses, model, list(range(1, 8)) + list(range(6, -1, -1)), 0
+    # loop: 192 half-steps around the circuit; odd poses tracked (96, 0.4 m apart), 8 even poses mapped
+    cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2)
+    poses = loop_trajectory(cfg, 2 * LOOP_PERIOD)
+    order = list(range(3, 2 * LOOP_PERIOD, 2)) + [1]
+    map_frames = list(range(0, 2 * LOOP_PERIOD, 2 * LOOP_PERIOD // 8))
     dirs = ray_directions(cfg)
-    wanted = sorted(set(order[:min(frames_needed, LOOP_PERIOD)]) | set(map_frames))
-    scans = {f: render_scan(cfg, poses[f], f, dirs) for f in wanted}
+    tracked = order[:min(frames_needed, LOOP_PERIOD)]
+    scans = {f: render_scan(cfg, poses[f], f, dirs) for f in sorted(set(tracked) | set(map_frames))}
     model = make_fixed_map(cfg, [scans[f] for f in map_frames], poses[map_frames], ref_frame=0, num_points=100_000)
-    return cfg, scans, poses, model, order
+    return {f: scans[f] for f in tracked}, poses, into_frame(model, poses, 0, 1), order, 1
 
 
-def step_replica(ctx, scan_dev, vmap_out, init):
-    ctx.project(scan_dev, out=vmap_out)
-    if SYNC_STEP:
-        res = ctx.register(scan_dev, init)  # synchronises to return the pose
-        ctx.map_update(res.pose, None)
+class Tracker:
+    """One tracked sequence on one context: the per-frame step of the hot path and its bookkeeping."""
+
+    def __init__(self, args, seq, trajectory, frames, device_index, sharded=None):
+        from pylidar_slam_amd.engine import IcpContext
+        self.args, self.sharded = args, sharded
+        scans, self.poses, model, self.order, self.prev = make_workload(seq, trajectory, frames)
+        self.host_scans, self.model = scans, model
+        self.dev = torch.device("cuda", device_index)
+        self.ctx = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
+                              scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size, max_rings=args.max_rings,
+                              device=device_index)
+        for opt in args.option:
+            name, value = opt.split("=", 1)
+            self.ctx.set_option(name, float(value))
+        self.ctx.use_torch_stream()
+        self.scans = {f: torch.from_numpy(s).to(self.dev) for f, s in scans.items()}
+        self.n_pts = next(iter(scans.values())).shape[0]
+        self.vmap = torch.empty((3, 64, 2048), dtype=torch.float32, device=self.dev)
+        self.ctx.map_set(torch.from_numpy(model).to(self.dev))
+        self.slices = None
+        if sharded is not None:
+            from pylidar_slam_amd.distributed import shard_bounds
+            world, rank = sharded
+            b, e = shard_bounds(self.n_pts, world, rank)
+            self.slices = {f: s[b:e].contiguous() for f, s in self.scans.items()}
+            self.n_local = e - b
+        self.last = None
+        self.cursor = 0
+        self.max_err = 0.0
+        self.last_err = 0.0
+        self.step_ms = []
+
+    def step(self, f, init):
+        ctx, scan = self.ctx, self.scans[f]
+        ctx.project(scan, out=self.vmap)
+        if self.slices is not None:
+            from pylidar_slam_amd.distributed import sharded_register
+            res = sharded_register(ctx, self.slices[f], init, self.args.iters)
+            ctx.map_update(res.pose, None)
+            return res
+        if SYNC_STEP:
+            res = ctx.register(scan, init)  # synchronises to return the pose
+            ctx.map_update(res.pose, None)
+            return res
+        ctx.register_launch(scan, init)  # all iterations + the result copy enqueued
+        ctx.map_update(None, None)       # re-expression by the device-resident result pose, behind the registration
+        return ctx.register_end()        # waits for the registration only: the pose arrives while the map rebuilds
+
+    def run(self, k, record=False):
+        res = None
+        for _ in range(k):
+            f = self.order[self.cursor % len(self.order)]
+            t0 = time.perf_counter()
+            res = self.step(f, self.last if self.args.init == "cv" else None)  # CV: the last relative pose
+            if record:
+                self.step_ms.append((time.perf_counter() - t0) * 1e3)
+            self.last = res.pose
+            gt_rel = np.linalg.inv(self.poses[self.prev]) @ self.poses[f]  # O(1) host bookkeeping, not device work
+            self.last_err = float(np.linalg.norm(gt_rel[:3, 3] - res.pose[:3, 3]))
+            self.max_err = max(self.max_err, self.last_err)
+            self.prev = f
+            self.cursor += 1
         return res
-    ctx.register_launch(scan_dev, init)  # all iterations + the result copy enqueued
-    ctx.map_update(None, None)           # map re-expression by the device-resident result pose, behind the registration
-    return ctx.register_end()            # waits for the registration only: the host gets the pose while the map rebuilds
+
+    def close(self):
+        self.ctx.close()
 
 
-def step_sharded(ctx, scan_slice_dev, full_scan_dev, vmap_out, iters, init):
-    from pylidar_slam_amd.distributed import sharded_register
-    ctx.project(full_scan_dev, out=vmap_out)
-    # per iteration: accumulate -> all-reduce (RCCL, 256 B, in place on the library's vector) -> identical solve
-    res = sharded_register(ctx, scan_slice_dev, init, iters)
-    ctx.map_update(res.pose, None)
-    return res
+class SequenceThread(threading.Thread):
+    """Throughput mode: one more sequence on its own context / HIP stream / host thread."""
+
+    def __init__(self, args, seq, device_index):
+        super().__init__(daemon=True)
+        self.args, self.seq, self.device_index = args, seq, device_index
+        self.go, self.done, self.ready = threading.Event(), threading.Event(), threading.Event()
+        self.phase = 0
+        self.max_err = 0.0
+
+    def run(self):
+        torch.cuda.set_device(self.device_index)
+        stream = torch.cuda.Stream(device=torch.device("cuda", self.device_index))
+        with torch.cuda.stream(stream):
+            tr = Tracker(self.args, self.seq, self.args.trajectory, self.args.warmup + self.args.steps,
+                         self.device_index)
+            self.ready.set()
+            while True:
+                self.go.wait()
+                self.go.clear()
+                if self.phase is None:
+                    tr.close()
+                    return
+                tr.run(self.phase)
+                self.max_err = tr.max_err
+                stream.synchronize()
+                self.done.set()
+
+    def start_phase(self, k):
+        self.phase = k
+        self.done.clear()
+        self.go.set()
 
 
-def cpu_baseline(scan, model, args):
+def cpu_baseline(tracker, args, frames=3):
+    """The oracle ("port") on the same workload on the host cores of this box: one warm-up frame, then the median of
+    `frames` frames (projection + 20-iteration registration + map re-expression and kd-tree rebuild, like a GPU step);
+    the first kd-tree build is reported on its own."""
     import icp_oracle as O
     lm = O.KdTreeLocalMapOracle()
     t0 = time.perf_counter()
-    lm.set_map_pointcloud(model)
+    lm.set_map_pointcloud(tracker.model)
+    build_s = time.perf_counter() - t0
     orc = O.ICPFrameToModelOracle(O.ICPOracleConfig(max_num_alignments=args.iters, threshold_delta_pose=0.0,
                                                     scheme=args.scheme, sigma=args.sigma, height=64, width=2048))
     orc.local_map = lm
-    O.build_projection_map(scan, 64, 2048, 3.0, -24.0)
-    _, pose = orc.register_new_frame(scan, np.eye(4, dtype=np.float32))
-    lm.update(pose)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 frame of the same workload (131072-pt scan vs 100k map, {args.iters} iters, "
-                      f"projection + registration + map update) with oracle/icp_oracle.py: numpy f32 + "
-                      f"scipy cKDTree(workers=-1) standing in for pykdtree; {dt:.2f} s",
-            "ms_per_icp_iter": dt * 1e3 / args.iters}, pose
+    times, last = [], np.eye(4, dtype=np.float32)
+    order = tracker.order
+    for i in range(frames + 1):
+        scan = tracker.host_scans[order[i % len(order)]]
+        t0 = time.perf_counter()
+        O.build_projection_map(scan, 64, 2048, 3.0, -24.0)
+        _, pose = orc.register_new_frame(scan, last if args.init == "cv" else np.eye(4, dtype=np.float32))
+        lm.update(pose)
+        times.append(time.perf_counter() - t0)
+        last = pose
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {"value": 1.0 / med, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"median of {frames} frames after 1 warm-up frame of the same workload (131072-pt scan vs 100k "
+                      f"map, {args.iters} iters; projection + registration + map re-expression/kd-tree rebuild) with "
+                      f"oracle/icp_oracle.py: numpy f32 + scipy cKDTree(workers=-1) standing in for pykdtree",
+            "frame_s": {"min": timed[0], "median": med, "max": timed[-1], "warmup": times[0]},
+            "tree_build_s": build_s, "ms_per_icp_iter": med * 1e3 / args.iters,
+            "torch_threads": torch.get_num_threads()}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter run (with its provenance)."""
+    path = os.path.join(ROOT, "profiles", "pmc_search_kernel.json")
+    try:
+        rec = json.load(open(path))
+        return rec.get("hbm_bytes_per_launch"), {"file": "profiles/pmc_search_kernel.json", "head": rec.get("head"),
+                                                 "workload": rec.get("workload")}
+    except Exception:
+        return None, None
+
+
+def timed_region(extra, main_tr, steps, dist, dev):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t_ in extra:
+        t_.start_phase(steps)
+    res = main_tr.run(steps, record=True)
+    for t_ in extra:
+        t_.done.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return res, elapsed
 
 
 def main():
@@ -155,180 +312,96 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    from pylidar_slam_amd.engine import IcpContext
     sharded = args.mode == "sharded" and world > 1
-    # replicas: every rank has its own sequence (seed offset); sharded: all ranks share sequence 0
-    cfg, scans, poses, model, order = make_workload(0 if sharded else rank, args.trajectory, args.warmup + args.steps)
-    n_pts = scans[order[0]].shape[0]
-    ctx = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
-                     scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size, max_rings=args.max_rings,
-                     device=local_rank)
-    ctx.use_torch_stream()
-    dev = torch.device("cuda", local_rank)
-    scans_dev = {f: torch.from_numpy(s).to(dev) for f, s in scans.items()}
-    vmap = torch.empty((3, 64, 2048), dtype=torch.float32, device=dev)
-    ctx.map_set(torch.from_numpy(model).to(dev))
-    neq = ctx.normal_equations_tensor() if sharded else None
-    if sharded:
-        from pylidar_slam_amd.distributed import shard_bounds
-        b, e = shard_bounds(n_pts, world, rank)
-        slices = {f: s[b:e].contiguous() for f, s in scans_dev.items()}
-
-    state = {"last": None, "prev_frame": 0, "max_err": 0.0}
-
-    def run(k, first_frame):
-        res = None
-        for i in range(k):
-            f = order[(first_frame + i) % len(order)]
-            init = state["last"] if args.init == "cv" else None  # ConstantVelocityInitialization: last relative pose
-            if sharded:
-                res = step_sharded(ctx, slices[f], scans_dev[f], vmap, args.iters, init)
-            else:
-                res = step_replica(ctx, scans_dev[f], vmap, init)
-            state["last"] = res.pose
-            gt_rel = np.linalg.inv(poses[state["prev_frame"]]) @ poses[f]  # O(1) host bookkeeping, not device work
-            state["max_err"] = max(state["max_err"], float(np.linalg.norm(gt_rel[:3, 3] - res.pose[:3, 3])))
-            state["prev_frame"] = f
-        return res
-
-    # ---- throughput mode: S - 1 more sequences on their own contexts / streams / host threads
-    extra = []
     S = max(1, args.sequences_per_gpu)
-    if S > 1:
-        assert not sharded, "--sequences-per-gpu applies to independent sequences"
-        import threading
-
-        class Sequence(threading.Thread):
-            def __init__(self, j):
-                super().__init__(daemon=True)
-                self.j = j
-                self.go = threading.Event()
-                self.done = threading.Event()
-                self.phase = None
-                self.max_err = 0.0
-                self.stream = torch.cuda.Stream(device=dev)
-
-            def run(self):
-                torch.cuda.set_device(local_rank)
-                with torch.cuda.stream(self.stream):
-                    _, sc, ps, mdl, od = make_workload(rank * S + self.j + 100, args.trajectory, args.warmup + args.steps)
-                    c = IcpContext(height=64, width=2048, max_num_alignments=args.iters, threshold_delta_pose=0.0,
-                                   scheme=args.scheme, sigma=args.sigma, cell_size=args.cell_size,
-                                   max_rings=args.max_rings, device=local_rank)
-                    c.use_torch_stream()
-                    sd = {f: torch.from_numpy(x).to(dev) for f, x in sc.items()}
-                    vm = torch.empty((3, 64, 2048), dtype=torch.float32, device=dev)
-                    c.map_set(torch.from_numpy(mdl).to(dev))
-                    last, prev, first = None, 0, 0
-                    while True:
-                        self.go.wait()
-                        self.go.clear()
-                        if self.phase is None:
-                            c.close()
-                            return
-                        for i in range(self.phase):
-                            f = od[(first + i) % len(od)]
-                            r = step_replica(c, sd[f], vm, last if args.init == "cv" else None)
-                            last = r.pose
-                            gt = np.linalg.inv(ps[prev]) @ ps[f]
-                            self.max_err = max(self.max_err, float(np.linalg.norm(gt[:3, 3] - r.pose[:3, 3])))
-                            prev = f
-                        first += self.phase
-                        self.stream.synchronize()
-                        self.done.set()
-
-            def start_phase(self, k):
-                self.phase = k
-                self.done.clear()
-                self.go.set()
-
-        extra = [Sequence(j) for j in range(1, S)]
-        for t_ in extra:
-            t_.start()
-        for t_ in extra:
-            t_.start_phase(args.warmup)
-    run(args.warmup, 0)
+    assert not (sharded and S > 1), "--sequences-per-gpu applies to independent sequences"
+    # replicas: every rank (and every sequence of a rank) has its own seeded sequence; sharded: all ranks share one
+    main_tr = Tracker(args, 0 if sharded else rank * S, args.trajectory, args.warmup + args.steps, local_rank,
+                      sharded=(world, rank) if sharded else None)
+    extra = [SequenceThread(args, rank * S + j, local_rank) for j in range(1, S)]
+    for t_ in extra:
+        t_.start()
+    for t_ in extra:
+        t_.ready.wait()
+        t_.start_phase(args.warmup)
+    main_tr.run(args.warmup)
     for t_ in extra:
         t_.done.wait()
     if not args.no_profile:
-        ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4 adds the normals
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t_ in extra:
-        t_.start_phase(args.steps)
-    res = run(args.steps, args.warmup)
-    for t_ in extra:
-        t_.done.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read() if not args.no_profile else None
-    ctx.profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        main_tr.ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4: + normals
+    res, elapsed = timed_region(extra, main_tr, args.steps, dist, dev)
+    prof = main_tr.ctx.profile_read() if not args.no_profile else None
+    main_tr.ctx.profile_enable(0)
 
-    # sanity of the tracked trajectory (outside the timed region): the last relative pose against ground truth
-    last = order[(args.warmup + args.steps - 1) % len(order)]
-    prev = order[(args.warmup + args.steps - 2) % len(order)]
-    gt_rel = np.linalg.inv(poses[prev]) @ poses[last]
-    gt_err = float(np.linalg.norm(gt_rel[:3, 3] - res.pose[:3, 3]))
+    # the closed-circuit trajectory next to the headline (single sequence, rank 0 only, outside the headline timing)
+    loop = None
+    if rank == 0 and args.loop_steps > 0 and args.trajectory != "loop" and not sharded and S == 1:
+        lt = Tracker(args, rank * S, "loop", 3 + args.loop_steps, local_rank)
+        lt.run(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lt.run(args.loop_steps, record=True)
+        torch.cuda.synchronize()
+        le = time.perf_counter() - t0
+        loop = {"value": args.loop_steps / le, "unit": "scans/s", "steps": args.loop_steps, "warmup": 3,
+                "ms_per_step": le * 1e3 / args.loop_steps, "ms_per_icp_iter": le * 1e3 / args.loop_steps / args.iters,
+                "max_pose_error_vs_ground_truth_m": lt.max_err}
+        lt.close()
 
     if rank == 0:
         scans_total = args.steps * (1 if sharded else world) * S
         value = scans_total / elapsed
         ms_step = elapsed * 1e3 / args.steps
+        sm = sorted(main_tr.step_ms)
         out = {
             "metric": "scans/sec + ms/ICP-iter, 64x2048-pt scan vs 100k-pt map, 20 iters",
             "value": value, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "ms_per_icp_iter": ms_step / args.iters, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 64x2048 synthetic scan (131072 pts) vs fixed 100000-pt local map, "
-                                   f"{args.iters} point-to-plane ICP iterations, frame = projection + registration "
-                                   "+ map re-expression/rebuild",
+            "config": {"workload": "C2: 64x2048 synthetic scan (131072 pts) vs fixed 100000-pt local map made of 8 "
+                                   f"other scans (tracked scans never in the map), {args.iters} point-to-plane ICP "
+                                   "iterations, frame = projection + registration + map re-expression/rebuild",
                        "scheme": args.scheme, "sigma": args.sigma, "cell_size_m": args.cell_size,
-                       "parallelism": ("points-sharded + RCCL all-reduce of 6x6 normal equations" if sharded else
-                                       f"{world * S} independent sequences, {S} per GPU (replicated map, no collective)")},
-            "last_pose_error_vs_ground_truth_m": gt_err,
-            "max_pose_error_vs_ground_truth_m": max([state["max_err"]] + [t_.max_err for t_ in extra]),
-            "init": args.init, "trajectory": args.trajectory, "sequences_per_gpu": S,
-            "iterations_last_frame": int(res.iterations),
+                       "trajectory": args.trajectory, "init": args.init, "options": args.option,
+                       "parallelism": ("points-sharded + exchange of the 6x6 normal equations per iteration" if sharded
+                                       else f"{world * S} independent sequences, {S} per GPU (replicated map, no "
+                                            "collective)")},
+            "ms_per_step_spread": {"min": sm[0], "median": sm[len(sm) // 2], "p90": sm[int(0.9 * (len(sm) - 1))],
+                                   "max": sm[-1]},
+            "last_pose_error_vs_ground_truth_m": main_tr.last_err,
+            "max_pose_error_vs_ground_truth_m": max([main_tr.max_err] + [t_.max_err for t_ in extra]),
+            "sequences_per_gpu": S, "iterations_last_frame": int(res.iterations),
         }
+        if args.steps < MIN_STEPS_FOR_HEADLINE:
+            out["note"] = (f"only {args.steps} timed steps ({elapsed * 1e3:.0f} ms): SURVEY.md §8(d) asks for >= "
+                           f"{MIN_STEPS_FOR_HEADLINE}; read ms_per_step_spread with the value")
+        if loop is not None:
+            out["loop"] = loop
         if prof and prof["search_launches"] > 0:
             avg_s = prof["search_ms"] * 1e-3 / prof["search_launches"]
-            n_local = slices[order[0]].shape[0] if sharded else n_pts
+            n_local = main_tr.n_local if sharded else main_tr.n_pts
             achieved = BYTES_PER_POINT_ITER * n_local / avg_s
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_search_kernel.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "k_iterate_rows (per-iteration fused kernel: transform + exact 1-NN in the voxel-hash grid + "
-                                         "point-to-plane rows + per-block partial normal equations)",
+            traffic, source = pmc_traffic()
+            out["roofline"] = {"bound": "hbm",
+                               "kernel": "k_iterate_rows (per-iteration fused kernel: transform + exact 1-NN in the "
+                                         "voxel-hash grid + point-to-plane rows + per-block partial normal equations)",
                                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": traffic,
+                               "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
                                "avg_launch_us": avg_s * 1e6, "launches": prof["search_launches"],
                                "algorithmic_bytes_per_launch": BYTES_PER_POINT_ITER * n_local}
         if prof and prof.get("normals_ms", 0.0) > 0.0:
             out["normals_ms_per_step"] = prof["normals_ms"] / args.steps
         if not args.no_cpu_baseline and world == 1:
-            f = order[(args.warmup + args.steps - 1) % len(order)]
-            cb, _ = cpu_baseline(scans[f], model, args)
-            out["cpu_baseline"] = cb
+            out["cpu_baseline"] = cpu_baseline(main_tr, args)
         print(json.dumps(out))
     for t_ in extra:
         t_.phase = None

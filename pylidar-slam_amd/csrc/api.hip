@@ -140,7 +140,10 @@ __global__ void k_map_move(const float* __restrict__ in, long long m, Pose16 rel
     if (threadIdx.x == 0) {
         float pose[16], inv[16];
         for (int k = 0; k < 16; ++k) pose[k] = st ? st->pose[k] : rel.m[k];
-        if (!invert4(pose, inv))  // cannot happen for a pose built from Euler angles; the host path checks beforehand
+        // a registration that stopped on an error moves nothing: the reference raises before it would touch the map
+        // (slam/common/optimization.py:334-336 inside icp_odometry.py:286), the host learns of it in icp_register_end
+        const bool failed = st && st->status != ICP_OK;
+        if (failed || !invert4(pose, inv))  // a pose built from Euler angles is never singular; the host path checks
             for (int k = 0; k < 16; ++k) inv[k] = (k % 5 == 0) ? 1.f : 0.f;
         for (int k = 0; k < 16; ++k) T[k] = inv[k];
     }
@@ -175,7 +178,20 @@ __global__ void k_vmap_points(const float* __restrict__ vmap, int npix, float th
 }  // namespace icp
 
 // ---- helpers --------------------------------------------------------------------------------------------------------
-static thread_local std::string g_create_error;
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it (a
+// process may hold contexts on several GPUs, and torch shares the thread's current device with us).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const icp_ctx* ctx) : DeviceGuard(ctx ? ctx->cfg.device : -1) {}
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 static int fail(icp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->error = msg;
@@ -284,22 +300,12 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
         cfg->num_neighbors_normals < 1 || cfg->num_neighbors_normals > 64 || cfg->local_map_size < 1 ||
         cfg->max_num_alignments < 1)
         return ICP_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(cfg->device) != hipSuccess) return ICP_ERR_HIP;
+    DeviceGuard device_guard(cfg->device);
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != cfg->device) return ICP_ERR_HIP;
     icp_ctx* ctx = new icp_ctx();
     ctx->cfg = *cfg;
     ctx->cell_h = cfg->cell_size > 0.f ? cfg->cell_size : 0.5f;
-    if (const char* v = getenv("ICP_SEARCH_VARIANT")) ctx->search_variant = atoi(v);
-    if (const char* v = getenv("ICP_SORT_TARGETS")) ctx->sort_targets = atoi(v);
-    if (const char* v = getenv("ICP_NN_CACHE")) ctx->use_nn_cache = atoi(v);
-    if (const char* v = getenv("ICP_KNN_RINGS")) ctx->knn_rings = atoi(v);
-    if (const char* v = getenv("ICP_KNN_LANES")) ctx->knn_lanes = atoi(v) == 2 ? 2 : 4;
-    if (const char* v = getenv("ICP_SEARCH_STATS")) ctx->search_stats = atoi(v);
-    if (ctx->search_stats) {
-        if (ctx->dbg_counts.reserve(64) != hipSuccess) ctx->search_stats = 0;
-        else (void)hipMemset(ctx->dbg_counts.ptr, 0, 64);
-    }
-    if (const char* v = getenv("ICP_FUSE_ITERATION")) ctx->fuse_iteration = atoi(v);
-    if (const char* v = getenv("ICP_TARGET_OCCUPANCY")) ctx->target_occupancy = atof(v) > 0.1 ? atof(v) : 4.0;
     int rc = ensure_state(ctx);
     if (rc == ICP_OK) rc = init_state(ctx, nullptr);
     if (rc != ICP_OK) {
@@ -312,6 +318,7 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
 
 void icp_destroy(icp_ctx* ctx) {
     if (!ctx) return;
+    DeviceGuard device_guard(ctx);
     (void)hipDeviceSynchronize();
     DeviceBuffer* bufs[] = {&ctx->map_xyz[0], &ctx->map_xyz[1], &ctx->table,   &ctx->sorted_pts, &ctx->normals,
                             &ctx->nflag,      &ctx->slot_of,    &ctx->rank_of, &ctx->scan_tmp,   &ctx->worklist,
@@ -319,11 +326,11 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
                             &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
-                            &ctx->grid_stats, &ctx->tgt4,       &ctx->tgt_perm,  &ctx->row_of_slot, &ctx->slot_of_cell,
+                            &ctx->grid_stats, &ctx->tgt4,       &ctx->row_of_slot, &ctx->slot_of_cell,
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cslot_of,
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
-                            &ctx->vox_out};
+                            &ctx->vox_out,    &ctx->seed_orig};
     for (DeviceBuffer* b : bufs) b->release();
     if (ctx->host_result) (void)hipHostFree(ctx->host_result);
     if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
@@ -337,12 +344,41 @@ void icp_destroy(icp_ctx* ctx) {
 const char* icp_last_error(const icp_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
 int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ctx->stream = (hipStream_t)hip_stream;
     return ICP_OK;
 }
 
+int icp_set_option(icp_ctx* ctx, const char* name, double value) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !name) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    const std::string k(name);
+    const int iv = (int)value;
+    if (k == "nn_cache") ctx->use_nn_cache = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
+    else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
+    else if (k == "compact_misses") ctx->compact_misses = iv != 0;
+    else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
+    else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
+    else if (k == "normals_two_pass") ctx->normals_two_pass = iv != 0;
+    else if (k == "knn_rings") ctx->knn_rings = iv;
+    else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
+    else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 5.0;
+    else if (k == "search_stats") {
+        ctx->search_stats = iv != 0;
+        if (ctx->search_stats) {
+            ICP_HIP(ctx, ctx->dbg_counts.reserve(64));
+            ICP_HIP(ctx, hipMemsetAsync(ctx->dbg_counts.ptr, 0, 64, ctx->stream));
+        }
+    } else {
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "unknown option");
+    }
+    return ICP_OK;
+}
+
 int icp_synchronize(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
@@ -350,6 +386,7 @@ int icp_synchronize(icp_ctx* ctx) {
 
 int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num_alignments,
                       float threshold_delta_pose) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     if (scheme < 0 || scheme > ICP_SCHEME_CAUCHY || max_num_alignments < 1)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "bad alignment parameters");
@@ -362,6 +399,7 @@ int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num
 
 // ---- projection -----------------------------------------------------------------------------------------------------
 int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_out, int32_t* index_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
     const size_t npix = (size_t)ctx->cfg.height * ctx->cfg.width;
     const void* in;
@@ -379,6 +417,7 @@ int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_
 
 int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
                        int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !rows_out || !cols_out) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -395,6 +434,7 @@ int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float
 
 int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int stride, int mem, double* xyz_out,
                            int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || stride < 3 || (n > 0 && (!scan || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, scan, (size_t)n * stride * 4, mem, ctx->stage_in, &in);
@@ -410,6 +450,7 @@ int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int strid
 // ---- grid sampling --------------------------------------------------------------------------------------------------
 int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                    int64_t* hashes_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !(voxel_size > 0)) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -426,6 +467,7 @@ int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double vo
 
 int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                     float* points_out, int64_t* count_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -450,6 +492,7 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
 int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                          int64_t* hashes_out, int64_t* voxel_ids_out, int64_t* num_voxels_out, int64_t* sizes_out,
                          float* means_out, float* covs_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !(voxel_size > 0) || !num_voxels_out || !voxel_ids_out) return ICP_ERR_INVALID_ARGUMENT;
     const bool stats = sizes_out || means_out || covs_out;
     if (stats && !(sizes_out && means_out && covs_out)) return ICP_ERR_INVALID_ARGUMENT;
@@ -498,6 +541,7 @@ int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, dou
 
 int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                         double* points_out, int64_t* count_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -522,6 +566,7 @@ int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, dou
 // ---- de-skew --------------------------------------------------------------------------------------------------------
 int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_t n, int mem, const double rel_pose[16],
                 double* xyz_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !rel_pose || (n > 0 && (!xyz || !timestamps || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
     const void *in, *ts;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -537,6 +582,7 @@ int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_
 
 // ---- local map ------------------------------------------------------------------------------------------------------
 int icp_map_init(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ctx->map_m = 0;
     ctx->cloud_sizes.clear();
@@ -545,6 +591,7 @@ int icp_map_init(icp_ctx* ctx) {
 }
 
 int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || m < 0 || (m > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
     icp_map_init(ctx);  // set_map_pointcloud() calls init(): `_local_map_num_elements` stays empty (local_map.py:294)
     DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
@@ -554,7 +601,8 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
                                     mem == ICP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                     ctx->stream));
     ctx->map_m = m;
-    int rc = build_grid(ctx);
+    int rc = stash_frame_seeds(ctx, 0, false);  // a new map: the old neighbours mean nothing
+    if (!rc) rc = build_grid(ctx);
     if (rc) return rc;
     if (mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
@@ -566,6 +614,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
     int rc = ensure_state(ctx);
     if (rc) return rc;
     int64_t inserted = 0;
+    int64_t evicted = 0;
     if (ctx->map_m == 0 && ctx->cloud_sizes.empty() && !ctx->grid_valid) {
         // first cloud: the map becomes the cloud, the pose is ignored (local_map.py:334-337)
         DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
@@ -588,6 +637,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         const size_t clouds_after = ctx->cloud_sizes.size() + (has_cloud ? 1 : 0);
         if ((int64_t)clouds_after > ctx->cfg.local_map_size && !ctx->cloud_sizes.empty()) evict = ctx->cloud_sizes[0];
         if (evict > ctx->map_m) evict = ctx->map_m;
+        evicted = evict;
         const int64_t keep = ctx->map_m - evict;
         const int next = ctx->map_cur ^ 1;
         DeviceBuffer& dst = ctx->map_xyz[next];
@@ -616,11 +666,13 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         ICP_HIP(ctx, hipGetLastError());
     }
     if (inserted_out) *inserted_out = inserted;
+    if ((rc = stash_frame_seeds(ctx, evicted, true))) return rc;  // kept points keep their order: index - evicted
     return build_grid(ctx);
 }
 
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
     if (!rel_pose && !ctx->have_device_pose)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL needs a previous registration on this context");
@@ -640,6 +692,7 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
 
 int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,
                               int64_t* inserted_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !rel_pose || !vmap) return ICP_ERR_INVALID_ARGUMENT;
     const int npix = ctx->cfg.height * ctx->cfg.width;
     const void* in;
@@ -656,6 +709,7 @@ int64_t icp_map_size(const icp_ctx* ctx) { return ctx ? ctx->map_m : 0; }
 int icp_map_num_clouds(const icp_ctx* ctx) { return ctx ? (int)ctx->cloud_sizes.size() : 0; }
 
 int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !xyz_out) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m == 0) return ICP_OK;
     ICP_HIP(ctx, hipMemcpyAsync(xyz_out, ctx->map_xyz[ctx->map_cur].ptr, (size_t)ctx->map_m * 12,
@@ -667,9 +721,11 @@ int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem) {
 
 int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* neighbor_points_out,
                                 float* neighbor_normals_out, int32_t* neighbor_index_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
-    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    if (ctx->in_registration || ctx->result_pending)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     int rc = ensure_state(ctx);
     if (rc) return rc;
     const void* in;
@@ -677,8 +733,9 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     ctx->tgt_ptr = (const float*)in;
     ctx->tgt_n = n;
     ctx->tgt_mode = ICP_TARGETS_ALL;
+    ctx->have_device_pose = false;  // the search re-initialises the device state: it no longer holds a registration
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, nullptr, 0))) return rc;
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
     if ((rc = init_state(ctx, nullptr))) return rc;
     if ((rc = launch_search_raw(ctx))) return rc;
     if (neighbor_normals_out && (rc = launch_normals(ctx))) return rc;
@@ -697,6 +754,7 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
 
 // ---- projective local map -------------------------------------------------------------------------------------------
 int icp_compute_normal_map(icp_ctx* ctx, const float* vmap, int mem, int kernel_size, float* nmap_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !vmap || !nmap_out || kernel_size < 1 || kernel_size > 15 || !(kernel_size & 1))
         return ICP_ERR_INVALID_ARGUMENT;
     const size_t bytes = (size_t)ctx->cfg.height * ctx->cfg.width * 12;
@@ -713,6 +771,7 @@ int icp_compute_normal_map(icp_ctx* ctx, const float* vmap, int mem, int kernel_
 
 int icp_compute_neighbors(icp_ctx* ctx, const float* tgt_vmap, const float* ref_vmaps, const float* ref_fields,
                           int k_maps, int c_fields, int mem, float* neighbors_out, float* fields_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !tgt_vmap || !ref_vmaps || !neighbors_out || k_maps < 1 || c_fields < 0) return ICP_ERR_INVALID_ARGUMENT;
     const size_t px = (size_t)ctx->cfg.height * ctx->cfg.width;
     const void *t, *r, *f = nullptr;
@@ -736,6 +795,7 @@ int icp_compute_neighbors(icp_ctx* ctx, const float* tgt_vmap, const float* ref_
 }
 
 int icp_pmap_init(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ctx->pm_slots.clear();
     ctx->pm_poses.clear();
@@ -745,6 +805,7 @@ int icp_pmap_init(icp_ctx* ctx) {
 int icp_pmap_num_maps(const icp_ctx* ctx) { return ctx ? (int)ctx->pm_slots.size() : 0; }
 
 int icp_pmap_update(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem, int normals_kernel_size) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !rel_pose) return ICP_ERR_INVALID_ARGUMENT;
     if (vmap && (normals_kernel_size < 1 || normals_kernel_size > 15 || !(normals_kernel_size & 1)))
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "normals_kernel_size must be odd, 1..15");
@@ -807,6 +868,7 @@ int icp_pmap_update(icp_ctx* ctx, const float rel_pose[16], const float* vmap, i
 }
 
 int icp_pmap_get_model(icp_ctx* ctx, float* model_v4_out, float* model_n4_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     const size_t bytes = (size_t)ctx->pm_slots.size() * ctx->cfg.height * ctx->cfg.width * 16;
     if (bytes == 0) return ICP_OK;
@@ -819,6 +881,7 @@ int icp_pmap_get_model(icp_ctx* ctx, float* model_v4_out, float* model_n4_out, i
 
 int icp_pmap_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows9_out,
                                      int64_t* count_out, int out_mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || !rows9_out || !count_out) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->pm_slots.empty()) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     int rc = ensure_state(ctx);
@@ -845,6 +908,7 @@ int icp_pmap_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, 
 
 int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
                       icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !result || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->pm_slots.empty()) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     int rc = ensure_state(ctx);
@@ -854,7 +918,7 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
     ctx->tgt_ptr = (const float*)in;
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, init_pose, 0))) return rc;
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
     if ((rc = init_state(ctx, init_pose))) return rc;
     ctx->in_registration = true;
     const int iters = ctx->cfg.max_num_alignments;
@@ -883,6 +947,7 @@ static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], d
 int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
                              int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
                              double* normal_eq_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n <= 0 || !ref_points || !tgt_points || !ref_normals) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -915,6 +980,7 @@ static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], d
 int icp_align_point_to_point(icp_ctx* ctx, const float* ref_points, const float* tgt_points, int64_t n, int mem,
                              const float x0[6], float params_out[6], float pose_out[16], double* loss_out,
                              double* normal_eq_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n <= 0 || !ref_points || !tgt_points) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -997,6 +1063,7 @@ static double det3(const double* M) {
 
 int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* ref_points, const float* weights,
                             int64_t n, int mem, double pose_out[16]) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n <= 0 || !ref_points || !tgt_points || !pose_out) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -1033,6 +1100,7 @@ int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* 
 // ---- registration ---------------------------------------------------------------------------------------------------
 int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
                        const float init_pose[16]) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     int rc = ensure_state(ctx);
@@ -1043,7 +1111,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n, init_pose, ctx->sort_targets))) return rc;
+    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
     if ((rc = init_state(ctx, init_pose))) return rc;
     ctx->have_device_pose = true;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
@@ -1054,10 +1122,11 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     return ICP_OK;
 }
 
-// the fused search + rows kernel needs every normal it may touch: eager mode, and the rows search variant
-static bool fused_path(const icp_ctx* ctx) { return ctx->normals_ready && ctx->search_variant == 2 && ctx->fuse_iteration; }
+// the fused search + rows kernel needs every normal it may touch: the eager schedule
+static bool fused_path(const icp_ctx* ctx) { return ctx->normals_ready && ctx->fuse_iteration; }
 
 int icp_iteration_accumulate(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
     int rc;
     if (fused_path(ctx)) {
@@ -1071,6 +1140,7 @@ int icp_iteration_accumulate(icp_ctx* ctx) {
 }
 
 int icp_iteration_solve(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
     return launch_solve(ctx);
 }
@@ -1110,6 +1180,7 @@ static int enqueue_result_copy(icp_ctx* ctx) {
 }
 
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !ctx->in_registration || !result) return ICP_ERR_INVALID_ARGUMENT;
     ctx->in_registration = false;
     RegState st;
@@ -1197,6 +1268,7 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
 }
 
 int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
     if (rc) return rc;
@@ -1211,6 +1283,7 @@ int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int 
 
 int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
                  icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !result) return ICP_ERR_INVALID_ARGUMENT;
     int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
     if (rc) return rc;
@@ -1219,12 +1292,14 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
 }
 
 void* icp_normal_equations_ptr(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return nullptr;
     if (ensure_state(ctx) != ICP_OK) return nullptr;
     return ctx->neq;
 }
 
 int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -1234,6 +1309,7 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
 
 // ---- profiling ------------------------------------------------------------------------------------------------------
 int icp_profile_enable(icp_ctx* ctx, int enable) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ctx->prof.enabled = enable != 0;
     ctx->prof.mask = enable;
@@ -1247,6 +1323,7 @@ int icp_profile_enable(icp_ctx* ctx, int enable) {
 
 int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
                      double* normals_ms_out) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);

@@ -271,22 +271,10 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // K4: solve + pose update (one thread)
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float sy, float cz, float sz, float* R);
+
 __device__ inline void euler_to_mat_f32(float ex, float ey, float ez, float* R) {
-    // torch_euler_to_mat: Rz(ez) @ Ry(ey) @ Rx(ex)   (slam/common/rotation.py:144-150), float32
-    const float cx = cosf(ex), sx = sinf(ex), cy = cosf(ey), sy = sinf(ey), cz = cosf(ez), sz = sinf(ez);
-    // Ry Rx
-    const float a00 = cy, a01 = sy * sx, a02 = sy * cx;
-    const float a10 = 0.f, a11 = cx, a12 = -sx;
-    const float a20 = -sy, a21 = cy * sx, a22 = cy * cx;
-    R[0] = cz * a00 - sz * a10;
-    R[1] = cz * a01 - sz * a11;
-    R[2] = cz * a02 - sz * a12;
-    R[3] = sz * a00 + cz * a10;
-    R[4] = sz * a01 + cz * a11;
-    R[5] = sz * a02 + cz * a12;
-    R[6] = a20;
-    R[7] = a21;
-    R[8] = a22;
+    euler_trig_to_mat_f32(cosf(ex), sinf(ex), cosf(ey), sinf(ey), cosf(ez), sinf(ez), R);
 }
 
 __device__ inline void build_pose_f32(const float* p, float* T) {  // slam/common/pose.py:120-144
@@ -296,23 +284,6 @@ __device__ inline void build_pose_f32(const float* p, float* T) {  // slam/commo
     T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = p[1];
     T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
-}
-
-__device__ inline void from_pose_f32(const float* T, float* p) {  // pose.py:188-207, rotation.py:253-270
-    const float r00 = T[0], r10 = T[4], r20 = T[8], r21 = T[9], r22 = T[10], r11 = T[5], r12 = T[6];
-    const float sy = sqrtf(r00 * r00 + r10 * r10);
-    p[0] = T[3];
-    p[1] = T[7];
-    p[2] = T[11];
-    if (!(sy < 1.0e-6f)) {
-        p[3] = atan2f(r21, r22);
-        p[4] = atan2f(-r20, sy);
-        p[5] = atan2f(r10, r00);
-    } else {
-        p[3] = atan2f(-r12, r11);
-        p[4] = atan2f(-r20, sy);
-        p[5] = 0.f;
-    }
 }
 
 // Cholesky H = L L^T in f64 with fully unrolled static indexing (everything stays in registers): returns det(H)
@@ -397,56 +368,133 @@ __device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double
     return ICP_OK;
 }
 
-// `it` / `pose_in`: st->iter and st->pose as read by the caller (k_sum_solve fetches them while the partial rows are
-// still in flight; the other callers read them on the spot)
+// rotation matrix from the sines / cosines of the three Euler angles: Rz(ez) @ Ry(ey) @ Rx(ex)
+// (torch_euler_to_mat, slam/common/rotation.py:144-150), float32
+__device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float sy, float cz, float sz, float* R) {
+    const float a00 = cy, a01 = sy * sx, a02 = sy * cx;
+    const float a10 = 0.f, a11 = cx, a12 = -sx;
+    const float a20 = -sy, a21 = cy * sx, a22 = cy * cx;
+    R[0] = cz * a00 - sz * a10;
+    R[1] = cz * a01 - sz * a11;
+    R[2] = cz * a02 - sz * a12;
+    R[3] = sz * a00 + cz * a10;
+    R[4] = sz * a01 + cz * a11;
+    R[5] = sz * a02 + cz * a12;
+    R[6] = a20;
+    R[7] = a21;
+    R[8] = a22;
+}
+
+// sines and cosines of three angles, one angle per lane (lane % 3), gathered into every lane of the wave: three
+// independent libm chains run side by side instead of six calls in a row on one lane
+__device__ inline void wave_sincos3(float e0, float e1, float e2, float* sn, float* cs) {
+    const int a = (int)(threadIdx.x & 63) % 3;
+    const float ang = a == 0 ? e0 : (a == 1 ? e1 : e2);
+    const float s = sinf(ang), c = cosf(ang);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sn[k] = __shfl(s, k, 64);
+        cs[k] = __shfl(c, k, 64);
+    }
+}
+
+__device__ inline void wave_build_pose_f32(const float* p, float* T) {  // slam/common/pose.py:120-144
+    float sn[3], cs[3], R[9];
+    wave_sincos3(p[3], p[4], p[5], sn, cs);
+    euler_trig_to_mat_f32(cs[0], sn[0], cs[1], sn[1], cs[2], sn[2], R);
+    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = p[0];
+    T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = p[1];
+    T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+__device__ inline void wave_from_pose_f32(const float* T, float* p) {  // pose.py:188-207, rotation.py:253-270
+    const float r00 = T[0], r10 = T[4], r20 = T[8], r21 = T[9], r22 = T[10], r11 = T[5], r12 = T[6];
+    const float sy = sqrtf(r00 * r00 + r10 * r10);
+    const bool regular = !(sy < 1.0e-6f);
+    const int a = (int)(threadIdx.x & 63) % 3;  // one atan2 per lane
+    float y, x;
+    if (a == 0) {
+        y = regular ? r21 : -r12;
+        x = regular ? r22 : r11;
+    } else if (a == 1) {
+        y = -r20;
+        x = sy;
+    } else {
+        y = r10;
+        x = r00;
+    }
+    const float e = atan2f(y, x);
+    p[0] = T[3];
+    p[1] = T[7];
+    p[2] = T[11];
+    p[3] = __shfl(e, 0, 64);
+    p[4] = __shfl(e, 1, 64);
+    p[5] = regular ? __shfl(e, 2, 64) : 0.f;
+}
+
+// One Gauss-Newton step + the pose update of register_new_frame, executed by ALL 64 lanes of one wave: the f64 Cholesky
+// runs redundantly (identical in every lane), the trigonometry of the pose algebra — most of the serial time — is
+// spread one angle per lane; lane 0 writes the state.  `it` / `pose_in`: st->iter and st->pose as read by the caller
+// (k_sum_solve fetches them while the partial rows are still in flight).
 __device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
                                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
                                         int it, const float* pose_in) {
-    st->n_worklist = 0;
-    st->n_targets = (int)neq[29];
+    const bool writer = (threadIdx.x & 63) == 0;
     float dx[6];
     double loss;
     int stopped;
     const int status = gauss_newton_from_neq(neq, dx, &loss, &stopped);
-    if (it < hist_cap) {
-        loss_hist[it] = loss;
-        for (int a = 0; a < 6; ++a) dx_hist[6 * it + a] = dx[a];
+    if (writer) {
+        st->n_worklist = 0;
+        st->n_targets = (int)neq[29];
+        if (it < hist_cap) {
+            loss_hist[it] = loss;
+            for (int a = 0; a < 6; ++a) dx_hist[6 * it + a] = dx[a];
+        }
+        st->iter = it + 1;
     }
-    st->iter = it + 1;
     if (status != ICP_OK) {
-        st->status = status;
-        st->done = 1;
+        if (writer) {
+            st->status = status;
+            st->done = 1;
+        }
         return;
     }
     // if delta_pose.norm() < threshold: break     (icp_odometry.py:292) — also taken by the residual guard (dx = 0)
     float nrm2 = 0.f;
     for (int a = 0; a < 6; ++a) nrm2 += dx[a] * dx[a];
     if (sqrtf(nrm2) < ap.threshold_delta_pose || stopped) {
-        st->done = 1;
-        st->converged = 1;
+        if (writer) {
+            st->done = 1;
+            st->converged = 1;
+        }
         return;
     }
     // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
-    float D[16], P[16];
-    for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = pose_in[k2];
-    build_pose_f32(dx, D);
+    float D[16], P[16], prm[6], T[16];
+    wave_build_pose_f32(dx, D);
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 4; ++c) {
             float s = 0.f;
             for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * pose_in[4 * k2 + c];
             P[4 * r + c] = s;
         }
-    float prm[6];
-    from_pose_f32(P, prm);
-    for (int a = 0; a < 6; ++a) st->params[a] = prm[a];
-    build_pose_f32(prm, st->pose);
-    if (st->iter >= ap.max_iters) st->done = 1;
+    wave_from_pose_f32(P, prm);
+    wave_build_pose_f32(prm, T);
+    if (writer) {
+        for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = pose_in[k2];
+        for (int a = 0; a < 6; ++a) st->params[a] = prm[a];
+        for (int k2 = 0; k2 < 16; ++k2) st->pose[k2] = T[k2];
+        if (it + 1 >= ap.max_iters) st->done = 1;
+    }
 }
 
-__global__ void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
-                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->done) return;
+__global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
+                                              double* __restrict__ loss_hist, float* __restrict__ dx_hist,
+                                              int hist_cap) {
+    if (blockIdx.x != 0) return;
+    if (st->done) return;  // wave-uniform
     float pose_in[16];
     for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
     solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap, st->iter, pose_in);
@@ -461,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     const int done = st->done;
     int it = 0;
     float pose_in[16];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {  // the solving wave (uniform addresses: one transaction)
         it = st->iter;
 #pragma unroll
         for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
@@ -471,7 +519,7 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     __syncthreads();
     if (done) return;
     if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
-    if (threadIdx.x == 0) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
+    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
 }
 
 // align() on given correspondences: writes params = x0 + dx [6], pose[16] = build_pose_matrix(params) (f32) and loss

@@ -300,80 +300,19 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Target preparation for a registration: rows -> float4, ordered along a Morton curve of the map's cells (under the
-// initial pose) so that the 64 lanes of a wave query a compact blob of cells.  Ring-major scan order is only coherent
-// in 1-D: a far-range arc of 64 points spans hundreds of cells, a Morton run of 64 points a handful.  The order only
-// changes which lanes work together and the (fixed) order of the f64 reduction, never a per-point result.
+// Target preparation for a registration: [n,3] rows -> float4 (x, y, z, bits(row)), one aligned 16-byte load per target
+// in the iteration kernels.
 // ---------------------------------------------------------------------------------------------------------------------
-struct PoseArg {
-    float m[16];
-};
-
-__device__ inline unsigned spread10(unsigned v) {  // 10 bits -> every third bit
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-__global__ void k_morton_keys(const float* __restrict__ xyz, int n, PoseArg T, float inv_h, unsigned* __restrict__ keys,
-                              int* __restrict__ vals) {
+__global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    unsigned key = 0x7fffffffu;  // NaN rows last
-    if (x == x && y == y && z == z) {
-        const float px = fmaf(z, T.m[2], fmaf(y, T.m[1], x * T.m[0])) + T.m[3];
-        const float py = fmaf(z, T.m[6], fmaf(y, T.m[5], x * T.m[4])) + T.m[7];
-        const float pz = fmaf(z, T.m[10], fmaf(y, T.m[9], x * T.m[8])) + T.m[11];
-        const int cx = cell_coord(px, inv_h), cy = cell_coord(py, inv_h), cz = cell_coord(pz, inv_h);
-        key = spread10((unsigned)cx) | (spread10((unsigned)cy) << 1) | (spread10((unsigned)cz) << 2);
-    }
-    keys[i] = key;
-    vals[i] = i;
+    out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
-__global__ void k_gather_targets(const float* __restrict__ xyz, const int* __restrict__ perm, int n,
-                                 float4* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int i = perm ? perm[j] : j;
-    out[j] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
-}
-
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const float* pose16_host, int sort) {
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n) {
     ICP_HIP(ctx, ctx->tgt4.reserve((size_t)(n > 0 ? n : 1) * sizeof(float4)));
     if (n <= 0) return ICP_OK;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    const int* perm = nullptr;
-    if (sort && n > 1024) {
-        ICP_HIP(ctx, ctx->keys_a.reserve((size_t)n * 8));
-        ICP_HIP(ctx, ctx->keys_b.reserve((size_t)n * 8));
-        ICP_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
-        ICP_HIP(ctx, ctx->tgt_perm.reserve((size_t)n * 4));
-        unsigned* ka = ctx->keys_a.as<unsigned>();
-        unsigned* kb = ctx->keys_b.as<unsigned>();
-        int* va = ctx->vals_a.as<int>();
-        int* vb = ctx->tgt_perm.as<int>();
-        PoseArg T;
-        if (pose16_host) {
-            memcpy(T.m, pose16_host, sizeof(T.m));
-        } else {
-            memset(T.m, 0, sizeof(T.m));
-            T.m[0] = T.m[5] = T.m[10] = T.m[15] = 1.f;
-        }
-        hipLaunchKernelGGL(k_morton_keys, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, T, 1.0f / ctx->cell_h, ka,
-                           va);
-        size_t tmp_bytes = 0;
-        ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 31, ctx->stream));
-        ICP_HIP(ctx, ctx->sort_tmp.reserve(tmp_bytes));
-        ICP_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 31,
-                                               ctx->stream));
-        perm = vb;
-    }
-    hipLaunchKernelGGL(k_gather_targets, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, perm, (int)n,
+    hipLaunchKernelGGL(k_pack_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
                        ctx->tgt4.as<float4>());
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;

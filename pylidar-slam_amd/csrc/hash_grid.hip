@@ -443,6 +443,7 @@ int build_grid(icp_ctx* ctx) {
     ctx->ctable_size = tsize;
     ICP_HIP(ctx, hipGetLastError());
     ctx->grid_valid = true;
+    ctx->grid_gen += 1;  // cell-sorted positions handed out before this build are void
     return ICP_OK;
 }
 

@@ -143,14 +143,13 @@ struct icp_ctx {
     icp::DeviceBuffer scan_tmp;
     icp::DeviceBuffer worklist;        // int[M]
     bool grid_valid = false;
-    int search_variant = 2;            // 0: per-lane ring search, 1: wave tiles in LDS, 2: neighbour rows + 4 lanes per
-                                       // query (default); env ICP_SEARCH_VARIANT — all three give identical results
+    uint64_t grid_gen = 0;             // bumped by every grid build: cell-sorted positions are only valid within one
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
     int64_t normals_eager_count = 0;
     float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
     icp::DeviceBuffer grid_stats;      // int[4]: occupied cells of the last build
     int occupied_cells = 0;
-    double target_occupancy = 5.0;     // auto-tuning target, map points per occupied cell (env ICP_TARGET_OCCUPANCY)
+    double target_occupancy = 5.0;     // auto-tuning target, map points per occupied cell (option "target_occupancy")
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
@@ -166,15 +165,23 @@ struct icp_ctx {
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer nn_cache;        // int2[N]: (NN position, bits(L)) — L = lower bound on the distance to every other map point
     int iter_in_registration = 0;
-    int knn_rings = -1;                // env ICP_KNN_RINGS: fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
-    int knn_lanes = 4;                 // env ICP_KNN_LANES: lanes per map point in the kNN kernels (4 or 2)
-    int use_nn_cache = 2;              // env ICP_NN_CACHE: 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
-    icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read (Morton-sorted for a registration)
-    icp::DeviceBuffer tgt_perm;        // int[N]: sorted position -> caller's row
-    int search_stats = 0;              // env ICP_SEARCH_STATS: count which path resolved each query (dev)
+    // tuning options (icp_set_option; none of them changes a result)
+    int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
+    int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
+    int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
+    int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
+    int compact_misses = 1;            // "compact_misses": fused kernel with in-block compaction of the cache misses
+    int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
+    int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
+    int normals_two_pass = 1;          // "normals_two_pass": eager normals as ring-1 pass + dense worklist pass
+    int search_stats = 0;              // "search_stats": count which path resolved each query (dev)
     icp::DeviceBuffer dbg_counts;
-    int fuse_iteration = 1;            // search + rows + partial sums in one kernel when normals are ready (env ICP_FUSE_ITERATION)
-    int sort_targets = 0;              // Morton-sort the targets of a registration (env ICP_SORT_TARGETS)
+    icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read
+    // what nn_cache currently describes: `cache_n` targets against the grid of generation `cache_gen` (map of cache_m points)
+    int64_t cache_n = 0, cache_m = 0;
+    uint64_t cache_gen = 0;
+    icp::DeviceBuffer seed_orig;       // int[N]: original map index of the neighbour each scan slot had in the last frame
+    int64_t seed_n = 0;                // valid entries of seed_orig (0: none)
     icp::DeviceBuffer partials;        // double[blocks][NEQ]
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
@@ -230,6 +237,9 @@ int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, qu
 int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
 int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager mode)
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
+// before a grid rebuild: nn_cache of the last registration -> seeds of the next frame (`evicted` oldest points dropped;
+// indices_survive = false when the map is replaced wholesale)
+int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive);
 
 // ---- gauss_newton.hip
 AlignParams make_align_params(const icp_ctx* ctx);
@@ -266,8 +276,8 @@ int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, doubl
                            double* points_dev, int* count_dev);
 int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int64_t n, const double* rel_pose16,
                    double* out_dev);
-// targets -> float4 rows in ctx->tgt4; sorted along a Morton curve of the map's cells under `pose` when sort != 0
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const float* pose16_host, int sort);
+// targets -> float4 rows (x, y, z, bits(row)) in ctx->tgt4
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n);
 int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                             long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
                             float* covs_dev, int* count_dev);

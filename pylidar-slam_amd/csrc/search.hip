@@ -9,206 +9,25 @@
 // the query inside its cell.  Cells whose box is farther than the current best are skipped without a table probe.
 // Queries that exhaust `max_rings` fall back to an exhaustive scan, so the result is the exact NN for every input.
 // Distance ties are broken on the smaller original map index (the kd-tree's tie order is unspecified).
-#include <stdlib.h>
-
-#include <mutex>
-
 #include "gn_device.h"
 #include "icp_internal.h"
 #include "search_device.h"
 
 namespace icp {
 
-__constant__ int g_debug_flags = 0;  // dev-only ablation switches (env ICP_DEBUG_FLAGS), 0 in production
-
 // ---------------------------------------------------------------------------------------------------------------------
-// K1: transform + exact 1-NN; queue the hit map points that have no normal yet
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_search(GridView g, const float4* __restrict__ tgt, int n, int mode,
-                                                int transform, RegState* __restrict__ st, int max_rings,
-                                                int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                int* __restrict__ worklist, int queue_normals) {
-    if (st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 t4 = tgt[i];
-    const float x = t4.x, y = t4.y, z = t4.z;
-    if (!target_valid(x, y, z, mode)) {
-        nn_pos[i] = -1;
-        return;
-    }
-    float px = x, py = y, pz = z;
-    if (transform) transform_point(st->pose, x, y, z, px, py, pz);
-    const Best b = nearest_in_grid(g, px, py, pz, max_rings);
-    nn_pos[i] = b.pos;
-    if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
-        if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K1 (tiled): the same exact search, with the candidate cells of each WAVE staged in LDS.
+// K1: transform + exact 1-NN, neighbour rows, 4 lanes per query.
 //
-// 64 consecutive scan points are spatially adjacent (ring-major order), so their 27-cell neighbourhoods overlap almost
-// completely.  Per wave: (1) cell box of its 64 queries dilated by one cell; (2) the lanes probe the hash table for the
-// cells of that box IN PARALLEL (independent probes instead of 27 dependent ones per lane) and copy the found cells'
-// points into an LDS tile; (3) every lane walks its own 27 cells through a dense LDS cell index, pruning by box
-// distance, reading candidates from LDS.  A lane whose best is not provably exact after ring 1 (or a wave whose box or
-// tile does not fit) falls back to the per-lane global search above, so results are identical to `k_search`.
-// ---------------------------------------------------------------------------------------------------------------------
-static constexpr int WS_CELLS = 512;   // cells of a wave's dilated box
-static constexpr int WS_POINTS = 768;  // map points staged per wave
-
-struct WaveTile {
-    float4 pts[WS_POINTS];
-    unsigned seg[WS_CELLS];  // (tile offset << 16) | count, 0 = empty cell
-    int gstart[WS_CELLS];    // cell start in the global cell-sorted array (to report positions)
-};
-
-__device__ inline int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ inline int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-__device__ inline void scan_tile_cell(const WaveTile& T, unsigned packed, int gstart, float px, float py, float pz,
-                                      Best& b) {
-    const int off = (int)(packed >> 16), count = (int)(packed & 0xffffu);
-    const int last = count - 1;
-    for (int k = 0; k <= last; k += 2) {
-        const int k1 = min(k + 1, last);
-        const float4 q0 = T.pts[off + k], q1 = T.pts[off + k1];
-        consider(q0, gstart + k, px, py, pz, b);
-        consider(q1, gstart + k1, px, py, pz, b);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_search_tiled(GridView g, const float4* __restrict__ tgt, int n, int mode,
-                                                      int transform, RegState* __restrict__ st, int max_rings,
-                                                      int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                      int* __restrict__ worklist, int queue_normals) {
-    __shared__ WaveTile tiles[4];
-    __shared__ int cursor[4];
-    __shared__ int overflow[4];
-    if (st->done) return;  // block-uniform
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    WaveTile& T = tiles[w];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool valid = i < n;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
-        const float4 t4 = tgt[i];
-        const float x = t4.x, y = t4.y, z = t4.z;
-        valid = target_valid(x, y, z, mode);
-        px = x;
-        py = y;
-        pz = z;
-        if (valid && transform) transform_point(st->pose, x, y, z, px, py, pz);
-    }
-    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
-    const int BIG = 0x3fffffff;
-    const int mnx = wave_min_i(valid ? cx : BIG), mny = wave_min_i(valid ? cy : BIG), mnz = wave_min_i(valid ? cz : BIG);
-    const int mxx = wave_max_i(valid ? cx : -BIG), mxy = wave_max_i(valid ? cy : -BIG),
-              mxz = wave_max_i(valid ? cz : -BIG);
-    const bool any_valid = mnx != BIG;
-    const long long X = (long long)mxx - mnx + 3, Y = (long long)mxy - mny + 3, Z = (long long)mxz - mnz + 3;
-    const bool tiled = any_valid && X <= WS_CELLS && Y <= WS_CELLS && Z <= WS_CELLS && X * Y * Z <= WS_CELLS;
-    if (lane == 0) {
-        cursor[w] = 0;
-        overflow[w] = 0;
-    }
-    __syncthreads();
-    const int iX = (int)X, iY = (int)Y;
-    if (tiled) {
-        const int ncells = (int)(X * Y * Z);
-        for (int c = lane; c < ncells; c += 64) {
-            const int ix = c % iX, iy = (c / iX) % iY, iz = c / (iX * iY);
-            int start, count;
-            unsigned packed = 0;
-            int gs = 0;
-            if (grid_lookup(g, mnx - 1 + ix, mny - 1 + iy, mnz - 1 + iz, start, count)) {
-                const int off = atomicAdd(&cursor[w], count);
-                if (off + count <= WS_POINTS) {
-                    packed = ((unsigned)off << 16) | (unsigned)count;
-                    gs = start;
-                    for (int k = 0; k < count; ++k) T.pts[off + k] = g.pts[start + k];
-                } else {
-                    overflow[w] = 1;
-                }
-            }
-            T.seg[c] = packed;
-            T.gstart[c] = gs;
-        }
-    }
-    __syncthreads();
-    if (!valid) {
-        if (i < n) nn_pos[i] = -1;
-        return;
-    }
-    Best b;
-    b.d2 = INFINITY;
-    b.idx = 0x7fffffff;
-    b.pos = -1;
-    b.second = 0.f;
-    bool resolved = false;
-    if (tiled && !overflow[w]) {
-        const float h = g.h;
-        const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
-        const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
-        const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
-        const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-        const int lx = cx - (mnx - 1), ly = cy - (mny - 1), lz = cz - (mnz - 1);
-        const int c0 = (lz * iY + ly) * iX + lx;
-        unsigned packed = T.seg[c0];
-        if (packed) scan_tile_cell(T, packed, T.gstart[c0], px, py, pz, b);
-#pragma unroll
-        for (int oz = -1; oz <= 1; ++oz) {
-            const float gz = axis_gap(oz, fz, h);
-            const float gz2 = gz * gz;
-            if (gz2 > b.d2) continue;
-#pragma unroll
-            for (int oy = -1; oy <= 1; ++oy) {
-                const float gy = axis_gap(oy, fy, h);
-                const float gyz2 = fmaf(gy, gy, gz2);
-                if (gyz2 > b.d2) continue;
-#pragma unroll
-                for (int ox = -1; ox <= 1; ++ox) {
-                    if (ox == 0 && oy == 0 && oz == 0) continue;
-                    const float gx = axis_gap(ox, fx, h);
-                    if (fmaf(gx, gx, gyz2) > b.d2) continue;
-                    const int c = c0 + (oz * iY + oy) * iX + ox;
-                    packed = T.seg[c];
-                    if (packed) scan_tile_cell(T, packed, T.gstart[c], px, py, pz, b);
-                }
-            }
-        }
-        const float bound = h + edge;
-        resolved = b.d2 <= bound * bound * 0.999999f;
-    }
-    if (!resolved) b = nearest_in_grid(g, px, py, pz, max_rings);
-    nn_pos[i] = b.pos;
-    if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
-        if (atomicCAS(&nflag[b.pos], 0, 2) == 0) worklist[atomicAdd(&st->n_worklist, 1)] = b.pos;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K1 (rows, 4 lanes per query) — the default.
-//
-// What the hardware counters said about `k_search` (tools/pmc_probe.sh): L1 hit rate > 90 %, HBM traffic = the
-// compulsory bytes, yet 160 dependent load instructions and ~3000 VALU instructions per wave: the 27-cell loop runs
-// once per cell for the union of the lanes, each pass = hash + dependent probe + dependent candidate rounds.  So:
+// What the hardware counters said about a one-lane-per-query ring search (round 1, tools/pmc_probe.sh): L1 hit rate
+// > 90 %, HBM traffic = the compulsory bytes, yet 160 dependent load instructions and ~3000 VALU instructions per wave:
+// the 27-cell loop runs once per cell for the union of the lanes, each pass = hash + dependent probe + dependent
+// candidate rounds.  So:
 //   * one hash probe per query (its own cell); the 27 neighbour (start, count) pairs come from the cell's ROW
 //     (contiguous, loaded in one round, no hashing);
 //   * FOUR lanes per query: own-cell candidates strided over the lanes, the 26 neighbours split 7/6/7/6, two
 //     shuffle min-reductions.  4x the waves in flight (32 per CU instead of 8) and a 4x shorter dependent chain.
 // A query whose own cell is empty (no row) splits the 26 hashed probes over its 4 lanes instead.  Anything not provably
-// exact after ring 1 goes to the per-lane ring search, so results equal `k_search` bit for bit.
+// exact after ring 1 continues with rings 2.. / the coarse level / the exhaustive scan, split over the same 4 lanes.
 // ---------------------------------------------------------------------------------------------------------------------
 // e-th (0..47) shell cell of the three middle z-slabs of the 5x5x5 block: each slab contributes its 16 border cells
 __device__ inline int shell_mid(int e) {
@@ -449,6 +268,28 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 static constexpr int IT_THREADS = 512;            // 128 queries x 4 lanes per block -> N/128 partial rows
 static constexpr int IT_QUERIES = IT_THREADS / 4;
 
+// per-block partial normal equations from the 9-float rows of the block's queries: 4 x 30 threads, element e of quarter
+// `qtr` of the queries, f64, fixed order (bit-reproducible); one partial row per block
+__device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials) {
+    if (threadIdx.x < 4 * NEQ) {
+        const int e = threadIdx.x & (NEQ - 1), qtr = threadIdx.x / NEQ;
+        double acc = 0.0;
+        if (e < NEQ_USED) {
+            int a, b2;
+            neq_operands(e, a, b2);
+            const int j0 = qtr * (IT_QUERIES / 4);
+#pragma unroll 8
+            for (int j = 0; j < IT_QUERIES / 4; ++j) acc += (double)rowbuf[j0 + j][a] * (double)rowbuf[j0 + j][b2];
+        }
+        part[qtr][e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < NEQ)
+        partials[(size_t)blockIdx.x * NEQ + threadIdx.x] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+
 __global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const float4* __restrict__ tgt, int n,
                                                              int mode, RegState* __restrict__ st, int max_rings,
                                                              const float4* __restrict__ normals, AlignParams ap,
@@ -522,23 +363,147 @@ __global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const f
         for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
     }
     __syncthreads();
-    // 4 x 30 threads: element e of quarter `qtr` of the block's queries, fixed order
-    if (threadIdx.x < 4 * NEQ) {
-        const int e = threadIdx.x & (NEQ - 1), qtr = threadIdx.x / NEQ;
-        double acc = 0.0;
-        if (e < NEQ_USED) {
-            int a, b2;
-            neq_operands(e, a, b2);
-            const int j0 = qtr * (IT_QUERIES / 4);
-#pragma unroll 8
-            for (int j = 0; j < IT_QUERIES / 4; ++j) acc += (double)rowbuf[j0 + j][a] * (double)rowbuf[j0 + j][b2];
+    block_reduce_rows(rowbuf, part, partials);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused iteration kernel with in-block compaction of the cache misses — the default.
+//
+// From the third iteration on most queries keep their neighbour (exact NN cache, above), but a wave holds 16 queries
+// and runs the whole search path as soon as ONE of them misses: with a few per cent of misses nearly every wave still
+// paid for a search.  Here the block works in two phases:
+//   A. one lane per query (2 of the 8 waves): transform, cache test; a hit forms its row at once (map point and normal
+//      are fetched together, speculatively, behind the cache entry); a miss is appended to a list in LDS;
+//   B. the 4-lane groups of the whole block take the list entries in order: only ceil(misses / 16) waves search, the
+//      others go straight to the reduction.
+// The list order is not deterministic, the result is: every row lands in the slot of its query.
+// First iteration of a frame: no cache yet, but `frame_seed` (optional) names, per scan slot, the map point that was the
+// neighbour of the same slot at the end of the PREVIOUS frame (original map index, shifted by the points evicted
+// since) — a candidate that starts the search with a tight bound; like any seed it cannot change the minimum.
+// ---------------------------------------------------------------------------------------------------------------------
+struct IterInputs {
+    const float4* tgt;       // targets (x, y, z, row)
+    const float4* normals;   // by cell-sorted position
+    int2* nn_cache;          // (position, bits(L)) per query
+    const int* frame_seed;   // original map index per query or nullptr
+    double* partials;
+    int n, mode, max_rings, use_cache;
+};
+
+// MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
+// 131 072-point scan) resident in one round at 64 VGPRs (a few spilled dwords), 1 lets the compiler take what it wants
+// (66-72 VGPRs, 3 blocks per CU, a quarter of the blocks in a second round)
+template <int MINW>
+__global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
+                                                                      RegState* __restrict__ st, AlignParams ap) {
+    __shared__ float rowbuf[IT_QUERIES][9];
+    __shared__ double part[4][NEQ];
+    __shared__ int2 cellstack[7][IT_THREADS];
+    __shared__ float4 miss_p[IT_QUERIES];   // transformed target + bits(query slot)
+    __shared__ int4 miss_seed[IT_QUERIES];  // bits(seed d2), seed index, seed position
+    __shared__ int nmiss;
+    if (st->done) return;  // block-uniform
+    if (threadIdx.x == 0) nmiss = 0;
+    __syncthreads();
+    const int q0 = blockIdx.x * IT_QUERIES;
+    // ---- phase A: one lane per query
+    if (threadIdx.x < IT_QUERIES) {
+        const int lq = threadIdx.x, qi = q0 + lq;
+        float row[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) row[k] = 0.f;
+        bool valid = qi < in.n;
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            t4 = in.tgt[qi];
+            valid = target_valid(t4.x, t4.y, t4.z, in.mode);
+            if (!valid && !in.use_cache) in.nn_cache[qi] = make_int2(-1, 0);  // masked row: no neighbour, no seed
         }
-        part[qtr][e] = acc;
+        if (valid) {
+            float px, py, pz;
+            transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
+            bool hit = false;
+            float seed_d2 = INFINITY;
+            int seed_idx = 0x7fffffff, seed_pos = -1;
+            if (in.use_cache) {
+                const int2 c = in.nn_cache[qi];
+                if (c.x >= 0) {
+                    const float4 q = g.pts[c.x];
+                    const float4 nn = in.normals[c.x];  // speculative: needed on a hit only
+                    float ox, oy, oz;
+                    transform_point(st->pose_prev, t4.x, t4.y, t4.z, ox, oy, oz);
+                    const float mx = px - ox, my = py - oy, mz = pz - oz;
+                    const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                    const float L = __int_as_float(c.y) - delta;
+                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    hit = sqrtf(d2) * 1.000001f < L;
+                    if (hit) {
+                        in.nn_cache[qi] = make_int2(c.x, __float_as_int(L));
+                        point_to_plane_row(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+                    } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
+                        seed_d2 = d2;
+                        seed_idx = __float_as_int(q.w);
+                        seed_pos = c.x;
+                    }
+                }
+            } else if (in.frame_seed) {
+                const int o = in.frame_seed[qi];
+                if (o >= 0 && o < g.m) {
+                    const int sp = g.pos_of_orig[o];
+                    const float4 q = g.pts[sp];
+                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+                    seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    seed_idx = o;
+                    seed_pos = sp;
+                }
+            }
+            if (!hit) {
+                const int k = atomicAdd(&nmiss, 1);
+                miss_p[k] = make_float4(px, py, pz, __int_as_float(lq));
+                miss_seed[k] = make_int4(__float_as_int(seed_d2), seed_idx, seed_pos, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
     }
     __syncthreads();
-    if (threadIdx.x < NEQ)
-        partials[(size_t)blockIdx.x * NEQ + threadIdx.x] =
-            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    // ---- phase B: the misses, 4 lanes each, dense over the block's groups
+    {
+        const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
+        if (grp < nmiss) {  // group-uniform
+            const float4 mp = miss_p[grp];
+            const int4 ms = miss_seed[grp];
+            const Best b = search_rows_group(g, mp.x, mp.y, mp.z, sub, in.max_rings, &cellstack[0][threadIdx.x],
+                                             IT_THREADS, __int_as_float(ms.x), ms.y, ms.z);
+            if (sub == 0) {
+                const int lq = __float_as_int(mp.w);
+                in.nn_cache[q0 + lq] = make_int2(b.pos, __float_as_int(sqrtf(b.second) * 0.999999f));
+                if (b.pos >= 0) {
+                    const float4 q = g.pts[b.pos];
+                    const float4 nn = in.normals[b.pos];
+                    float row[9];
+                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    block_reduce_rows(rowbuf, part, in.partials);
+}
+
+// nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
+// coming map update drops (runs right before the grid is rebuilt, while the positions still mean something)
+__global__ void k_cache_to_seed(const int2* __restrict__ nn_cache, const float4* __restrict__ pts, int n, int m,
+                                int evicted, int* __restrict__ seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int pos = nn_cache[i].x;
+    int o = -1;
+    if (pos >= 0 && pos < m) o = __float_as_int(pts[pos].w) - evicted;
+    seed[i] = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -791,15 +756,17 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
     return false;
 }
 
-// Neighbourhood covariance of one map point by NL (4 or 2) lanes (lane 0 of the group writes cov[6]); the eigen-solve that turns
-// it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  A map point always lies in an occupied cell, so its 27-neighbourhood comes
+// Neighbourhood covariance of one map point by NL (4 or 2) lanes (lane 0 of the group writes cov[6]); the eigen-solve
+// that turns it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  Returns true
+// (group-uniform) when cov was written; with_fallback = false stops after ring 1 and returns false for a point whose
+// k-th neighbour is not provably inside it.  A map point always lies in an occupied cell, so its 27-neighbourhood comes
 // from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
 // neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
 // pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
 // level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
 template <int KN, int NL>
-__device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
-                                    int2* __restrict__ stack, int stride) {
+__device__ inline bool estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
+                                    int2* __restrict__ stack, int stride, bool with_fallback = true) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     TopK<KN> t;
@@ -856,7 +823,8 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
     merge_group<KN, NL>(t, m);
     const float bound1 = h + edge;
     bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
-    if (!exact && !(g_debug_flags & 4)) {
+    if (!exact && !with_fallback) return false;  // first pass of the eager schedule: the point is queued instead
+    if (!exact) {
         // fine rings 2..max_rings, then the coarse level, each ring split over the 4 lanes
         exact = max_rings >= 2 && coop_knn_rings<KN, NL>(g, px, py, pz, sub, 2, max_rings, m);
         if (!exact && g.ctable) {
@@ -868,8 +836,8 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
             scan_cell_knn<KN>(g, 0, g.m, px, py, pz, m);
         }
     }
-    if (sub != 0) return;
-    neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+    if (sub == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+    return true;
 }
 
 // merge of the NL lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
@@ -898,16 +866,19 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 // with one lane in NL active.
 static constexpr int NRM_THREADS = 256;
 
-// lazy: the map points queued by the search of this iteration
+// the map points of a worklist: those queued by the search of this iteration (lazy schedule; `st` given: the launch is
+// a no-op once the registration is done, and the count feeds `normals_computed`) or those the first pass of the eager
+// schedule could not settle inside ring 1 (`st` = nullptr)
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
+                                                         const int* __restrict__ count_ptr,
                                                          const int* __restrict__ worklist, int max_rings,
                                                          float4* __restrict__ normals, int* __restrict__ nflag) {
     constexpr int PTS = NRM_THREADS / NL;
-    if (st->done) return;
+    if (st && st->done) return;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
-    const int nw = st->n_worklist;
+    const int nw = *count_ptr;
     const int sub = threadIdx.x % NL, lq = threadIdx.x / NL;
     for (int base = blockIdx.x * PTS; base < nw; base += gridDim.x * PTS) {  // block-uniform trip count
         const int w = base + lq;
@@ -918,11 +889,12 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
             normal_from_cov(covs[threadIdx.x], worklist[base + threadIdx.x], normals, nflag);
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
+    if (st && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
 }
 
-// eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values
-// are the same either way: a normal depends on the map only)
+// eager, single pass: every map point with its fallback inline (round 1's schedule, kept for A/B: option
+// "normals_two_pass" = 0)
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
@@ -936,6 +908,33 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max
     __syncthreads();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+}
+
+// eager, first of two passes (chosen when the map is not much larger than the scan; the values are the same under
+// every schedule: a normal depends on the map only): every map point searches ring 1 only.  Where the k-th neighbour
+// is provably inside it the normal is finished here; the other points — whose hashed ring-2 / coarse-level search made
+// every wave of the single-pass kernel wait for its slowest group — are queued and handled DENSELY by `k_normals`.
+template <int KN, int NL>
+__global__ __launch_bounds__(NRM_THREADS) void k_normals_ring1(GridView g, int max_rings, float4* __restrict__ normals,
+                                                               int* __restrict__ nflag, int* __restrict__ worklist,
+                                                               int* __restrict__ count) {
+    constexpr int PTS = NRM_THREADS / NL;
+    __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
+    __shared__ float covs[PTS][7];
+    __shared__ int settled[PTS];
+    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
+    const int s = blockIdx.x * PTS + lq;
+    if (s < g.m) {
+        const bool ok = estimate_cov<KN, NL>(g, s, sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS,
+                                             false);
+        if (sub == 0) {
+            settled[lq] = ok ? 1 : 0;
+            if (!ok) worklist[atomicAdd(count, 1)] = s;
+        }
+    }
+    __syncthreads();
+    const int s2 = blockIdx.x * PTS + threadIdx.x;
+    if (threadIdx.x < PTS && s2 < g.m && settled[threadIdx.x]) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -1045,35 +1044,64 @@ static GridView make_view(icp_ctx* ctx) {
     return g;
 }
 
+static void launch_search_rows(icp_ctx* ctx, int n, int mode, int transform) {
+    hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       make_view(ctx), ctx->tgt4.as<float4>(), n, mode, transform, reg_state(ctx), ctx->cfg.max_rings,
+                       ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
+                       ctx->normals_ready ? 0 : 1);
+}
+
 int launch_search(icp_ctx* ctx) {
     const int n = (int)ctx->tgt_n;
     if (n <= 0) return ICP_OK;
     const int tok = prof_begin(ctx, 0);
-    if (ctx->search_variant == 0)
-        hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
-                           ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                           ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
-    else if (ctx->search_variant == 1)
-        hipLaunchKernelGGL(k_search_tiled, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx),
-                           ctx->tgt4.as<float4>(), n, ctx->tgt_mode, 1, reg_state(ctx), ctx->cfg.max_rings,
-                           ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
-                           ctx->normals_ready ? 0 : 1);
-    else
-        hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           make_view(ctx), ctx->tgt4.as<float4>(), n, ctx->tgt_mode, 1, reg_state(ctx),
-                           ctx->cfg.max_rings, ctx->nn_pos.as<int>(), ctx->nflag.as<int>(),
-                           ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
+    launch_search_rows(ctx, n, ctx->tgt_mode, 1);
     prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// search without pose transform (LocalMap.nearest_neighbor_search seam): the state must have done = 0
+int launch_search_raw(icp_ctx* ctx) {
+    const int n = (int)ctx->tgt_n;
+    if (n <= 0) return ICP_OK;
+    launch_search_rows(ctx, n, ICP_TARGETS_ALL, 0);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
 // fine rings tried by the kNN before it moves to the coarse level: ring 3 means 218 hashed probes for a handful of extra
 // candidates, the coarse level reaches the same points through a few 4x larger cells (measured: 233 -> 199 us per
-// 100k-point map with 2 instead of 3).  env ICP_KNN_RINGS (read in icp_create) overrides.
+// 100k-point map with 2 instead of 3).  Option "knn_rings" overrides.
 static int knn_fine_rings(const icp_ctx* ctx) {
     if (ctx->knn_rings >= 0) return ctx->knn_rings;
     return ctx->cfg.max_rings < 2 ? ctx->cfg.max_rings : 2;
+}
+
+// the worklist kernel for the three compiled neighbourhood sizes
+template <int NL>
+static void launch_worklist_t(icp_ctx* ctx, int kn, const GridView& g, RegState* st, const int* count_ptr, int blocks) {
+    const int rings = knn_fine_rings(ctx);
+    const int* wl = ctx->worklist.as<int>();
+    float4* nrm = ctx->normals.as<float4>();
+    int* nf = ctx->nflag.as<int>();
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+                           rings, nrm, nf);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+                           rings, nrm, nf);
+    else
+        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+                           rings, nrm, nf);
+}
+
+static int worklist_blocks(int64_t cap, int nl) {
+    const int pts = NRM_THREADS / nl;
+    int64_t blocks = (cap + pts - 1) / pts;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    return (int)blocks;
 }
 
 template <int NL>
@@ -1082,22 +1110,32 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
+    if (!ctx->normals_two_pass) {
+        if (kn == 11)
+            hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        else if (kn == 6)
+            hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        else
+            hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        return;
+    }
+    // pass 1 settles what ring 1 can; the rest is queued behind grid_stats[3] (zeroed by every grid build) and handled
+    // densely by the worklist kernel
+    int* wl = ctx->worklist.as<int>();
+    int* count = ctx->grid_stats.as<int>() + 3;
     if (kn == 11)
-        hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_ring1<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
+                           wl, count);
     else if (kn == 6)
-        hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_ring1<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
+                           wl, count);
     else
-        hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_ring1<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
+                           wl, count);
+    launch_worklist_t<NL>(ctx, kn, g, nullptr, count, worklist_blocks(ctx->map_m, NL));
 }
 
 int launch_normals_all(icp_ctx* ctx) {
-    static std::once_flag dbg_once;  // dev-only ablation switches
-    std::call_once(dbg_once, [] {
-        if (const char* v = getenv("ICP_DEBUG_FLAGS")) {
-            int f = atoi(v);
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_flags), &f, sizeof(int));
-        }
-    });
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
@@ -1119,35 +1157,55 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     const int blocks = n > 0 ? (int)(((long long)n * 4 + IT_THREADS - 1) / IT_THREADS) : 1;
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
+    const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
     const int tok = prof_begin(ctx, 0);
-    hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
-                       ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings, ctx->normals.as<float4>(),
-                       make_align_params(ctx), ctx->partials.as<double>(), ctx->nn_cache.as<int2>(),
-                       (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0);
+    if (ctx->compact_misses) {
+        IterInputs in;
+        in.tgt = ctx->tgt4.as<float4>();
+        in.normals = ctx->normals.as<float4>();
+        in.nn_cache = ctx->nn_cache.as<int2>();
+        // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
+        in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
+                            ? ctx->seed_orig.as<int>() : nullptr;
+        in.partials = ctx->partials.as<double>();
+        in.n = n;
+        in.mode = ctx->tgt_mode;
+        in.max_rings = ctx->cfg.max_rings;
+        in.use_cache = use_cache;
+        if (ctx->iterate_dense)
+            hipLaunchKernelGGL(k_iterate_compact<8>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
+                               reg_state(ctx), make_align_params(ctx));
+        else
+            hipLaunchKernelGGL(k_iterate_compact<1>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
+                               reg_state(ctx), make_align_params(ctx));
+    } else {
+        hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx),
+                           ctx->tgt4.as<float4>(), n, ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings,
+                           ctx->normals.as<float4>(), make_align_params(ctx), ctx->partials.as<double>(),
+                           ctx->nn_cache.as<int2>(), use_cache);
+    }
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;
+    ctx->cache_n = n;  // nn_cache now describes these targets against the current grid
+    ctx->cache_m = ctx->map_m;
+    ctx->cache_gen = ctx->grid_gen;
     *blocks_out = blocks;
     return ICP_OK;
 }
 
-template <int NL>
-static void launch_normals_t(icp_ctx* ctx, int kn, const GridView& g, int64_t cap) {
-    constexpr int PTS = NRM_THREADS / NL;
-    int blocks = (int)((cap + PTS - 1) / PTS);
-    if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
-    const int rings = knn_fine_rings(ctx);
-    RegState* st = reg_state(ctx);
-    const int* wl = ctx->worklist.as<int>();
-    float4* nrm = ctx->normals.as<float4>();
-    int* nf = ctx->nflag.as<int>();
-    if (kn == 11)
-        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
-    else if (kn == 6)
-        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
-    else
-        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl, rings, nrm, nf);
+// Called by the grid build before it overwrites the cell-sorted points: the neighbours the last registration left in
+// nn_cache become the seeds of the next frame's first iteration.  `evicted` = oldest map points about to be dropped.
+int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive) {
+    ctx->seed_n = 0;
+    if (!indices_survive || !ctx->frame_seed || ctx->cache_n <= 0 || ctx->cache_gen != ctx->grid_gen) return ICP_OK;
+    const int n = (int)ctx->cache_n;
+    ICP_HIP(ctx, ctx->seed_orig.reserve((size_t)n * sizeof(int)));
+    hipLaunchKernelGGL(k_cache_to_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nn_cache.as<int2>(),
+                       ctx->sorted_pts.as<float4>(), n, (int)ctx->cache_m, (int)evicted, ctx->seed_orig.as<int>());
+    ICP_HIP(ctx, hipGetLastError());
+    ctx->seed_n = n;
+    return ICP_OK;
 }
 
 int launch_normals(icp_ctx* ctx) {
@@ -1157,41 +1215,20 @@ int launch_normals(icp_ctx* ctx) {
     const int64_t cap = ctx->tgt_n < ctx->map_m ? ctx->tgt_n : ctx->map_m;
     const int tok = prof_begin(ctx, 2);
     GridView g = make_view(ctx);
+    RegState* st = reg_state(ctx);
     if (kn == 11 || kn == 6 || kn == 21) {
         if (ctx->knn_lanes == 2)
-            launch_normals_t<2>(ctx, kn, g, cap);
+            launch_worklist_t<2>(ctx, kn, g, st, &st->n_worklist, worklist_blocks(cap, 2));
         else
-            launch_normals_t<4>(ctx, kn, g, cap);
+            launch_worklist_t<4>(ctx, kn, g, st, &st->n_worklist, worklist_blocks(cap, 4));
     } else {
         int blocks = (int)((cap + 127) / 128);
         if (blocks < 1) blocks = 1;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_normals_generic, dim3(blocks), dim3(128), 0, ctx->stream, g, reg_state(ctx),
+        hipLaunchKernelGGL(k_normals_generic, dim3(blocks), dim3(128), 0, ctx->stream, g, st,
                            ctx->worklist.as<int>(), kn, ctx->normals.as<float4>(), ctx->nflag.as<int>());
     }
     prof_end(ctx, tok);
-    ICP_HIP(ctx, hipGetLastError());
-    return ICP_OK;
-}
-
-// search without pose transform (LocalMap.nearest_neighbor_search API): state must have done = 0
-int launch_search_raw(icp_ctx* ctx) {
-    const int n = (int)ctx->tgt_n;
-    if (n <= 0) return ICP_OK;
-    if (ctx->search_variant == 0)
-        hipLaunchKernelGGL(k_search, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx), ctx->tgt4.as<float4>(), n,
-                           ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings, ctx->nn_pos.as<int>(),
-                           ctx->nflag.as<int>(), ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
-    else if (ctx->search_variant == 1)
-        hipLaunchKernelGGL(k_search_tiled, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, make_view(ctx),
-                           ctx->tgt4.as<float4>(), n, ICP_TARGETS_ALL, 0, reg_state(ctx), ctx->cfg.max_rings,
-                           ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
-                           ctx->normals_ready ? 0 : 1);
-    else
-        hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           make_view(ctx), ctx->tgt4.as<float4>(), n, ICP_TARGETS_ALL, 0, reg_state(ctx),
-                           ctx->cfg.max_rings, ctx->nn_pos.as<int>(), ctx->nflag.as<int>(),
-                           ctx->worklist.as<int>(), ctx->normals_ready ? 0 : 1);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

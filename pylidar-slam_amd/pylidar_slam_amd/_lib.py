@@ -65,6 +65,7 @@ EXPORTED_SYMBOLS = {
     "icp_version": (C.c_char_p, []),
     "icp_set_stream": (_INT, [_P, _P]),
     "icp_synchronize": (_INT, [_P]),
+    "icp_set_option": (_INT, [_P, C.c_char_p, C.c_double]),
     "icp_set_alignment": (_INT, [_P, C.c_int32, C.c_float, C.c_int32, C.c_float]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_project_pixels": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),

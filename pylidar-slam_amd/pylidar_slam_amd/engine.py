@@ -109,6 +109,10 @@ class IcpContext:
     def synchronize(self):
         self._check(self._lib.icp_synchronize(self._h))
 
+    def set_option(self, name: str, value: float):
+        """MI355X-side tuning option (see `icp_set_option` in include/icp_mi355x.h); never changes a result."""
+        self._check(self._lib.icp_set_option(self._h, name.encode(), float(value)))
+
     def set_alignment(self, scheme: str, sigma: float, max_num_alignments: int, threshold_delta_pose: float):
         self._check(self._lib.icp_set_alignment(self._h, SCHEMES[scheme], float(sigma), int(max_num_alignments),
                                                 float(threshold_delta_pose)))

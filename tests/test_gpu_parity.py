@@ -301,32 +301,52 @@ def test_fresh_context_after_a_large_one_reads_no_stale_memory(torch_cuda, O, go
     assert ctx.register(g["nn_queries"]).iterations == 3
 
 
-def test_nn_cache_and_kernel_variants_are_bit_identical(torch_cuda, monkeypatch):
-    """The per-iteration NN cache (skip the search when the cached neighbour is provably still the nearest), the fused
-    search+rows kernel and the alternative search kernels are pure schedule changes: same poses and losses, bit for bit
-    where the reduction order is shared, to 1e-12 relative otherwise."""
+def test_schedule_options_are_bit_identical(torch_cuda):
+    """The tuning options of `icp_set_option` are pure schedule changes: the per-iteration NN cache (skip the search
+    when the cached neighbour is provably still the nearest), the in-block compaction of its misses, the 64-register
+    build, the cross-frame seeds and the two-pass normal schedule give the same poses, losses and maps bit for bit;
+    the unfused path shares everything but the reduction order (1e-6 relative)."""
     from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
     cfg = SceneConfig(height=32, width=1024)
-    scans, poses = make_sequence(cfg, 5)
+    scans, poses = make_sequence(cfg, 7)
     model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    variants = {"default": {}, "nocache": {"nn_cache": 0}, "cache_noseed": {"nn_cache": 1},
+                "rows_kernel": {"compact_misses": 0}, "sparse_build": {"iterate_dense": 0},
+                "no_frame_seed": {"frame_seed": 0}, "one_pass_normals": {"normals_two_pass": 0},
+                "lanes2": {"knn_lanes": 2}, "unfused": {"fuse_iteration": 0}}
     results = {}
-    for name, env in (("default", {}), ("nocache", {"ICP_NN_CACHE": "0"}), ("unfused", {"ICP_FUSE_ITERATION": "0"}),
-                      ("perlane", {"ICP_SEARCH_VARIANT": "0"}), ("tiles", {"ICP_SEARCH_VARIANT": "1"}),
-                      ("sorted", {"ICP_SORT_TARGETS": "1"})):
-        for k in ("ICP_NN_CACHE", "ICP_FUSE_ITERATION", "ICP_SEARCH_VARIANT", "ICP_SORT_TARGETS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for name, opts in variants.items():
         ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure",
                    sigma=0.3)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
         ctx.map_set(model)
-        results[name] = ctx.register(scans[4])
+        frames, init = [], None
+        for f in (4, 5, 6):  # three consecutive frames: the second and third start from the first's neighbours
+            ctx.register_launch(scans[f], init)
+            ctx.map_update(None, None)
+            r = ctx.register_end()
+            frames.append(r)
+            init = r.pose
+        _, nrm, _ = ctx.nearest_neighbor_search(scans[6][::7])
+        results[name] = (frames, ctx.map_points(), nrm)
         ctx.close()
-    ref = results["default"]
-    assert np.array_equal(results["nocache"].pose, ref.pose) and np.array_equal(results["nocache"].losses, ref.losses)
-    for name in ("unfused", "perlane", "tiles", "sorted"):
-        np.testing.assert_allclose(results[name].pose, ref.pose, atol=2e-7)
-        np.testing.assert_allclose(results[name].losses, ref.losses, rtol=1e-6)
+    with pytest.raises(AssertionError):
+        c = _ctx()
+        c.set_option("no_such_option", 1)
+    ref_frames, ref_map, ref_nrm = results["default"]
+    for name, (frames, mp, nrm) in results.items():
+        for r, ref in zip(frames, ref_frames):
+            assert r.iterations == ref.iterations == 12
+            if name == "unfused":
+                np.testing.assert_allclose(r.pose, ref.pose, atol=2e-7)
+                np.testing.assert_allclose(r.losses, ref.losses, rtol=1e-6)
+            else:
+                assert np.array_equal(r.pose, ref.pose), name
+                assert np.array_equal(r.losses, ref.losses) and np.array_equal(r.dx, ref.dx), name
+        if name != "unfused":
+            assert np.array_equal(mp, ref_map), name
+            assert np.array_equal(nrm, ref_nrm), name
 
 
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
