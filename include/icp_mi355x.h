@@ -100,11 +100,9 @@ int icp_synchronize(icp_ctx* ctx);
 /* MI355X-side tuning options by name (no reference counterpart; none of them changes a result, only the schedule):
  *   "nn_cache" 0 | 1 | 2 (2)        exact nearest-neighbour cache across ICP iterations (2: a missed entry seeds the search)
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
- *   "compact_misses" 0 | 1 (1)      that kernel with the cache misses of a block compacted before the search
- *   "iterate_dense" 0 | 1 (1)       its 64-register build (the whole scan resident in one round of workgroups)
+ *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
- *   "normals_two_pass" 0 | 1 (1)    eager normals as a ring-1 pass over the map + a dense pass over the unsettled points
- *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (5), "search_stats" 0 | 1 (0)
+ *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 (0)
  * The library reads no environment variables. */
 int icp_set_option(icp_ctx* ctx, const char* name, double value);
 /* runtime re-configuration of the alignment (RIGID_ALIGNMENT.load, slam/odometry/alignment.py:200-208) */

@@ -177,6 +177,8 @@ __global__ void k_vmap_points(const float* __restrict__ vmap, int npix, float th
 
 }  // namespace icp
 
+static constexpr size_t DBG_BYTES = 64 + 24 * 1024 * 4 * sizeof(long long);  // dev statistics ("search_stats")
+
 // ---- helpers --------------------------------------------------------------------------------------------------------
 // Every entry point runs on the context's device and leaves the calling thread's current device as it found it (a
 // process may hold contexts on several GPUs, and torch shares the thread's current device with us).
@@ -358,18 +360,16 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     const int iv = (int)value;
     if (k == "nn_cache") ctx->use_nn_cache = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
-    else if (k == "compact_misses") ctx->compact_misses = iv != 0;
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
-    else if (k == "normals_two_pass") ctx->normals_two_pass = iv != 0;
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
-    else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 5.0;
+    else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
         ctx->search_stats = iv != 0;
-        if (ctx->search_stats) {
-            ICP_HIP(ctx, ctx->dbg_counts.reserve(64));
-            ICP_HIP(ctx, hipMemsetAsync(ctx->dbg_counts.ptr, 0, 64, ctx->stream));
+        if (ctx->search_stats) {  // 16 path counters + 4 phase timestamps per workgroup and iteration
+            ICP_HIP(ctx, ctx->dbg_counts.reserve(DBG_BYTES));
+            ICP_HIP(ctx, hipMemsetAsync(ctx->dbg_counts.ptr, 0, DBG_BYTES, ctx->stream));
         }
     } else {
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "unknown option");
@@ -1206,11 +1206,33 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         ctx->stats_at_launch = false;
     }
     if (ctx->search_stats) {
-        int c[8];
-        if (hipMemcpy(c, ctx->dbg_counts.ptr, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "[icp stats] N=%lld M=%lld h=%.3f iters=%d ring1=%d need_ring2=%d need_ring3=%d fine_failed=%d exhaustive=%d own_empty=%d\n",
-                    (long long)ctx->tgt_n, (long long)ctx->map_m, ctx->cell_h, st.iter, c[0], c[1], c[2], c[3], c[4], c[5]);
-            (void)hipMemset(ctx->dbg_counts.ptr, 0, 64);
+        std::vector<char> raw(DBG_BYTES);
+        if (hipMemcpy(raw.data(), ctx->dbg_counts.ptr, DBG_BYTES, hipMemcpyDeviceToHost) == hipSuccess) {
+            const int* c = (const int*)raw.data();
+            fprintf(stderr, "[icp stats] N=%lld M=%lld h=%.3f iters=%d ring1=%d need_ring2=%d need_ring3=%d fine_failed=%d exhaustive=%d own_empty=%d misses=%d by-iteration(0-2,3-5,..)=%d,%d,%d,%d,%d,%d,%d\n",
+                    (long long)ctx->tgt_n, (long long)ctx->map_m, ctx->cell_h, st.iter, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
+            // phase timestamps per iteration launch (100 MHz wall clock -> us)
+            const long long* tall = (const long long*)(c + 16);
+            const int nb = (int)((ctx->tgt_n * 4 + 511) / 512);
+            for (int it = 0; it < st.iter && it < 24 && nb > 0 && nb <= 1024; ++it) {
+                const long long* t = tall + 4 * (size_t)it * 1024;
+                if (t[0] == 0) continue;
+                long long first = t[0], last_start = t[0], last_end = t[3];
+                double a = 0, b = 0, r = 0, amax = 0, bmax = 0;
+                for (int i = 0; i < nb; ++i) {
+                    const long long* q = t + 4 * i;
+                    if (q[0] < first) first = q[0];
+                    if (q[0] > last_start) last_start = q[0];
+                    if (q[3] > last_end) last_end = q[3];
+                    const double da = (q[1] - q[0]) * 0.01, db = (q[2] - q[1]) * 0.01, dr = (q[3] - q[2]) * 0.01;
+                    a += da; b += db; r += dr;
+                    if (da > amax) amax = da;
+                    if (db > bmax) bmax = db;
+                }
+                fprintf(stderr, "[icp phases] it %2d: blocks=%d start skew %.2f us, span %.2f us; phase A mean %.2f max %.2f, phase B mean %.2f max %.2f, reduce mean %.2f us\n",
+                        it, nb, (last_start - first) * 0.01, (last_end - first) * 0.01, a / nb, amax, b / nb, bmax, r / nb);
+            }
+            (void)hipMemset(ctx->dbg_counts.ptr, 0, DBG_BYTES);
         }
     }
     st.normals_computed += ctx->normals_eager_count;

@@ -5,7 +5,9 @@
 namespace icp {
 
 __device__ inline float robust_weight(int scheme, float sigma, float r, float dist2_pq) {
-    // slam/common/optimization.py:45-50 with the per-scheme cost(); least_square short-circuits to 1 (:70-72)
+    // slam/common/optimization.py:45-50 with the per-scheme cost(); least_square short-circuits to 1 (:70-72).
+    // Evaluated operation by operation like the reference (sigma + r * r is a rounded product then a rounded sum): the
+    // library is built with -ffp-contract=off, so every kernel that inlines this forms the same weight bit for bit.
     if (scheme == ICP_SCHEME_LEAST_SQUARE) return 1.0f;
     const float a = fabsf(r);
     float cost;

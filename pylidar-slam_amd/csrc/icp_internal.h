@@ -149,7 +149,7 @@ struct icp_ctx {
     float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
     icp::DeviceBuffer grid_stats;      // int[4]: occupied cells of the last build
     int occupied_cells = 0;
-    double target_occupancy = 5.0;     // auto-tuning target, map points per occupied cell (option "target_occupancy")
+    double target_occupancy = 10.0;    // auto-tuning target, map points per occupied cell (option "target_occupancy")
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
@@ -170,10 +170,8 @@ struct icp_ctx {
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
-    int compact_misses = 1;            // "compact_misses": fused kernel with in-block compaction of the cache misses
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
-    int normals_two_pass = 1;          // "normals_two_pass": eager normals as ring-1 pass + dense worklist pass
     int search_stats = 0;              // "search_stats": count which path resolved each query (dev)
     icp::DeviceBuffer dbg_counts;
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read

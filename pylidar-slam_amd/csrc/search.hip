@@ -47,7 +47,7 @@ __device__ inline void group_min4(Best& b) {
         const int idx = __shfl_xor(b.idx, o, 64);
         const int pos = __shfl_xor(b.pos, o, 64);
         float sec = fminf(b.second, __shfl_xor(b.second, o, 64));
-        if (pos != b.pos) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
+        if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
         if (better(d2, idx, b.d2, b.idx)) {
             b.d2 = d2;
             b.idx = idx;
@@ -90,14 +90,21 @@ __device__ inline bool coop_rings(const GridView& lv, float px, float py, float 
                 const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
                 if (m < r) continue;  // interior: visited by the previous rings
                 const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > b.d2) continue;
+                const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+                if (gap2 > b.d2) {
+                    b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
+                    continue;
+                }
                 if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
                     scan_cell_1nn(lv, start, count, px, py, pz, b);
             }
         }
         group_min4(b);
         const float bound = (float)r * h + edge;
-        if (b.d2 <= bound * bound * 0.999999f) return true;
+        if (b.d2 <= bound * bound * 0.999999f) {
+            b.second = fminf(b.second, bound * bound * 0.999999f);  // nothing outside the visited block is closer
+            return true;
+        }
     }
     return false;
 }
@@ -207,19 +214,19 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     }
     float bound = h + edge;
     bool resolved = b.d2 <= bound * bound * 0.999999f;  // group-uniform: b is shared after the reduction
-    // nothing outside the 27-cell block is closer than `bound`; beyond ring 1 the cache is simply not fed
-    b.second = resolved ? fminf(b.second, bound * bound * 0.999999f) : 0.f;
+    // nothing outside the 27-cell block is closer than `bound` (when that settles the search); otherwise b.second keeps
+    // bounding the OTHER points seen or pruned so far and the rings below extend it
+    if (resolved) b.second = fminf(b.second, bound * bound * 0.999999f);
     if (g.dbg && sub == 0) atomicAdd(&g.dbg[resolved ? 0 : 1], 1);
     if (g.dbg && sub == 0 && e.key != key) atomicAdd(&g.dbg[5], 1);
-    const bool ring1 = resolved;
     if (!resolved) {
         // rings 2..max_rings of the fine level, then the coarse level (4x cells), every ring split over the 4 lanes
         if (g.dbg && sub == 0) atomicAdd(&g.dbg[2], 1);
         resolved = max_rings >= 2 && coop_rings(g, px, py, pz, sub, 2, max_rings, b);
         if (!resolved && g.ctable) {
             if (g.dbg && sub == 0) atomicAdd(&g.dbg[3], 1);
-            // candidates of the coarse level carry positions of ITS point array: identify the winner by original index
-            b.pos = -2;  // the fine position must not alias a coarse one in the re-read test of `consider`
+            // candidates of the coarse level carry positions of ITS point array: the winner is identified by its original
+            // index (`consider` recognises the best so far by index, so meeting it again changes nothing)
             resolved = coop_rings(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b);
             if (b.idx != 0x7fffffff) b.pos = g.pos_of_orig[b.idx];
         }
@@ -228,10 +235,10 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             b.d2 = INFINITY;
             b.idx = 0x7fffffff;
             b.pos = -1;
-            scan_cell_1nn(g, 0, g.m, px, py, pz, b);
+            b.second = INFINITY;
+            scan_cell_1nn(g, 0, g.m, px, py, pz, b);  // every other point is seen: b.second = the second-nearest
         }
     }
-    if (!ring1) b.second = 0.f;  // only ring-1 results feed the NN cache
     return b;
 }
 
@@ -262,8 +269,8 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused iteration kernel (every needed normal is ready): the search above + the point-to-plane row of each query +
 // the per-block partial normal equations, in one launch — no nn_pos round trip, no second pass over the targets.
-// 64 queries per block: their 9-float rows go to LDS, then 30 threads each own one packed element and add up its 64
-// products in f64 in a fixed order (bit-reproducible), one partial row per block.
+// 128 queries per block: their 9-float rows go to LDS, then 4 x 30 threads each own one packed element of a quarter of
+// the queries and add up its products in f64 in a fixed order (bit-reproducible), one partial row per block.
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr int IT_THREADS = 512;            // 128 queries x 4 lanes per block -> N/128 partial rows
 static constexpr int IT_QUERIES = IT_THREADS / 4;
@@ -290,86 +297,14 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 }
 
 
-__global__ __launch_bounds__(IT_THREADS) void k_iterate_rows(GridView g, const float4* __restrict__ tgt, int n,
-                                                             int mode, RegState* __restrict__ st, int max_rings,
-                                                             const float4* __restrict__ normals, AlignParams ap,
-                                                             double* __restrict__ partials,
-                                                             int2* __restrict__ nn_cache, int use_cache) {
-    __shared__ float rowbuf[IT_QUERIES][9];
-    __shared__ double part[4][NEQ];
-    __shared__ int2 cellstack[7][IT_THREADS];
-    if (st->done) return;  // block-uniform
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int qi = gid >> 2, sub = gid & 3;
-    const int lq = threadIdx.x >> 2;  // query slot in the block
-    bool valid = qi < n;
-    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-        t4 = tgt[qi];
-        valid = target_valid(t4.x, t4.y, t4.z, mode);
-    }
-    float row[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) row[k] = 0.f;
-    if (valid) {  // group-uniform
-        float px, py, pz;
-        transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
-        // NN cache (exact): the previous search left, besides the neighbour, a lower bound L on the distance to EVERY
-        // OTHER map point.  The target moved by delta since, so every other point is still >= L - delta away: if the
-        // cached neighbour is strictly closer than that it is still THE nearest neighbour and the search is skipped.
-        int pos = -1;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool hit = false;
-        float seed_d2 = INFINITY;
-        int seed_idx = 0x7fffffff, seed_pos = -1;
-        if (use_cache) {
-            const int2 c = nn_cache[qi];
-            if (c.x >= 0) {
-                float ox, oy, oz;
-                transform_point(st->pose_prev, t4.x, t4.y, t4.z, ox, oy, oz);
-                const float mx = px - ox, my = py - oy, mz = pz - oz;
-                const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                const float L = __int_as_float(c.y) - delta;
-                q = g.pts[c.x];
-                const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-                const float d = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) * 1.000001f;
-                hit = d < L;
-                if (hit) {
-                    pos = c.x;
-                    if (sub == 0) nn_cache[qi] = make_int2(c.x, __float_as_int(L));
-                } else if (use_cache > 1) {  // not provably still the nearest, but a candidate: seed the search with it
-                    seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    seed_idx = __float_as_int(q.w);
-                    seed_pos = c.x;
-                }
-            }
-        }
-        if (!hit) {  // group-uniform: the 4 lanes read the same cache entry
-            const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], IT_THREADS,
-                                             seed_d2, seed_idx, seed_pos);
-            if (sub == 0) {
-                pos = b.pos;
-                if (pos >= 0) q = g.pts[pos];
-                if (nn_cache) nn_cache[qi] = make_int2(pos, __float_as_int(sqrtf(b.second) * 0.999999f));
-            }
-        }
-        if (sub == 0 && pos >= 0) {
-            const float4 nn = normals[pos];
-            point_to_plane_row(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-        }
-    }
-    if (sub == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
-    }
-    __syncthreads();
-    block_reduce_rows(rowbuf, part, partials);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Fused iteration kernel with in-block compaction of the cache misses — the default.
+// The kernel, with in-block compaction of the cache misses.
 //
-// From the third iteration on most queries keep their neighbour (exact NN cache, above), but a wave holds 16 queries
+// NN cache (exact): a search leaves, besides the neighbour, a lower bound L on the distance to EVERY OTHER map point
+// (second-best candidate, box distance of every pruned cell, the bound of the last ring).  The target moved by delta
+// since, so every other point is still >= L - delta away: if the cached neighbour is strictly closer than that it is
+// still THE nearest neighbour and the search is skipped.
+// From the third iteration on most queries keep their neighbour, but a wave holds 16 queries
 // and runs the whole search path as soon as ONE of them misses: with a few per cent of misses nearly every wave still
 // paid for a search.  Here the block works in two phases:
 //   A. one lane per query (2 of the 8 waves): transform, cache test; a hit forms its row at once (map point and normal
@@ -391,8 +326,8 @@ struct IterInputs {
 };
 
 // MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
-// 131 072-point scan) resident in one round at 64 VGPRs (a few spilled dwords), 1 lets the compiler take what it wants
-// (66-72 VGPRs, 3 blocks per CU, a quarter of the blocks in a second round)
+// 131 072-point scan) resident in one round at 64 VGPRs (some spilled dwords), 6 allows 80 VGPRs (3 blocks per CU, a
+// quarter of the blocks in a second round)
 template <int MINW>
 __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                       RegState* __restrict__ st, AlignParams ap) {
@@ -403,7 +338,15 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
     __shared__ int4 miss_seed[IT_QUERIES];  // bits(seed d2), seed index, seed position
     __shared__ int nmiss;
     if (st->done) return;  // block-uniform
-    if (threadIdx.x == 0) nmiss = 0;
+    // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
+    // counters
+    long long* stamps = nullptr;
+    if (g.dbg && gridDim.x <= 1024 && st->iter < 24)
+        stamps = reinterpret_cast<long long*>(g.dbg + 16) + 4 * ((size_t)st->iter * 1024 + blockIdx.x);
+    if (threadIdx.x == 0) {
+        nmiss = 0;
+        if (stamps) stamps[0] = wall_clock64();
+    }
     __syncthreads();
     const int q0 = blockIdx.x * IT_QUERIES;
     // ---- phase A: one lane per query
@@ -468,6 +411,11 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
         for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0) {
+        stamps[1] = wall_clock64();
+        atomicAdd(&g.dbg[6], nmiss);
+        atomicAdd(&g.dbg[8 + min(st->iter, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
+    }
     // ---- phase B: the misses, 4 lanes each, dense over the block's groups
     {
         const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
@@ -491,7 +439,9 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
         }
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     block_reduce_rows(rowbuf, part, in.partials);
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
 // nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
@@ -520,6 +470,11 @@ __device__ inline unsigned long long make_key(float d2, int idx) {
 __device__ inline float key_d2(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
 __device__ inline int key_idx(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
+__device__ inline unsigned long long point_key(const float4 q, float px, float py, float pz) {
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    return make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w));
+}
+
 template <int KN>
 struct TopK {
     unsigned long long key[KN];
@@ -544,10 +499,14 @@ struct TopK {
 template <int KN>
 __device__ inline void scan_cell_knn(const GridView& g, int start, int count, float px, float py, float pz,
                                      TopK<KN>& t) {
-    for (int k = 0; k < count; ++k) {
-        const float4 q = g.pts[start + k];
-        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-        t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
+    const int last = start + count - 1;
+    for (int k = start; k <= last; k += 4) {
+        const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+        const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+        t.insert(point_key(q0, px, py, pz));
+        if (k1 != k) t.insert(point_key(q1, px, py, pz));
+        if (k2 != k1) t.insert(point_key(q2, px, py, pz));
+        if (k3 != k2) t.insert(point_key(q3, px, py, pz));
     }
 }
 
@@ -757,16 +716,15 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
 }
 
 // Neighbourhood covariance of one map point by NL (4 or 2) lanes (lane 0 of the group writes cov[6]); the eigen-solve
-// that turns it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  Returns true
-// (group-uniform) when cov was written; with_fallback = false stops after ring 1 and returns false for a point whose
-// k-th neighbour is not provably inside it.  A map point always lies in an occupied cell, so its 27-neighbourhood comes
+// that turns it into a normal runs afterwards on dense waves, one lane per point (see k_normals_all).  A map point
+// always lies in an occupied cell, so its 27-neighbourhood comes
 // from the cell's row (no hashing).  Each lane keeps the top-k of its share of the candidates (own cell strided,
 // neighbour cells split 7/6/7/6), then the four sorted lists are merged by k rounds of "group-min of the heads, winner
 // pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
 // level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
 template <int KN, int NL>
-__device__ inline bool estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
-                                    int2* __restrict__ stack, int stride, bool with_fallback = true) {
+__device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
+                                    int2* __restrict__ stack, int stride) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     TopK<KN> t;
@@ -783,10 +741,19 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, int max_r
     int2 cell[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) cell[k] = r[sub * CPL + k];
-    for (int k = own.x + sub; k < own.x + own.y; k += NL) {
-        const float4 q = g.pts[k];
-        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-        t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
+    // candidates are fetched four at a time (independent 16-byte loads in flight together): one load per insert made
+    // the whole kernel wait a full memory latency per candidate
+    {
+        const int last = own.x + own.y - 1;
+        for (int k = own.x + sub; k <= last; k += 4 * NL) {
+            const bool v1 = k + NL <= last, v2 = k + 2 * NL <= last, v3 = k + 3 * NL <= last;
+            const float4 q0 = g.pts[k], q1 = g.pts[v1 ? k + NL : k], q2 = g.pts[v2 ? k + 2 * NL : k],
+                         q3 = g.pts[v3 ? k + 3 * NL : k];
+            t.insert(point_key(q0, px, py, pz));
+            if (v1) t.insert(point_key(q1, px, py, pz));
+            if (v2) t.insert(point_key(q2, px, py, pz));
+            if (v3) t.insert(point_key(q3, px, py, pz));
+        }
     }
     // the lane's neighbour cells go to its LDS list, then ONE loop streams their candidates (an insert is ~100 VALU:
     // walking the 7 row entries in lockstep would make the wave pay every lane's longest cell 7 times over)
@@ -813,17 +780,20 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, int max_r
                 cnt = nx.y & 0xffffff;
                 k = 0;
             }
-            const float4 q = g.pts[st + k];
-            const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-            t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
-            ++k;
+            const int last = st + cnt - 1, k0 = st + k;
+            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
+            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+            t.insert(point_key(q0, px, py, pz));
+            if (k1 != k0) t.insert(point_key(q1, px, py, pz));
+            if (k2 != k1) t.insert(point_key(q2, px, py, pz));
+            if (k3 != k2) t.insert(point_key(q3, px, py, pz));
+            k += 4;
         }
     }
     TopK<KN> m;
     merge_group<KN, NL>(t, m);
     const float bound1 = h + edge;
     bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
-    if (!exact && !with_fallback) return false;  // first pass of the eager schedule: the point is queued instead
     if (!exact) {
         // fine rings 2..max_rings, then the coarse level, each ring split over the 4 lanes
         exact = max_rings >= 2 && coop_knn_rings<KN, NL>(g, px, py, pz, sub, 2, max_rings, m);
@@ -837,7 +807,6 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, int max_r
         }
     }
     if (sub == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
-    return true;
 }
 
 // merge of the NL lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
@@ -866,9 +835,8 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 // with one lane in NL active.
 static constexpr int NRM_THREADS = 256;
 
-// the map points of a worklist: those queued by the search of this iteration (lazy schedule; `st` given: the launch is
-// a no-op once the registration is done, and the count feeds `normals_computed`) or those the first pass of the eager
-// schedule could not settle inside ring 1 (`st` = nullptr)
+// lazy schedule: the map points queued by the search of this iteration (a no-op once the registration is done; the
+// count feeds `normals_computed`)
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
                                                          const int* __restrict__ count_ptr,
@@ -893,8 +861,9 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
         atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
 }
 
-// eager, single pass: every map point with its fallback inline (round 1's schedule, kept for A/B: option
-// "normals_two_pass" = 0)
+// eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values are
+// the same under both schedules: a normal depends on the map only).  (A two-pass variant — ring 1 for everyone, then a
+// dense pass over the unsettled points — measured slower at every cell size: 276-332 vs 210 us.)
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
@@ -908,33 +877,6 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max
     __syncthreads();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
-}
-
-// eager, first of two passes (chosen when the map is not much larger than the scan; the values are the same under
-// every schedule: a normal depends on the map only): every map point searches ring 1 only.  Where the k-th neighbour
-// is provably inside it the normal is finished here; the other points — whose hashed ring-2 / coarse-level search made
-// every wave of the single-pass kernel wait for its slowest group — are queued and handled DENSELY by `k_normals`.
-template <int KN, int NL>
-__global__ __launch_bounds__(NRM_THREADS) void k_normals_ring1(GridView g, int max_rings, float4* __restrict__ normals,
-                                                               int* __restrict__ nflag, int* __restrict__ worklist,
-                                                               int* __restrict__ count) {
-    constexpr int PTS = NRM_THREADS / NL;
-    __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
-    __shared__ float covs[PTS][7];
-    __shared__ int settled[PTS];
-    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
-    const int s = blockIdx.x * PTS + lq;
-    if (s < g.m) {
-        const bool ok = estimate_cov<KN, NL>(g, s, sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS,
-                                             false);
-        if (sub == 0) {
-            settled[lq] = ok ? 1 : 0;
-            if (!ok) worklist[atomicAdd(count, 1)] = s;
-        }
-    }
-    __syncthreads();
-    const int s2 = blockIdx.x * PTS + threadIdx.x;
-    if (threadIdx.x < PTS && s2 < g.m && settled[threadIdx.x]) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
 }
 
 // generic k (rare): top-k list in scratch memory
@@ -1110,29 +1052,12 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (!ctx->normals_two_pass) {
-        if (kn == 11)
-            hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else if (kn == 6)
-            hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else
-            hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        return;
-    }
-    // pass 1 settles what ring 1 can; the rest is queued behind grid_stats[3] (zeroed by every grid build) and handled
-    // densely by the worklist kernel
-    int* wl = ctx->worklist.as<int>();
-    int* count = ctx->grid_stats.as<int>() + 3;
     if (kn == 11)
-        hipLaunchKernelGGL((k_normals_ring1<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
-                           wl, count);
+        hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else if (kn == 6)
-        hipLaunchKernelGGL((k_normals_ring1<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
-                           wl, count);
+        hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else
-        hipLaunchKernelGGL((k_normals_ring1<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf,
-                           wl, count);
-    launch_worklist_t<NL>(ctx, kn, g, nullptr, count, worklist_blocks(ctx->map_m, NL));
+        hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
 }
 
 int launch_normals_all(icp_ctx* ctx) {
@@ -1159,31 +1084,24 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
     const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
     const int tok = prof_begin(ctx, 0);
-    if (ctx->compact_misses) {
-        IterInputs in;
-        in.tgt = ctx->tgt4.as<float4>();
-        in.normals = ctx->normals.as<float4>();
-        in.nn_cache = ctx->nn_cache.as<int2>();
-        // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
-        in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
-                            ? ctx->seed_orig.as<int>() : nullptr;
-        in.partials = ctx->partials.as<double>();
-        in.n = n;
-        in.mode = ctx->tgt_mode;
-        in.max_rings = ctx->cfg.max_rings;
-        in.use_cache = use_cache;
-        if (ctx->iterate_dense)
-            hipLaunchKernelGGL(k_iterate_compact<8>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
-                               reg_state(ctx), make_align_params(ctx));
-        else
-            hipLaunchKernelGGL(k_iterate_compact<1>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
-                               reg_state(ctx), make_align_params(ctx));
-    } else {
-        hipLaunchKernelGGL(k_iterate_rows, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx),
-                           ctx->tgt4.as<float4>(), n, ctx->tgt_mode, reg_state(ctx), ctx->cfg.max_rings,
-                           ctx->normals.as<float4>(), make_align_params(ctx), ctx->partials.as<double>(),
-                           ctx->nn_cache.as<int2>(), use_cache);
-    }
+    IterInputs in;
+    in.tgt = ctx->tgt4.as<float4>();
+    in.normals = ctx->normals.as<float4>();
+    in.nn_cache = ctx->nn_cache.as<int2>();
+    // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
+    in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
+                        ? ctx->seed_orig.as<int>() : nullptr;
+    in.partials = ctx->partials.as<double>();
+    in.n = n;
+    in.mode = ctx->tgt_mode;
+    in.max_rings = ctx->cfg.max_rings;
+    in.use_cache = use_cache;
+    if (ctx->iterate_dense)
+        hipLaunchKernelGGL(k_iterate_compact<8>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
+                           reg_state(ctx), make_align_params(ctx));
+    else
+        hipLaunchKernelGGL(k_iterate_compact<6>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
+                           reg_state(ctx), make_align_params(ctx));
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;

@@ -38,7 +38,8 @@ __device__ inline void consider(const float4 q, int pos, float px, float py, flo
     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const int idx = __float_as_int(q.w);
-    if (pos == b.pos) return;  // clamped re-read of the current best (tail of a 4-wide fetch)
+    if (idx == b.idx) return;  // the current best again (clamped tail of a 4-wide fetch, a seed met in its cell, or the
+                               // same point seen through the coarse level): original indices are unique
     if (better(d2, idx, b.d2, b.idx)) {
         b.second = fminf(b.second, b.d2);
         b.d2 = d2;
