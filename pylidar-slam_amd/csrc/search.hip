@@ -839,14 +839,13 @@ static constexpr int NRM_THREADS = 256;
 // count feeds `normals_computed`)
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
-                                                         const int* __restrict__ count_ptr,
                                                          const int* __restrict__ worklist, int max_rings,
                                                          float4* __restrict__ normals, int* __restrict__ nflag) {
     constexpr int PTS = NRM_THREADS / NL;
-    if (st && st->done) return;
+    if (st->done) return;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
-    const int nw = *count_ptr;
+    const int nw = st->n_worklist;
     const int sub = threadIdx.x % NL, lq = threadIdx.x / NL;
     for (int base = blockIdx.x * PTS; base < nw; base += gridDim.x * PTS) {  // block-uniform trip count
         const int w = base + lq;
@@ -857,13 +856,16 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
             normal_from_cov(covs[threadIdx.x], worklist[base + threadIdx.x], normals, nflag);
         __syncthreads();
     }
-    if (st && blockIdx.x == 0 && threadIdx.x == 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)nw);
 }
 
 // eager: every map point, right after a rebuild (chosen when the map is not much larger than the scan; the values are
-// the same under both schedules: a normal depends on the map only).  (A two-pass variant — ring 1 for everyone, then a
-// dense pass over the unsettled points — measured slower at every cell size: 276-332 vs 210 us.)
+// the same under both schedules: a normal depends on the map only).  Measured and dropped in round 2: a two-pass variant
+// (ring 1 for everyone, then a dense pass over the unsettled points: 276-332 vs 210 us — at cell sizes tuned for the
+// 1-NN search most points need ring 2 for their 10th neighbour) and a cell-centric variant (one wave per cell, its
+// 27-cell candidates staged once in LDS, brute-force top-k per point: 137 us for the ring-1 part alone + 166 us for the
+// unsettled points, vs 154 us here).
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
@@ -1022,19 +1024,19 @@ static int knn_fine_rings(const icp_ctx* ctx) {
 
 // the worklist kernel for the three compiled neighbourhood sizes
 template <int NL>
-static void launch_worklist_t(icp_ctx* ctx, int kn, const GridView& g, RegState* st, const int* count_ptr, int blocks) {
+static void launch_worklist_t(icp_ctx* ctx, int kn, const GridView& g, RegState* st, int blocks) {
     const int rings = knn_fine_rings(ctx);
     const int* wl = ctx->worklist.as<int>();
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
     if (kn == 11)
-        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
                            rings, nrm, nf);
     else if (kn == 6)
-        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
                            rings, nrm, nf);
     else
-        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, count_ptr, wl,
+        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
                            rings, nrm, nf);
 }
 
@@ -1136,9 +1138,9 @@ int launch_normals(icp_ctx* ctx) {
     RegState* st = reg_state(ctx);
     if (kn == 11 || kn == 6 || kn == 21) {
         if (ctx->knn_lanes == 2)
-            launch_worklist_t<2>(ctx, kn, g, st, &st->n_worklist, worklist_blocks(cap, 2));
+            launch_worklist_t<2>(ctx, kn, g, st, worklist_blocks(cap, 2));
         else
-            launch_worklist_t<4>(ctx, kn, g, st, &st->n_worklist, worklist_blocks(cap, 4));
+            launch_worklist_t<4>(ctx, kn, g, st, worklist_blocks(cap, 4));
     } else {
         int blocks = (int)((cap + 127) / 128);
         if (blocks < 1) blocks = 1;
