@@ -54,6 +54,14 @@ typedef enum {
  * (the "non-null pixels of the vertex map" case, :303-305).  Skipped rows contribute nothing, exactly as if removed. */
 typedef enum { ICP_TARGETS_ALL = 0, ICP_TARGETS_SKIP_NULL = 1 } icp_target_mode;
 
+/* Cost minimised by every alignment of the registration loop: RIGID_ALIGNMENT `mode` of the reference
+ * (slam/odometry/alignment.py:200-208, selected at slam/odometry/icp_odometry.py:98). */
+typedef enum {
+    ICP_COST_POINT_TO_PLANE = 0, /* point_to_plane_gauss_newton: GaussNewtonPointToPlaneAlignment :80-127 */
+    ICP_COST_POINT_TO_POINT = 1  /* point_to_point_gauss_newton: GaussNewtonPointToPointAlignment :143-189, one step
+                                    of PointToPointCost linearised at x0 = 0 per ICP iteration; no map normals */
+} icp_cost;
+
 typedef struct {
     /* SphericalProjector(height, width, 3, up_fov, down_fov), slam/common/projection.py:426-445 */
     int32_t height;
@@ -108,6 +116,8 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value);
 /* runtime re-configuration of the alignment (RIGID_ALIGNMENT.load, slam/odometry/alignment.py:200-208) */
 int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num_alignments,
                       float threshold_delta_pose);
+/* the alignment mode of the registration loop (icp_cost; default point to plane) */
+int icp_set_cost(icp_ctx* ctx, int32_t cost);
 
 /* ---- projection: Projector.build_projection_map (slam/common/projection.py:331-418) ------------------------------
  * xyz [n,3] -> vertex map [3,H,W] planar (zeros where empty), nearest point wins each pixel.
@@ -203,18 +213,19 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
 /* ---- rigid alignment: GaussNewtonPointToPlaneAlignment.align (slam/odometry/alignment.py:91-127) on given
  * correspondences; one Gauss-Newton step from x0 = 0 (slam/common/optimization.py:296-344).
  * dx_out[6], pose_out[16] = build_pose_matrix(dx), loss_out = sum (w r)^2, normal_eq_out (optional) = 32 doubles:
- * 21 upper-triangular JtJ, 6 Jtr, sum (w r)^2, sum r^2, row count, 2 pad. */
+ * 21 upper-triangular JtJ, 6 Jtr, sum (w r)^2, sum r^2, row count, 2 pad; residuals_out (optional, [n] float, in the
+ * memory space `mem` of the inputs) = (w r)^2 per row, the residual tensor `align` returns (optimization.py:342-344). */
 int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
                              int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
-                             double* normal_eq_out);
+                             double* normal_eq_out, float* residuals_out);
 
 /* GaussNewtonPointToPointAlignment.align (slam/odometry/alignment.py:143-189) on given correspondences: one
  * Gauss-Newton step of PointToPointCost (slam/common/optimization.py:458-560) linearised at x0 (NULL = zeros; with
  * `initialize_with_svd` the caller passes from_pose_matrix(icp_weighted_procrustes(...))).  params_out = x0 + dx,
- * pose_out = build_pose_matrix(params_out); loss_out / normal_eq_out as above. */
+ * pose_out = build_pose_matrix(params_out); loss_out / normal_eq_out / residuals_out as above. */
 int icp_align_point_to_point(icp_ctx* ctx, const float* ref_points, const float* tgt_points, int64_t n, int mem,
                              const float x0[6], float params_out[6], float pose_out[16], double* loss_out,
-                             double* normal_eq_out);
+                             double* normal_eq_out, float* residuals_out);
 /* weighted_procrustes (slam/common/registration.py:15-74): closed-form rigid transform target -> reference.  weights
  * [n] float32 or NULL (ones); as in the reference they enter the centroids only.  pose_out row-major 4x4 float64. */
 int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* ref_points, const float* weights,

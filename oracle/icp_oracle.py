@@ -656,6 +656,9 @@ class ICPOracleConfig:
     up_fov: float = 3.0
     down_fov: float = -24.0
     accumulate: type = F32
+    # "point_to_plane" | "point_to_point": the RIGID_ALIGNMENT mode (alignment.py:200-208); point to point = one
+    # `GaussNewtonPointToPointAlignment.align` step from x0 = 0 per iteration (:143-189), no normals
+    alignment: str = "point_to_plane"
 
 
 @dataclass
@@ -717,7 +720,11 @@ class ICPFrameToModelOracle:
         for _ in range(c.max_num_alignments):
             p = apply_transformation(target, pose)  # :275
             q, n, _ = self.local_map.nearest_neighbor_search(p)  # :278
-            step = gauss_newton_step(p, q, n, c.scheme, c.sigma, c.accumulate)  # :284-287
+            if c.alignment == "point_to_point":
+                _, dx, loss = point_to_point_step(p, q, None, c.scheme, c.sigma, c.accumulate)
+                step = GNStep(dx, loss, None, None, False)
+            else:
+                step = gauss_newton_step(p, q, n, c.scheme, c.sigma, c.accumulate)  # :284-287
             trace.dx.append(step.dx)
             trace.loss.append(step.loss)
             if np.sqrt((step.dx.astype(F32) ** 2).sum(dtype=F32)) < c.threshold_delta_pose:  # :292

@@ -336,6 +336,7 @@ void icp_destroy(icp_ctx* ctx) {
     for (DeviceBuffer* b : bufs) b->release();
     if (ctx->host_result) (void)hipHostFree(ctx->host_result);
     if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
+    if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -348,7 +349,14 @@ const char* icp_last_error(const icp_ctx* ctx) { return ctx ? ctx->error.c_str()
 int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
-    ctx->stream = (hipStream_t)hip_stream;
+    hipStream_t next = (hipStream_t)hip_stream;
+    if (next != ctx->stream) {
+        // work already enqueued on the previous stream (map builds, a registration in flight) must precede what follows
+        if (!ctx->switch_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+        ICP_HIP(ctx, hipEventRecord(ctx->switch_event, ctx->stream));
+        ICP_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_event, 0));
+        ctx->stream = next;
+    }
     return ICP_OK;
 }
 
@@ -374,6 +382,16 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     } else {
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "unknown option");
     }
+    return ICP_OK;
+}
+
+int icp_set_cost(icp_ctx* ctx, int32_t cost) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    if (cost != ICP_COST_POINT_TO_PLANE && cost != ICP_COST_POINT_TO_POINT)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "unknown alignment mode");
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    ctx->cost = cost;
     return ICP_OK;
 }
 
@@ -946,16 +964,19 @@ static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], d
 
 int icp_align_point_to_plane(icp_ctx* ctx, const float* ref_points, const float* tgt_points, const float* ref_normals,
                              int64_t n, int mem, float dx_out[6], float pose_out[16], double* loss_out,
-                             double* normal_eq_out) {
+                             double* normal_eq_out, float* residuals_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || n <= 0 || !ref_points || !tgt_points || !ref_normals) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
     const void *r, *t, *nr;
+    void* res_dev;
     if ((rc = import_buffer(ctx, ref_points, (size_t)n * 12, mem, ctx->stage_in, &r))) return rc;
     if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
     if ((rc = import_buffer(ctx, ref_normals, (size_t)n * 12, mem, ctx->stage_out2, &nr))) return rc;
-    if ((rc = launch_align_given(ctx, (const float*)r, (const float*)t, (const float*)nr, n))) return rc;
+    if ((rc = export_target(ctx, residuals_out, (size_t)n * 4, mem, ctx->flags, &res_dev))) return rc;
+    if ((rc = launch_align_given(ctx, (const float*)r, (const float*)t, (const float*)nr, n, (float*)res_dev))) return rc;
+    if ((rc = export_finish(ctx, residuals_out, res_dev, (size_t)n * 4, mem))) return rc;
     return finish_align(ctx, dx_out, pose_out, loss_out, normal_eq_out);
 }
 
@@ -979,15 +1000,18 @@ static int finish_align(icp_ctx* ctx, float params_out[6], float pose_out[16], d
 
 int icp_align_point_to_point(icp_ctx* ctx, const float* ref_points, const float* tgt_points, int64_t n, int mem,
                              const float x0[6], float params_out[6], float pose_out[16], double* loss_out,
-                             double* normal_eq_out) {
+                             double* normal_eq_out, float* residuals_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || n <= 0 || !ref_points || !tgt_points) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
     const void *r, *t;
+    void* res_dev;
     if ((rc = import_buffer(ctx, ref_points, (size_t)n * 12, mem, ctx->stage_in, &r))) return rc;
     if ((rc = import_buffer(ctx, tgt_points, (size_t)n * 12, mem, ctx->targets, &t))) return rc;
-    if ((rc = launch_align_p2p(ctx, (const float*)r, (const float*)t, n, x0))) return rc;
+    if ((rc = export_target(ctx, residuals_out, (size_t)n * 4, mem, ctx->flags, &res_dev))) return rc;
+    if ((rc = launch_align_p2p(ctx, (const float*)r, (const float*)t, n, x0, (float*)res_dev))) return rc;
+    if ((rc = export_finish(ctx, residuals_out, res_dev, (size_t)n * 4, mem))) return rc;
     return finish_align(ctx, params_out, pose_out, loss_out, normal_eq_out);
 }
 
@@ -1116,14 +1140,18 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->have_device_pose = true;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
-    if (!ctx->normals_ready && ctx->map_m <= 2 * n && (rc = launch_normals_all(ctx))) return rc;
+    if (ctx->cost == ICP_COST_POINT_TO_PLANE && !ctx->normals_ready && ctx->map_m <= 2 * n &&
+        (rc = launch_normals_all(ctx)))
+        return rc;
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     return ICP_OK;
 }
 
 // the fused search + rows kernel needs every normal it may touch: the eager schedule
-static bool fused_path(const icp_ctx* ctx) { return ctx->normals_ready && ctx->fuse_iteration; }
+static bool fused_path(const icp_ctx* ctx) {
+    return ctx->cost == ICP_COST_POINT_TO_PLANE && ctx->normals_ready && ctx->fuse_iteration;
+}
 
 int icp_iteration_accumulate(icp_ctx* ctx) {
     DeviceGuard device_guard(ctx);
@@ -1135,6 +1163,7 @@ int icp_iteration_accumulate(icp_ctx* ctx) {
         return launch_sum_partials(ctx, blocks);
     }
     if ((rc = launch_search(ctx))) return rc;
+    if (ctx->cost == ICP_COST_POINT_TO_POINT) return launch_reduce_p2p(ctx, false);
     if ((rc = launch_normals(ctx))) return rc;
     return launch_reduce(ctx);
 }
@@ -1272,6 +1301,8 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
             int blocks = 0;
             rc = launch_iterate_fused(ctx, &blocks);
             if (!rc) rc = launch_sum_solve(ctx, blocks);
+        } else if (ctx->cost == ICP_COST_POINT_TO_POINT) {
+            (rc = launch_search(ctx)) || (rc = launch_reduce_p2p(ctx, true));
         } else {
             (rc = launch_search(ctx)) || (rc = launch_normals(ctx)) || (rc = launch_reduce_solve(ctx));
         }

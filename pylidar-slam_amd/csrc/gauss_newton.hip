@@ -23,8 +23,8 @@ struct RowAcc {
         for (int k = 0; k < NEQ_USED; ++k) v[k] = 0.0;
     }
     // one correspondence: p (transformed target), q (map point), n (map normal)
-    __device__ inline void add(float px, float py, float pz, float qx, float qy, float qz, float nx, float ny, float nz,
-                               int scheme, float sigma) {
+    __device__ inline float add(float px, float py, float pz, float qx, float qy, float qz, float nx, float ny, float nz,
+                                int scheme, float sigma) {
         const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
         // r = ((p - q) * n).sum(-1)   (optimization.py:427-431)
         const float r = __fadd_rn(__fadd_rn(__fmul_rn(dx, nx), __fmul_rn(dy, ny)), __fmul_rn(dz, nz));
@@ -37,10 +37,11 @@ struct RowAcc {
         J[4] = __fsub_rn(__fmul_rn(pz, nx), __fmul_rn(px, nz));
         J[5] = __fsub_rn(__fmul_rn(px, ny), __fmul_rn(py, nx));
         const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        add_row(J, r, robust_weight(scheme, sigma, r, d2));
+        return add_row(J, r, robust_weight(scheme, sigma, r, d2));
     }
-    // one residual r with Jacobian row J and weight w: res *= w, J *= w (optimization.py:329-330), f64 sums
-    __device__ inline void add_row(const float* J, float r, float w) {
+    // one residual r with Jacobian row J and weight w: res *= w, J *= w (optimization.py:329-330), f64 sums; returns
+    // (w r)^2, the row's entry of the residual vector `GaussNewton.compute` hands back (:342-344)
+    __device__ inline float add_row(const float* J, float r, float w) {
         const float rw = __fmul_rn(r, w);
         double Jw[6];
 #pragma unroll
@@ -52,9 +53,11 @@ struct RowAcc {
             for (int b = a; b < 6; ++b) v[k++] += Jw[a] * Jw[b];  // H = J^T J (:332-333), upper triangle
 #pragma unroll
         for (int a = 0; a < 6; ++a) v[21 + a] += Jw[a] * (double)rw;  // J^T r
-        v[27] += (double)__fmul_rn(rw, rw);                            // loss = sum (w r)^2
+        const float rw2 = __fmul_rn(rw, rw);
+        v[27] += (double)rw2;                                          // loss = sum (w r)^2
         v[28] += (double)__fmul_rn(r, r);                              // ||r||^2 for the 1e-7 guard (:323)
         v[29] += 1.0;
+        return rw2;
     }
 };
 
@@ -114,12 +117,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(const float4* __restrict
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_given(const float* __restrict__ ref,
                                                               const float* __restrict__ tgt,
                                                               const float* __restrict__ nrm, int n, AlignParams ap,
-                                                              double* __restrict__ partials) {
+                                                              double* __restrict__ partials,
+                                                              float* __restrict__ residuals) {
     RowAcc acc;
     acc.zero();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        acc.add(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], ref[3 * i], ref[3 * i + 1], ref[3 * i + 2], nrm[3 * i],
-                nrm[3 * i + 1], nrm[3 * i + 2], ap.scheme, ap.sigma);
+        const float rw2 = acc.add(tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], ref[3 * i], ref[3 * i + 1],
+                                  ref[3 * i + 2], nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], ap.scheme, ap.sigma);
+        if (residuals) residuals[i] = rw2;
     }
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
@@ -134,39 +139,72 @@ struct P2PLinearisation {
     float dR[27];   // d R / d ex, ey, ez at x0 (rotation.py:166-187)
 };
 
+// one point-to-point row: p = target (raw), q = reference
+__device__ inline float p2p_row(RowAcc& acc, float px, float py, float pz, float qx, float qy, float qz,
+                                const P2PLinearisation& L, AlignParams ap) {
+    float d[3], J[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // apply_transformation: einsum over j, then + t (pose.py:169-186)
+        const float rp = __fadd_rn(__fadd_rn(__fmul_rn(L.T0[3 * a], px), __fmul_rn(L.T0[3 * a + 1], py)),
+                                   __fmul_rn(L.T0[3 * a + 2], pz));
+        d[a] = __fsub_rn(__fadd_rn(rp, L.T0[9 + a]), a == 0 ? qx : (a == 1 ? qy : qz));
+    }
+    const float r = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    J[0] = d[0];
+    J[1] = d[1];
+    J[2] = d[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float* M = L.dR + 9 * k + 3 * a;
+            const float v = __fadd_rn(__fadd_rn(__fmul_rn(M[0], px), __fmul_rn(M[1], py)), __fmul_rn(M[2], pz));
+            s = __fadd_rn(s, __fmul_rn(v, d[a]));
+        }
+        J[3 + k] = s;
+    }
+    const float ex = __fsub_rn(px, qx), ey = __fsub_rn(py, qy), ez = __fsub_rn(pz, qz);
+    const float d2raw = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+    return acc.add_row(J, r, robust_weight(ap.scheme, ap.sigma, r, d2raw));
+}
+
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_p2p(const float* __restrict__ ref, const float* __restrict__ tgt,
                                                             int n, P2PLinearisation L, AlignParams ap,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials,
+                                                            float* __restrict__ residuals) {
     RowAcc acc;
     acc.zero();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float px = tgt[3 * i], py = tgt[3 * i + 1], pz = tgt[3 * i + 2];
-        const float qx = ref[3 * i], qy = ref[3 * i + 1], qz = ref[3 * i + 2];
-        float d[3], J[6];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {  // apply_transformation: einsum over j, then + t (pose.py:169-186)
-            const float rp = __fadd_rn(__fadd_rn(__fmul_rn(L.T0[3 * a], px), __fmul_rn(L.T0[3 * a + 1], py)),
-                                       __fmul_rn(L.T0[3 * a + 2], pz));
-            d[a] = __fsub_rn(__fadd_rn(rp, L.T0[9 + a]), a == 0 ? qx : (a == 1 ? qy : qz));
-        }
-        const float r = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
-        J[0] = d[0];
-        J[1] = d[1];
-        J[2] = d[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float s = 0.f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float* M = L.dR + 9 * k + 3 * a;
-                const float v = __fadd_rn(__fadd_rn(__fmul_rn(M[0], px), __fmul_rn(M[1], py)), __fmul_rn(M[2], pz));
-                s = __fadd_rn(s, __fmul_rn(v, d[a]));
-            }
-            J[3 + k] = s;
-        }
-        const float ex = __fsub_rn(px, qx), ey = __fsub_rn(py, qy), ez = __fsub_rn(pz, qz);
-        const float d2raw = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
-        acc.add_row(J, r, robust_weight(ap.scheme, ap.sigma, r, d2raw));
+        const float rw2 = p2p_row(acc, tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2], ref[3 * i], ref[3 * i + 1],
+                                  ref[3 * i + 2], L, ap);
+        if (residuals) residuals[i] = rw2;
+    }
+    block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
+}
+
+// point-to-point rows of a registration iteration: targets transformed by the current pose (icp_odometry.py:275) against
+// their nearest neighbours, linearised at x0 = 0 (what `GaussNewtonPointToPointAlignment.align` does without an initial
+// estimate, alignment.py:173-176)
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_p2p_nn(const float4* __restrict__ map_pts,
+                                                               const float4* __restrict__ tgt,
+                                                               const int* __restrict__ nn_pos, int n,
+                                                               const RegState* __restrict__ st, P2PLinearisation L,
+                                                               AlignParams ap, double* __restrict__ partials) {
+    if (st->done) return;
+    RowAcc acc;
+    acc.zero();
+    const float* T = st->pose;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int s = nn_pos[i];
+        if (s < 0) continue;
+        const float4 t4 = tgt[i];
+        const float x = t4.x, y = t4.y, z = t4.z;
+        const float px = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
+        const float py = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
+        const float pz = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
+        const float4 q = map_pts[s];
+        p2p_row(acc, px, py, pz, q.x, q.y, q.z, L, ap);
     }
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
@@ -623,12 +661,13 @@ static int launch_solve_given(icp_ctx* ctx, int blocks, const float* x0) {
     return ICP_OK;
 }
 
-int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n) {
+int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n,
+                       float* residuals_dev) {
     const int blocks = reduce_grid(n);
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     ICP_HIP(ctx, ctx->stage_out.reserve(256));
     hipLaunchKernelGGL(k_reduce_given, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, nrm, (int)n,
-                       make_align_params(ctx), ctx->partials.as<double>());
+                       make_align_params(ctx), ctx->partials.as<double>(), residuals_dev);
     return launch_solve_given(ctx, blocks, nullptr);
 }
 
@@ -664,13 +703,36 @@ static P2PLinearisation linearise_euler(const float* x0) {
     return L;
 }
 
-int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0) {
+int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0,
+                     float* residuals_dev) {
     const int blocks = reduce_grid(n);
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     ICP_HIP(ctx, ctx->stage_out.reserve(256));
     hipLaunchKernelGGL(k_reduce_p2p, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ref, tgt, (int)n,
-                       linearise_euler(x0), make_align_params(ctx), ctx->partials.as<double>());
+                       linearise_euler(x0), make_align_params(ctx), ctx->partials.as<double>(), residuals_dev);
     return launch_solve_given(ctx, blocks, x0);
+}
+
+// point-to-point cost in the registration loop: rows from the search result -> partial rows (`solve`: + final sum and
+// solve, the single-GPU path; otherwise + final sum only, the exchange seam)
+int launch_reduce_p2p(icp_ctx* ctx, bool solve) {
+    const int n = (int)ctx->tgt_n;
+    const int blocks = reduce_grid(n);
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
+    const int tok = prof_begin(ctx, 1);
+    hipLaunchKernelGGL(k_reduce_p2p_nn, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
+                       ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx), linearise_euler(nullptr),
+                       make_align_params(ctx), ctx->partials.as<double>());
+    if (solve)
+        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                           reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
+                           ctx->hist_cap);
+    else
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                           reg_state(ctx), 1, ctx->neq);
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
 }
 
 // sums for weighted_procrustes; host_out[NEQ] receives the fixed-order total of the pass (synchronises)

@@ -165,6 +165,7 @@ struct icp_ctx {
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer nn_cache;        // int2[N]: (NN position, bits(L)) — L = lower bound on the distance to every other map point
     int iter_in_registration = 0;
+    int cost = 0;                      // icp_cost of the registration loop (icp_set_cost)
     // tuning options (icp_set_option; none of them changes a result)
     int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
@@ -199,6 +200,7 @@ struct icp_ctx {
     void* host_result = nullptr;
     size_t host_result_bytes = 0;
     hipEvent_t result_event = nullptr;
+    hipEvent_t switch_event = nullptr;  // orders a change of stream (icp_set_stream) behind the work of the old one
     // ---- scratch for projection / sampling / io
     icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
         vals_b, counter;
@@ -248,8 +250,11 @@ int launch_sum_partials(icp_ctx* ctx, int blocks);
 // fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
 int launch_iterate_fused(icp_ctx* ctx, int* blocks_out);
 int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
-int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n);
-int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0);
+int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n,
+                       float* residuals_dev);
+int launch_align_p2p(icp_ctx* ctx, const float* ref, const float* tgt, int64_t n, const float* x0,
+                     float* residuals_dev);
+int launch_reduce_p2p(icp_ctx* ctx, bool solve);  // point-to-point rows of a registration iteration
 int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, const float* w, int64_t n,
                            const float* mu_tgt, const float* mu_ref, double* host_out);
 

@@ -992,7 +992,7 @@ static void launch_search_rows(icp_ctx* ctx, int n, int mode, int transform) {
     hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
                        make_view(ctx), ctx->tgt4.as<float4>(), n, mode, transform, reg_state(ctx), ctx->cfg.max_rings,
                        ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
-                       ctx->normals_ready ? 0 : 1);
+                       (ctx->normals_ready || ctx->cost == ICP_COST_POINT_TO_POINT) ? 0 : 1);  // p2p needs no normals
 }
 
 int launch_search(icp_ctx* ctx) {

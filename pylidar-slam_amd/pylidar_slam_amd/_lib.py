@@ -10,10 +10,12 @@ from typing import Optional
 import numpy as np
 
 __all__ = ["IcpLibraryError", "IcpConfig", "IcpRegisterResult", "load_library", "library_path", "EXPORTED_SYMBOLS",
-           "SCHEMES", "MEM_HOST", "MEM_DEVICE", "TARGETS_ALL", "TARGETS_SKIP_NULL", "STATUS_MESSAGES"]
+           "SCHEMES", "COSTS", "MEM_HOST", "MEM_DEVICE", "TARGETS_ALL", "TARGETS_SKIP_NULL", "STATUS_MESSAGES"]
 
 MEM_HOST, MEM_DEVICE = 0, 1
 TARGETS_ALL, TARGETS_SKIP_NULL = 0, 1
+# RIGID_ALIGNMENT modes of the reference (slam/odometry/alignment.py:200-208) -> icp_cost
+COSTS = {"point_to_plane_gauss_newton": 0, "point_to_point_gauss_newton": 1}
 
 ICP_OK = 0
 ICP_ERR_INVALID_ARGUMENT = -1
@@ -67,6 +69,7 @@ EXPORTED_SYMBOLS = {
     "icp_synchronize": (_INT, [_P]),
     "icp_set_option": (_INT, [_P, C.c_char_p, C.c_double]),
     "icp_set_alignment": (_INT, [_P, C.c_int32, C.c_float, C.c_int32, C.c_float]),
+    "icp_set_cost": (_INT, [_P, C.c_int32]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_project_pixels": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_kitti_correct_scan": (_INT, [_P, _P, _I64, _INT, _INT, _P, _INT]),
@@ -90,9 +93,9 @@ EXPORTED_SYMBOLS = {
     "icp_pmap_get_model": (_INT, [_P, _P, _P, _INT]),
     "icp_pmap_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, C.POINTER(_I64), _INT]),
     "icp_pmap_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
-    "icp_align_point_to_plane": (_INT, [_P, _P, _P, _P, _I64, _INT, _P, _P, _P, _P]),
+    "icp_align_point_to_plane": (_INT, [_P, _P, _P, _P, _I64, _INT, _P, _P, _P, _P, _P]),
     "icp_voxel_statistics": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, _P, _P, _P, _P, _P, _INT]),
-    "icp_align_point_to_point": (_INT, [_P, _P, _P, _I64, _INT, _P, _P, _P, _P, _P]),
+    "icp_align_point_to_point": (_INT, [_P, _P, _P, _I64, _INT, _P, _P, _P, _P, _P, _P]),
     "icp_weighted_procrustes": (_INT, [_P, _P, _P, _P, _I64, _INT, _P]),
     "icp_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_register_begin": (_INT, [_P, _P, _I64, _INT, _INT, _P]),

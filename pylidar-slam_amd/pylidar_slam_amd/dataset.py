@@ -86,6 +86,16 @@ class SyntheticDatasetConfig:
     train_sequences: List[str] = field(default_factory=lambda: ["room_00"])
     lidar_key: str = "vertex_map"
     with_numpy_pc: bool = True
+    device: str = "cuda:0"  # the GPU the scans are projected on
+    # False (default): items are CPU tensors, so the reference runner's DataLoader(pin_memory=True) works unchanged
+    # (slam/odometry/odometry_runner.py:51,149) and `_send_to_device` moves them; True: the vertex map stays on the
+    # device (no D2H + H2D round trip) — needs `pin_memory=false`, a CUDA tensor cannot be pinned
+    device_items: bool = False
+
+
+def _device_index(device: str) -> int:
+    d = torch.device(device)
+    return 0 if d.index is None else int(d.index)
 
 
 class SyntheticSequence(Dataset):
@@ -107,7 +117,8 @@ class SyntheticSequence(Dataset):
         d = {}
         if self.config.with_numpy_pc:
             d["numpy_pc"] = scan
-        d[self.config.lidar_key] = self.ctx.project(torch.from_numpy(scan).to(self.ctx.device))
+        vmap = self.ctx.project(torch.from_numpy(scan).to(self.ctx.device))
+        d[self.config.lidar_key] = vmap if self.config.device_items else vmap.cpu()
         d[DatasetLoader.absolute_gt_key()] = torch.from_numpy(self.poses[idx])
         return d
 
@@ -116,7 +127,7 @@ class SyntheticDatasetLoader(DatasetLoader):
     def __init__(self, config: SyntheticDatasetConfig):
         super().__init__(config)
         self._ctx = IcpContext(height=config.lidar_height, width=config.lidar_width, up_fov=config.up_fov,
-                               down_fov=config.down_fov)
+                               down_fov=config.down_fov, device=_device_index(config.device))
         self._sequences = {n: SyntheticSequence(config, self._ctx, n) for n in config.train_sequences}
 
     def projector(self) -> SphericalProjector:
@@ -174,6 +185,8 @@ class KITTIConfig:
     eval_sequences: List[str] = field(default_factory=lambda: ["09", "10"])
     test_sequences: List[str] = field(default_factory=lambda: [f"{i:02}" for i in range(22)])
     with_numpy_pc: bool = True
+    device: str = "cuda:0"       # the GPU scans are corrected and projected on
+    device_items: bool = False   # see SyntheticDatasetConfig.device_items
 
 
 class KITTIOdometrySequence(Dataset):
@@ -182,7 +195,8 @@ class KITTIOdometrySequence(Dataset):
 
     def __init__(self, sequences_root_dir: str, sequence_id: str, ctx: IcpContext,
                  corrected_lidar_channel: str = "vertex_map", ground_truth_channel: Optional[str] = None,
-                 with_numpy_pc: bool = False):
+                 with_numpy_pc: bool = False, device_items: bool = False):
+        self._device_items = device_items
         self.sequence_dir = Path(sequences_root_dir)
         self.sequence_id = sequence_id
         self.ctx = ctx
@@ -227,7 +241,8 @@ class KITTIOdometrySequence(Dataset):
         scan = self.correct_scan(kitti_read_scan(str(scan_path)))
         if self._with_numpy_pc:
             d["numpy_pc"] = scan
-        d[self.corrected_lidar_channel] = self.ctx.project(torch.from_numpy(scan).to(self.ctx.device))
+        vmap = self.ctx.project(torch.from_numpy(scan).to(self.ctx.device))
+        d[self.corrected_lidar_channel] = vmap if self._device_items else vmap.cpu()
         if self.ground_truth_channel and self.poses_gt is not None:
             d[self.ground_truth_channel] = torch.from_numpy(self.poses_gt[idx])
         return d
@@ -241,7 +256,7 @@ class KITTIDatasetLoader(DatasetLoader):
         self.odometry_sequence_dir = Path(config.kitti_sequence_dir)
         assert_debug(self.odometry_sequence_dir.exists())
         self._ctx = IcpContext(height=config.lidar_height, width=config.lidar_width, up_fov=config.up_fov,
-                               down_fov=config.down_fov)
+                               down_fov=config.down_fov, device=_device_index(config.device))
 
     def projector(self) -> SphericalProjector:
         c = self.config
@@ -266,7 +281,8 @@ class KITTIDatasetLoader(DatasetLoader):
                 return None
             present = [s for s in seqs if (self.odometry_sequence_dir / "sequences" / s / "velodyne").exists()]
             return [KITTIOdometrySequence(str(self.odometry_sequence_dir), s, self._ctx, c.lidar_key, c.absolute_gt_key,
-                                          with_numpy_pc=c.with_numpy_pc) for s in present], present
+                                          with_numpy_pc=c.with_numpy_pc, device_items=c.device_items)
+                    for s in present], present
 
         tr, ev, te = get(c.train_sequences), get(c.eval_sequences), get(c.test_sequences)
         return tr or (None, None), ev or (None, None), te or (None, None), lambda x: x

@@ -35,6 +35,8 @@ def sharded_register(engine, local_points, init_pose=None, iterations: Optional[
     """
     import torch.distributed as dist
     use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if hasattr(engine, "use_torch_stream"):
+        engine.use_torch_stream()  # accumulate / all-reduce / solve must share one stream: torch's current one
     neq = engine.normal_equations_tensor()
     iters = int(iterations if iterations is not None else engine.config.max_num_alignments)
     engine.register_begin(local_points, init_pose, skip_null=skip_null)

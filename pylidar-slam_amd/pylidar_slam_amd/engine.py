@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (IcpConfig, IcpLibraryError, IcpRegisterResult, MEM_DEVICE, MEM_HOST, SCHEMES, STATUS_MESSAGES,
-                   TARGETS_ALL, TARGETS_SKIP_NULL)
+from ._lib import (COSTS, IcpConfig, IcpLibraryError, IcpRegisterResult, MEM_DEVICE, MEM_HOST, SCHEMES,
+                   STATUS_MESSAGES, TARGETS_ALL, TARGETS_SKIP_NULL)
 
 Array = Union[np.ndarray, torch.Tensor]
 
@@ -48,6 +48,10 @@ def _ptr_mem(a: Optional[Array]) -> Tuple[Optional[int], int, object]:
         return n.ctypes.data, MEM_HOST, n
     n = np.ascontiguousarray(a, dtype=np.float32)
     return n.ctypes.data, MEM_HOST, n
+
+
+def _on_device(*arrays) -> bool:
+    return any(isinstance(a, torch.Tensor) and a.is_cuda for a in arrays)
 
 
 def _pose16(m) -> "C.Array":
@@ -103,11 +107,27 @@ class IcpContext:
         raise RuntimeError(f"libicp_mi355x: {msg} ({rc})")
 
     def use_torch_stream(self):
-        """Enqueue on torch's current HIP stream of this device."""
-        self._check(self._lib.icp_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        """Enqueue on torch's current HIP stream of this device (the library orders a switch of streams against the work
+        it enqueued on the previous one)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != getattr(self, "_bound_stream", None):
+            self._check(self._lib.icp_set_stream(self._h, C.c_void_p(stream)))
+            self._bound_stream = stream
+
+    def _bind(self, *arrays):
+        """Device tensors come from (and results go to) torch's current stream: make sure the library enqueues there."""
+        if _on_device(*arrays):
+            self.use_torch_stream()
 
     def synchronize(self):
         self._check(self._lib.icp_synchronize(self._h))
+
+    def set_cost(self, mode: str):
+        """Alignment mode of the registration loop: a RIGID_ALIGNMENT member name of the reference
+        ("point_to_plane_gauss_newton" | "point_to_point_gauss_newton")."""
+        if mode not in COSTS:
+            raise AssertionError(f"unknown alignment mode {mode}")
+        self._check(self._lib.icp_set_cost(self._h, COSTS[mode]))
 
     def set_option(self, name: str, value: float):
         """MI355X-side tuning option (see `icp_set_option` in include/icp_mi355x.h); never changes a result."""
@@ -123,6 +143,7 @@ class IcpContext:
     # ---- projection --------------------------------------------------------------------------------------------------
     def project(self, points: Array, with_index: bool = False, out: Optional[torch.Tensor] = None):
         """Vertex map [3, H, W] (same kind as the input: numpy in -> numpy out, cuda tensor in -> cuda tensor out)."""
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0]) if keep is not None else 0
         h, w = self.config.height, self.config.width
@@ -166,6 +187,7 @@ class IcpContext:
 
     def grid_sample(self, points: Array, voxel_size: float):
         """(sample points [V,3], indices [V] int64), ordered by ascending voxel hash."""
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])
         count = C.c_int64(0)
@@ -204,11 +226,21 @@ class IcpContext:
             out.update(voxel_sizes=sizes[:v].copy(), voxel_means=means[:v].copy(), voxel_covariances=covs[:v].copy())
         return out
 
-    def grid_sample_f64(self, points: np.ndarray, voxel_size: float):
-        """float64 cloud (the output of `distort`) -> (sample points [V,3] f64, indices [V] int64)."""
+    def grid_sample_f64(self, points: Array, voxel_size: float):
+        """float64 cloud (the output of `distort`) -> (sample points [V,3] f64, indices [V] int64); a cuda tensor stays
+        on the device (zero-copy in, device tensors out)."""
+        self._bind(points)
+        count = C.c_int64(0)
+        if isinstance(points, torch.Tensor) and points.is_cuda:
+            t = points.to(torch.float64).contiguous()
+            n = int(t.shape[0])
+            idx = torch.empty(max(n, 1), dtype=torch.int64, device=t.device)
+            out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=t.device)
+            self._check(self._lib.icp_grid_sample_f64(self._h, t.data_ptr(), n, MEM_DEVICE, float(voxel_size),
+                                                      idx.data_ptr(), out.data_ptr(), C.byref(count), MEM_DEVICE))
+            return out[:count.value], idx[:count.value]
         pts64 = np.ascontiguousarray(points, dtype=np.float64)
         n = int(pts64.shape[0])
-        count = C.c_int64(0)
         idx = np.empty(max(n, 1), np.int64)
         out = np.empty((max(n, 1), 3), np.float64)
         self._check(self._lib.icp_grid_sample_f64(self._h, pts64.ctypes.data, n, MEM_HOST, float(voxel_size),
@@ -216,13 +248,24 @@ class IcpContext:
         return out[:count.value].copy(), idx[:count.value].copy()
 
     # ---- de-skew -----------------------------------------------------------------------------------------------------
-    def distort(self, points: np.ndarray, timestamps: np.ndarray, rel_pose) -> np.ndarray:
-        """`Distortion.filter`: [N,3] f32 points + [N] f64 timestamps + 4x4 initial motion -> [N,3] f64."""
+    def distort(self, points: Array, timestamps: Array, rel_pose):
+        """`Distortion.filter`: [N,3] f32 points + [N] f64 timestamps + 4x4 initial motion -> [N,3] f64.  cuda tensors in
+        -> cuda tensor out (nothing crosses PCIe but the 4x4 pose)."""
+        self._bind(points)
+        pose = np.ascontiguousarray(np.asarray(rel_pose, dtype=np.float64).reshape(4, 4))
+        if isinstance(points, torch.Tensor) and points.is_cuda:
+            pts = points.to(torch.float32).contiguous()
+            ts = torch.as_tensor(timestamps).to(pts.device, torch.float64).reshape(-1).contiguous()
+            if pts.ndim != 2 or pts.shape[1] != 3 or ts.shape[0] != pts.shape[0]:
+                raise AssertionError(f"expected [N,3] points and [N] timestamps, got {tuple(pts.shape)} / {tuple(ts.shape)}")
+            out = torch.empty((pts.shape[0], 3), dtype=torch.float64, device=pts.device)
+            self._check(self._lib.icp_distort(self._h, pts.data_ptr(), ts.data_ptr(), int(pts.shape[0]), MEM_DEVICE,
+                                              pose.ctypes.data, out.data_ptr(), MEM_DEVICE))
+            return out
         pts = np.ascontiguousarray(points, dtype=np.float32)
         ts = np.ascontiguousarray(np.asarray(timestamps).reshape(-1), dtype=np.float64)
         if pts.ndim != 2 or pts.shape[1] != 3 or ts.shape[0] != pts.shape[0]:
             raise AssertionError(f"expected [N,3] points and [N] timestamps, got {pts.shape} / {ts.shape}")
-        pose = np.ascontiguousarray(np.asarray(rel_pose, dtype=np.float64).reshape(4, 4))
         out = np.empty((pts.shape[0], 3), np.float64)
         self._check(self._lib.icp_distort(self._h, pts.ctypes.data, ts.ctypes.data, int(pts.shape[0]), MEM_HOST,
                                           pose.ctypes.data, out.ctypes.data, MEM_HOST))
@@ -233,10 +276,12 @@ class IcpContext:
         self._check(self._lib.icp_map_init(self._h))
 
     def map_set(self, points: Array):
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         self._check(self._lib.icp_map_set(self._h, p, int(keep.shape[0]), mem))
 
     def map_update(self, rel_pose, new_points: Optional[Array] = None, skip_null: bool = False) -> int:
+        self._bind(new_points)
         p, mem, keep = _ptr_mem(new_points)
         n = int(keep.shape[0]) if keep is not None else 0
         if keep is not None and n == 0:
@@ -251,6 +296,7 @@ class IcpContext:
         return int(ins.value)
 
     def map_update_vertex_map(self, rel_pose, vmap: Array) -> int:
+        self._bind(vmap)
         p, mem, keep = _ptr_mem(vmap)
         ins = C.c_int64(0)
         self._check(self._lib.icp_map_update_vertex_map(self._h, _pose16(rel_pose), p, mem, C.byref(ins)))
@@ -269,6 +315,7 @@ class IcpContext:
         return out
 
     def nearest_neighbor_search(self, points: Array, with_normals: bool = True, with_index: bool = False):
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])
         if mem == MEM_DEVICE:
@@ -358,18 +405,27 @@ class IcpContext:
         return to_maps(v4), to_maps(n4)
 
     def pmap_nearest_neighbor_search(self, points: Array):
-        """(neighbour points, neighbour normals, new target points), each [n,3], matched pixels in pixel order."""
+        """(neighbour points, neighbour normals, new target points), each [n,3], matched pixels in pixel order; cuda
+        tensors for cuda points, numpy arrays otherwise."""
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])
         npix = self.config.height * self.config.width
-        rows = np.empty((npix, 9), np.float32)
         count = C.c_int64(0)
+        if mem == MEM_DEVICE:
+            rows = torch.empty((npix, 9), dtype=torch.float32, device=keep.device)
+            self._check(self._lib.icp_pmap_nearest_neighbor_search(self._h, p, n, mem, rows.data_ptr(), C.byref(count),
+                                                                   MEM_DEVICE))
+            r = rows[:count.value]
+            return r[:, 0:3].contiguous(), r[:, 3:6].contiguous(), r[:, 6:9].contiguous()
+        rows = np.empty((npix, 9), np.float32)
         self._check(self._lib.icp_pmap_nearest_neighbor_search(self._h, p, n, mem, rows.ctypes.data, C.byref(count),
                                                                MEM_HOST))
         r = rows[:count.value]
         return r[:, 0:3].copy(), r[:, 3:6].copy(), r[:, 6:9].copy()
 
     def pmap_register(self, points: Array, init_pose=None, skip_null: bool = False) -> RegisterResult:
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])
         cap = max(1, int(self.config.max_num_alignments))
@@ -382,8 +438,20 @@ class IcpContext:
         return self._result(res, losses, dxs)
 
     # ---- alignment ---------------------------------------------------------------------------------------------------
-    def align_point_to_plane(self, ref_points: Array, tgt_points: Array, ref_normals: Array):
-        """One Gauss-Newton point-to-plane step: (pose [4,4], dx [6], loss, normal equations [32] f64)."""
+    def _residual_buffer(self, n: int, mem: int, like, with_residuals: bool):
+        if not with_residuals:
+            return None, None
+        if mem == MEM_DEVICE:
+            buf = torch.empty(n, dtype=torch.float32, device=like.device)
+            return buf, buf.data_ptr()
+        buf = np.empty(n, np.float32)
+        return buf, buf.ctypes.data
+
+    def align_point_to_plane(self, ref_points: Array, tgt_points: Array, ref_normals: Array,
+                             with_residuals: bool = False):
+        """One Gauss-Newton point-to-plane step: (pose [4,4], dx [6], loss, normal equations [32] f64[, residuals [n]
+        = (w r)^2 per row, numpy / cuda tensor like the inputs])."""
+        self._bind(ref_points, tgt_points, ref_normals)
         r, mem_r, kr = _ptr_mem(ref_points)
         t, mem_t, kt = _ptr_mem(tgt_points)
         nn, mem_n, kn = _ptr_mem(ref_normals)
@@ -396,13 +464,17 @@ class IcpContext:
         pose = (C.c_float * 16)()
         loss = C.c_double(0)
         neq = (C.c_double * 32)()
-        self._check(self._lib.icp_align_point_to_plane(self._h, r, t, nn, n, mem_r, dx, pose, C.byref(loss), neq))
-        return (np.array(pose, np.float32).reshape(4, 4), np.array(dx, np.float32), float(loss.value),
-                np.array(neq, np.float64))
+        res, res_ptr = self._residual_buffer(n, mem_r, kr, with_residuals)
+        self._check(self._lib.icp_align_point_to_plane(self._h, r, t, nn, n, mem_r, dx, pose, C.byref(loss), neq,
+                                                       res_ptr))
+        out = (np.array(pose, np.float32).reshape(4, 4), np.array(dx, np.float32), float(loss.value),
+               np.array(neq, np.float64))
+        return out + (res,) if with_residuals else out
 
-    def align_point_to_point(self, ref_points: Array, tgt_points: Array, x0=None):
+    def align_point_to_point(self, ref_points: Array, tgt_points: Array, x0=None, with_residuals: bool = False):
         """One Gauss-Newton point-to-point step linearised at x0 ([6] or None = zeros):
-        (pose [4,4], params [6] = x0 + dx, loss, normal equations [32] f64)."""
+        (pose [4,4], params [6] = x0 + dx, loss, normal equations [32] f64[, residuals [n]])."""
+        self._bind(ref_points, tgt_points)
         r, mem_r, kr = _ptr_mem(ref_points)
         t, mem_t, kt = _ptr_mem(tgt_points)
         if mem_r != mem_t:
@@ -415,9 +487,12 @@ class IcpContext:
         pose = (C.c_float * 16)()
         loss = C.c_double(0)
         neq = (C.c_double * 32)()
-        self._check(self._lib.icp_align_point_to_point(self._h, r, t, n, mem_r, x, params, pose, C.byref(loss), neq))
-        return (np.array(pose, np.float32).reshape(4, 4), np.array(params, np.float32), float(loss.value),
-                np.array(neq, np.float64))
+        res, res_ptr = self._residual_buffer(n, mem_r, kr, with_residuals)
+        self._check(self._lib.icp_align_point_to_point(self._h, r, t, n, mem_r, x, params, pose, C.byref(loss), neq,
+                                                       res_ptr))
+        out = (np.array(pose, np.float32).reshape(4, 4), np.array(params, np.float32), float(loss.value),
+               np.array(neq, np.float64))
+        return out + (res,) if with_residuals else out
 
     def weighted_procrustes(self, tgt_points: Array, ref_points: Array, weights=None) -> np.ndarray:
         """`weighted_procrustes` (slam/common/registration.py:15-74): [4,4] float64 transform target -> reference."""
@@ -451,6 +526,7 @@ class IcpContext:
                               np.array(losses[:k], np.float64), np.array(dxs, np.float32).reshape(-1, 6)[:k])
 
     def register(self, points: Array, init_pose=None, skip_null: bool = False) -> RegisterResult:
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])
         cap = max(1, int(self.config.max_num_alignments))
@@ -466,12 +542,14 @@ class IcpContext:
     def normal_equations_tensor(self) -> torch.Tensor:
         """A torch-owned [32] f64 device vector installed as the context's normal-equation buffer, so that
         `torch.distributed.all_reduce` (RCCL) can sum it in place between accumulate() and solve()."""
+        self.use_torch_stream()  # the collective that sums this vector is ordered on torch's stream
         if self._neq_tensor is None:
             self._neq_tensor = torch.zeros(32, dtype=torch.float64, device=self.device)
             self._check(self._lib.icp_set_normal_equations_buffer(self._h, self._neq_tensor.data_ptr()))
         return self._neq_tensor
 
     def register_begin(self, points: Array, init_pose=None, skip_null: bool = False):
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         self._keep_targets = keep
         init = _pose16(init_pose if init_pose is not None else np.eye(4))
@@ -481,6 +559,7 @@ class IcpContext:
     def register_launch(self, points: Array, init_pose=None, skip_null: bool = False):
         """Enqueue a whole registration without waiting; `register_end()` later blocks on it alone, so work enqueued in
         between (e.g. `map_update(None)`) overlaps the host's wait."""
+        self._bind(points)
         p, mem, keep = _ptr_mem(points)
         self._keep_targets = keep
         init = _pose16(init_pose if init_pose is not None else np.eye(4))

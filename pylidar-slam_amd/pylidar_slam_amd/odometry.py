@@ -28,12 +28,12 @@ import torch
 
 from .engine import IcpContext, InvalidJacobianError, RegisterResult  # noqa: F401
 
-__all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap", "Distortion",
-           "ProjectiveLocalMap",
-           "DistortionConfig",
-           "PointToPlaneAlignment", "PointToPointAlignment", "SphericalProjector", "GridSample", "GridSampleConfig", "grid_sample",
-           "Voxelization", "VoxelizationConfig",
-           "ConstantVelocityInitialization", "NeighborhoodResult", "build_pose_matrix", "from_pose_matrix"]
+__all__ = ["OdometryAlgorithm", "MI355XICPConfig", "MI355XICPFrameToModel", "HashGridLocalMap",
+           "HashGridLocalMapConfig", "ProjectiveLocalMap", "ProjectiveLocalMapConfig", "PointToPlaneAlignment",
+           "PointToPlaneAlignmentConfig", "PointToPointAlignment", "PointToPointAlignmentConfig", "SphericalProjector",
+           "GridSample", "GridSampleConfig", "grid_sample", "Distortion", "DistortionConfig", "Voxelization",
+           "VoxelizationConfig", "ToDevice", "ToDeviceConfig", "ConstantVelocityInitialization", "NeighborhoodResult",
+           "build_pose_matrix", "from_pose_matrix"]
 
 
 def assert_debug(condition: bool, message: str = ""):
@@ -140,14 +140,15 @@ def grid_sample(pointcloud: np.ndarray, voxel_size: float, ctx: Optional[IcpCont
     return pts, idx
 
 
-_SHARED: Optional[IcpContext] = None
+_SHARED: Dict[int, IcpContext] = {}
 
 
-def _shared_context() -> IcpContext:
-    global _SHARED
-    if _SHARED is None:
-        _SHARED = IcpContext()
-    return _SHARED
+def _shared_context(device=None) -> IcpContext:
+    """One utility context per GPU for the stateless filters (grid sampling, de-skew, voxel statistics)."""
+    index = int(device.index) if device is not None and getattr(device, "index", None) is not None else 0
+    if index not in _SHARED:
+        _SHARED[index] = IcpContext(device=index)
+    return _SHARED[index]
 
 
 @dataclass
@@ -199,8 +200,14 @@ class GridSampleConfig:
     output_sample_key: str = "sample_points"
 
 
+def _is_device_tensor(a) -> bool:
+    return isinstance(a, torch.Tensor) and a.is_cuda
+
+
 class GridSample:
-    """slam/preprocessing.py:207-226 (`Filter.filter(data_dict)` seam)."""
+    """slam/preprocessing.py:207-226 (`Filter.filter(data_dict)` seam).  A numpy cloud gives numpy samples like the
+    reference; a cuda tensor (float32, or the float64 output of `Distortion`) is sampled in place on the device and the
+    samples / indices stay there — the device-resident hand-off towards the odometry."""
 
     def __init__(self, config: GridSampleConfig, ctx: Optional[IcpContext] = None, **kwargs):
         self.config = config
@@ -208,11 +215,73 @@ class GridSample:
 
     def filter(self, data_dict: dict):
         pc = data_dict[self.config.pointcloud_key]
-        assert_debug(isinstance(pc, np.ndarray), "Cannot Distort a non numpy frame")
+        assert_debug(isinstance(pc, np.ndarray) or _is_device_tensor(pc), "Cannot Distort a non numpy frame")
         assert_debug(pc.ndim == 2 and pc.shape[1] == 3, f"expected [N, 3], got {pc.shape}")
-        sample, indices = grid_sample(pc, self.config.voxel_size, self._ctx)
+        if _is_device_tensor(pc):
+            ctx = self._ctx or _shared_context(pc.device)
+            ctx.use_torch_stream()
+            sample, indices = ctx.grid_sample_f64(pc, self.config.voxel_size) if pc.dtype == torch.float64 else \
+                ctx.grid_sample(pc, self.config.voxel_size)
+        else:
+            sample, indices = grid_sample(pc, self.config.voxel_size, self._ctx)
         data_dict[self.config.output_sample_key] = sample
         data_dict[self.config.output_indices_key] = indices
+
+
+@dataclass
+class ToDeviceConfig:
+    """Config of `ToDevice` (FILTER member `to_device_mi355x`)."""
+    filter_name: str = "to_device_mi355x"
+    device: str = "cuda:0"
+    keys: Dict[str, str] = field(default_factory=lambda: {"numpy_pc": "pc_device",
+                                                          "numpy_pc_timestamps": "timestamps_device"})
+
+
+class ToDevice:
+    """Uploads the raw frame ONCE: every listed numpy array (or cpu tensor) present in the dict becomes a cuda tensor of
+    the same dtype under the new key; the filters behind it (`Distortion`, `GridSample`) and the odometry then work on
+    device memory only.  Keys that are absent are skipped (a dataset without timestamps has no `numpy_pc_timestamps`)."""
+
+    def __init__(self, config: ToDeviceConfig, device=None, **kwargs):
+        self.config = config
+        dev = torch.device(device if device is not None and str(device) != "cpu" else config.device)
+        self.device = dev if dev.type == "cuda" else torch.device(config.device)
+
+    def filter(self, data_dict: dict):
+        for old_key, new_key in dict(self.config.keys).items():
+            if old_key not in data_dict:
+                continue
+            a = data_dict[old_key]
+            t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+            assert_debug(isinstance(t, torch.Tensor), f"cannot upload `{old_key}` of type {type(a)}")
+            data_dict[new_key] = t.to(self.device, non_blocking=True)
+
+
+@dataclass
+class ToTensorConfig:
+    """slam/preprocessing.py:101-107, plus an optional dtype for the renamed tensors."""
+    filter_name: str = "to_tensor_mi355x"
+    device: str = "cuda:0"
+    keys: Dict[str, str] = field(default_factory=dict)
+    dtype: str = ""  # e.g. "float32": what the odometry computes in (saves its own cast); "": keep the dtype
+
+
+class ToTensor:
+    """slam/preprocessing.py:110-126: numpy arrays -> tensors on the device under new keys; a tensor that already lives
+    on the device is handed over as it is (zero-copy)."""
+
+    def __init__(self, config: ToTensorConfig, device=None, **kwargs):
+        self.config = config
+        self.device = torch.device(device if device is not None else config.device)
+
+    def filter(self, data_dict: dict):
+        dtype = getattr(torch, self.config.dtype) if self.config.dtype else None
+        for old_key, new_key in dict(self.config.keys).items():
+            assert_debug(old_key in data_dict)
+            a = data_dict[old_key]
+            assert_debug(isinstance(a, (np.ndarray, torch.Tensor)))
+            t = torch.from_numpy(a) if isinstance(a, np.ndarray) else a
+            data_dict[new_key] = t.to(self.device, dtype) if dtype is not None else t.to(self.device)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -231,7 +300,7 @@ class DistortionConfig:
 class Distortion:
     """slam/preprocessing.py:144-191: de-skews a frame with the initial motion estimate (per-point slerp + linear
     translation by the normalised timestamp).  Pass-through (same array object) when deactivated, without timestamps or
-    without an initial pose, exactly as the reference."""
+    without an initial pose, exactly as the reference.  numpy in -> numpy out; cuda tensors in -> cuda tensor out."""
 
     def __init__(self, config: DistortionConfig, ctx: Optional[IcpContext] = None, **kwargs):
         self.config = config
@@ -240,7 +309,7 @@ class Distortion:
     def filter(self, data_dict: dict):
         c = self.config
         pc = data_dict[c.pointcloud_key]
-        assert_debug(isinstance(pc, np.ndarray), "Cannot Distort a non numpy frame")
+        assert_debug(isinstance(pc, np.ndarray) or _is_device_tensor(pc), "Cannot Distort a non numpy frame")
         assert_debug(pc.ndim == 2 and pc.shape[1] == 3, f"expected [N, 3], got {pc.shape}")
         no_distortion = not c.activate or (c.timestamps_key not in data_dict)
         no_distortion = no_distortion or (data_dict[c.pose_key] is None if c.pose_key in data_dict else False)
@@ -250,10 +319,13 @@ class Distortion:
         rpose = np.asarray(data_dict[c.pose_key])
         assert_debug(rpose.shape == (4, 4))
         timestamps = data_dict[c.timestamps_key]
-        assert_debug(isinstance(timestamps, np.ndarray))
+        assert_debug(isinstance(timestamps, (np.ndarray, torch.Tensor)))
         timestamps = timestamps.reshape(-1)
         assert_debug(timestamps.shape[0] == pc.shape[0])
-        data_dict[c.output_key] = (self._ctx or _shared_context()).distort(pc, timestamps, rpose)
+        ctx = self._ctx or _shared_context(pc.device if _is_device_tensor(pc) else None)
+        if _is_device_tensor(pc):
+            ctx.use_torch_stream()
+        data_dict[c.output_key] = ctx.distort(pc, timestamps, rpose)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -289,13 +361,53 @@ class NeighborhoodResult:
     new_target_points: Any = None
 
 
+def _is_context(obj) -> bool:
+    return hasattr(obj, "map_init") and hasattr(obj, "register")
+
+
+def _context_from(config, projector, device=None, **overrides) -> IcpContext:
+    """An `IcpContext` for an inner-seam object built by one of the reference's registries (`LOCAL_MAP.load(config,
+    pose=..., projector=...)`, `RIGID_ALIGNMENT.load(config, pose=...)`): the projector gives the image geometry."""
+    kw = dict(height=int(getattr(projector, "height", 64)), width=int(getattr(projector, "width", 1024)),
+              up_fov=float(getattr(projector, "up_fov", 3.0)), down_fov=float(getattr(projector, "down_fov", -24.0)))
+    if device is not None and getattr(device, "index", None) is not None:
+        kw["device"] = int(device.index)
+    kw.update(overrides)
+    return IcpContext(**kw)
+
+
+def _like(reference, array: np.ndarray):
+    """numpy result -> the kind (numpy / torch, device) of `reference`."""
+    if isinstance(reference, torch.Tensor):
+        return torch.from_numpy(np.ascontiguousarray(array)).to(reference.device)
+    return array
+
+
+@dataclass
+class HashGridLocalMapConfig:
+    """Registry config of `HashGridLocalMap` (LOCAL_MAP member `hashgrid_local_map_mi355x`); the fields of
+    `KdTreeLocalMapConfig` (slam/odometry/local_map.py:243-251)."""
+    type: str = "hashgrid_local_map_mi355x"
+    pose: str = "euler"
+    local_map_size: int = 20
+    num_neighbors_normals: int = 10
+
+
 class HashGridLocalMap:
     """Drop-in for `KdTreeLocalMap` (slam/odometry/local_map.py:254-427): a sliding window of the last
     `local_map_size` clouds, rebuilt (voxel-hash grid instead of a kd-tree) and with its lazy normal cache cleared on
-    every update; exact 1-NN with no distance cap."""
+    every update; exact 1-NN with no distance cap.  Built either around an existing context (`HashGridLocalMap(ctx)`,
+    what `MI355XICPFrameToModel` does) or the way the reference's `LOCAL_MAP.load` builds a local map:
+    `HashGridLocalMap(config, pose=..., projector=...)` (local_map.py:437-445, icp_odometry.py:93-94)."""
 
-    def __init__(self, ctx: IcpContext, **kwargs):
-        self.ctx = ctx
+    def __init__(self, config_or_ctx=None, projector=None, pose=None, device=None, **kwargs):
+        if _is_context(config_or_ctx):
+            self.ctx, self.config = config_or_ctx, None
+        else:
+            self.config = config_or_ctx if config_or_ctx is not None else HashGridLocalMapConfig()
+            self.ctx = _context_from(self.config, projector, device,
+                                     local_map_size=int(_get(self.config, "local_map_size", 20)),
+                                     num_neighbors_normals=int(_get(self.config, "num_neighbors_normals", 10)))
         self._last_count = 0
 
     def init(self):  # :279-288
@@ -326,14 +438,16 @@ class HashGridLocalMap:
 
     def nearest_neighbor_search(self, target_points, with_normals: bool = True, with_new_target_points: bool = True,
                                 **kwargs) -> NeighborhoodResult:  # :372-395
+        """Results live where the query lives: cuda tensors for a cuda tensor (zero-copy), cpu tensors for a cpu
+        tensor (the reference returns tensors on the query's device, :389-394), numpy for numpy."""
         is_torch = isinstance(target_points, torch.Tensor)
         assert_debug(target_points.ndim == 2 and target_points.shape[1] == 3)
         nb, nm, _ = self.ctx.nearest_neighbor_search(target_points, with_normals=with_normals)
         res = NeighborhoodResult()
         if is_torch:
-            res.neighbor_points = (nb if isinstance(nb, torch.Tensor) else torch.from_numpy(nb)).unsqueeze(0)
+            res.neighbor_points = (nb if isinstance(nb, torch.Tensor) else _like(target_points, nb)).unsqueeze(0)
             if with_normals:
-                res.neighbor_normals = (nm if isinstance(nm, torch.Tensor) else torch.from_numpy(nm)).unsqueeze(0)
+                res.neighbor_normals = (nm if isinstance(nm, torch.Tensor) else _like(target_points, nm)).unsqueeze(0)
             if with_new_target_points:
                 res.new_target_points = target_points.reshape(1, -1, 3)
         else:
@@ -347,17 +461,37 @@ class HashGridLocalMap:
         return torch.from_numpy(pts[pts.shape[0] - self._last_count:])
 
 
+@dataclass
+class ProjectiveLocalMapConfig:
+    """Registry config of `ProjectiveLocalMap` (LOCAL_MAP member `projective_local_map_mi355x`); the fields of the
+    reference's `ProjectiveLocalMapConfig` (slam/odometry/local_map.py:82-88)."""
+    type: str = "projective_local_map_mi355x"
+    pose: str = "euler"
+    local_map_size: int = 20
+    normals_kernel_size: int = 5
+
+
 class ProjectiveLocalMap:
     """Drop-in for `ProjectiveLocalMap` (slam/odometry/local_map.py:91-240), the reference's "GPU" local map: the last
     `local_map_size` vertex maps with box-filter normal maps, re-projected into the current frame on every update;
-    neighbours by per-pixel association over the stored maps."""
+    neighbours by per-pixel association over the stored maps.  `ProjectiveLocalMap(ctx, normals_kernel_size)` or, the
+    reference's registry form, `ProjectiveLocalMap(config, projector=..., pose=...)`."""
 
-    def __init__(self, ctx: IcpContext, normals_kernel_size: int = 5, **kwargs):
-        self.ctx = ctx
-        self.normals_kernel_size = normals_kernel_size
+    def __init__(self, config_or_ctx=None, normals_kernel_size: Optional[int] = None, projector=None, pose=None,
+                 device=None, **kwargs):
+        if _is_context(config_or_ctx):
+            self.ctx, self.config = config_or_ctx, None
+            self.normals_kernel_size = 5 if normals_kernel_size is None else int(normals_kernel_size)
+        else:
+            self.config = config_or_ctx if config_or_ctx is not None else ProjectiveLocalMapConfig()
+            self.ctx = _context_from(self.config, projector, device,
+                                     local_map_size=int(_get(self.config, "local_map_size", 20)))
+            self.normals_kernel_size = int(_get(self.config, "normals_kernel_size", 5))
+        self._last_vmap = None
 
     def init(self):  # :113-119
         self.ctx.pmap_init()
+        self._last_vmap = None
 
     def update(self, relative_pose, new_vertex_map=None, **kwargs):  # :122-174
         if isinstance(relative_pose, torch.Tensor):
@@ -368,6 +502,7 @@ class ProjectiveLocalMap:
         if new_vertex_map is not None:
             assert_debug(new_vertex_map.ndim == 4 and new_vertex_map.shape[0] == 1 and new_vertex_map.shape[1] == 3)
             self.ctx.pmap_update(rel, new_vertex_map[0], self.normals_kernel_size)
+            self._last_vmap = new_vertex_map[0]
         else:
             self.ctx.pmap_update(rel, None)
 
@@ -375,8 +510,10 @@ class ProjectiveLocalMap:
                                 **kwargs) -> NeighborhoodResult:  # :205-235
         assert_debug(target_points.ndim == 2 and target_points.shape[1] == 3)
         nb, nm, tg = self.ctx.pmap_nearest_neighbor_search(target_points)
-        is_torch = isinstance(target_points, torch.Tensor)
-        wrap = (lambda a: torch.from_numpy(a).unsqueeze(0)) if is_torch else (lambda a: a[None])
+        if isinstance(target_points, torch.Tensor):  # results on the query's device (cuda: straight from the kernel)
+            wrap = lambda a: (a if isinstance(a, torch.Tensor) else _like(target_points, a)).unsqueeze(0)
+        else:
+            wrap = lambda a: a[None]
         res = NeighborhoodResult()
         res.neighbor_points = wrap(nb)
         if with_normals:
@@ -385,41 +522,97 @@ class ProjectiveLocalMap:
             res.new_target_points = wrap(tg)
         return res
 
-    def get_last_frame(self):  # :238-240
-        raise NotImplementedError("the stored vertex maps stay on the device; use IcpContext.pmap_model()")
+    def get_last_frame(self):  # :238-240 — the points of the newest stored vertex map, [H*W, 3] (null pixels included)
+        assert_debug(self._last_vmap is not None, "the local map is empty")
+        vm = self._last_vmap
+        if isinstance(vm, torch.Tensor):
+            return vm.permute(1, 2, 0).reshape(-1, 3)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(vm).transpose(1, 2, 0).reshape(-1, 3)))
+
+
+@dataclass
+class PointToPlaneAlignmentConfig:
+    """Registry config of `PointToPlaneAlignment` (RIGID_ALIGNMENT member `point_to_plane_gauss_newton_mi355x`); the
+    fields of `GaussNewtonPointToPlaneConfig` (slam/odometry/alignment.py:69-77)."""
+    mode: str = "point_to_plane_gauss_newton_mi355x"
+    pose: str = "euler"
+    num_gn_iters: int = 1
+    gauss_newton_config: Dict[str, Any] = field(default_factory=lambda: dict(max_iters=1))
+
+
+@dataclass
+class PointToPointAlignmentConfig:
+    """Registry config of `PointToPointAlignment` (RIGID_ALIGNMENT member `point_to_point_gauss_newton_mi355x`); the
+    fields of `GNPointToPointConfig` (slam/odometry/alignment.py:131-140)."""
+    mode: str = "point_to_point_gauss_newton_mi355x"
+    pose: str = "euler"
+    num_gn_iters: int = 1
+    initialize_with_svd: bool = False
+    gauss_newton_config: Dict[str, Any] = field(default_factory=lambda: dict(max_iters=1))
+
+
+def _alignment_context(config, device) -> IcpContext:
+    gn = _get(config, "gauss_newton_config", {}) or {}
+    assert_debug(int(_get(gn, "max_iters", 1)) == 1,
+                 "the MI355X alignments run exactly one Gauss-Newton step per align() (gauss_newton_config.max_iters "
+                 "= 1, the reference's default)")
+    return _context_from(config, None, device, scheme=str(_get(gn, "scheme", "default")),
+                         sigma=float(_get(gn, "sigma", 0.5)))
+
+
+def _residuals_like(reference, residuals):
+    """[n] residuals -> [1, n] on the device / of the kind of `reference`."""
+    if isinstance(reference, torch.Tensor):
+        r = residuals if isinstance(residuals, torch.Tensor) else torch.from_numpy(residuals)
+        return r.to(reference.device).unsqueeze(0)
+    return np.asarray(residuals)[None]
 
 
 class PointToPlaneAlignment:
     """Drop-in for `GaussNewtonPointToPlaneAlignment.align` (slam/odometry/alignment.py:91-127): one Gauss-Newton
-    point-to-plane step from x0 = 0 on given correspondences; returns (pose [1,4,4], params [1,6], loss)."""
+    point-to-plane step from x0 = 0 on given correspondences; returns (pose [1,4,4], params [1,6], residuals [1,N] =
+    (w r)^2 per row) — torch tensors on the device of the inputs, like the reference (its caller multiplies the pose
+    with a tensor on that device and sums the residuals, icp_odometry.py:284-297), numpy for numpy inputs.
+    `PointToPlaneAlignment(ctx)` or, the reference's registry form, `PointToPlaneAlignment(config, pose=...)`."""
 
-    def __init__(self, ctx: IcpContext, **kwargs):
-        self.ctx = ctx
+    def __init__(self, config_or_ctx=None, pose=None, device=None, **kwargs):
+        if _is_context(config_or_ctx):
+            self.ctx, self.config = config_or_ctx, None
+        else:
+            self.config = config_or_ctx if config_or_ctx is not None else PointToPlaneAlignmentConfig()
+            self.ctx = _alignment_context(self.config, device)
 
-    def align(self, ref_points, tgt_points, ref_normals=None, **kwargs):
+    def align(self, ref_points, tgt_points, ref_normals=None, initial_estimate=None, mask=None, **kwargs):
         assert_debug(ref_normals is not None,
                      "The argument 'ref_normals' is required for a point to plane alignemnt")
-        is_torch = isinstance(ref_points, torch.Tensor)
+        assert_debug(initial_estimate is None and mask is None,
+                     "`initial_estimate` / `mask` are not supported by the MI355X point-to-plane alignment (the "
+                     "frame-to-model loop passes neither, icp_odometry.py:284-287)")
         r = ref_points.reshape(-1, 3)
         t = tgt_points.reshape(-1, 3)
         n = ref_normals.reshape(-1, 3)
-        pose, dx, loss, _ = self.ctx.align_point_to_plane(r, t, n)
-        if is_torch:
-            return torch.from_numpy(pose).unsqueeze(0), torch.from_numpy(dx).unsqueeze(0), loss
-        return pose[None], dx[None], loss
+        pose, dx, _, _, res = self.ctx.align_point_to_plane(r, t, n, with_residuals=True)
+        return _like(ref_points, pose[None]), _like(ref_points, dx[None]), _residuals_like(ref_points, res)
 
 
 class PointToPointAlignment:
     """Drop-in for `GaussNewtonPointToPointAlignment.align` (slam/odometry/alignment.py:143-189): one Gauss-Newton
     point-to-point step on given correspondences, linearised at `initial_estimate` (zeros by default; the Procrustes
-    solution when `initialize_with_svd`); returns (pose [1,4,4], params [1,6], loss)."""
+    solution when `initialize_with_svd`); returns (pose [1,4,4], params [1,6], residuals [1,N]) like the reference,
+    on the device of the inputs."""
 
-    def __init__(self, ctx: IcpContext, initialize_with_svd: bool = False, **kwargs):
-        self.ctx = ctx
-        self.initialize_with_svd = initialize_with_svd
+    def __init__(self, config_or_ctx=None, initialize_with_svd: Optional[bool] = None, pose=None, device=None, **kwargs):
+        if _is_context(config_or_ctx):
+            self.ctx, self.config = config_or_ctx, None
+            self.initialize_with_svd = bool(initialize_with_svd)
+        else:
+            self.config = config_or_ctx if config_or_ctx is not None else PointToPointAlignmentConfig()
+            self.ctx = _alignment_context(self.config, device)
+            self.initialize_with_svd = bool(_get(self.config, "initialize_with_svd", False)) \
+                if initialize_with_svd is None else bool(initialize_with_svd)
 
-    def align(self, ref_points, tgt_points, initial_estimate=None, **kwargs):
-        is_torch = isinstance(ref_points, torch.Tensor)
+    def align(self, ref_points, tgt_points, initial_estimate=None, mask=None, **kwargs):
+        assert_debug(mask is None, "`mask` is not supported by the MI355X point-to-point alignment")
         r = ref_points.reshape(-1, 3)
         t = tgt_points.reshape(-1, 3)
         x0 = None
@@ -430,10 +623,8 @@ class PointToPointAlignment:
                 np.asarray(initial_estimate)
             x0 = from_pose_matrix(est.reshape(4, 4).astype(np.float32)) if est.size == 16 else \
                 est.reshape(6).astype(np.float32)
-        pose, params, loss, _ = self.ctx.align_point_to_point(r, t, x0)
-        if is_torch:
-            return torch.from_numpy(pose).unsqueeze(0), torch.from_numpy(params).unsqueeze(0), loss
-        return pose[None], params[None], loss
+        pose, params, _, _, res = self.ctx.align_point_to_point(r, t, x0, with_residuals=True)
+        return _like(ref_points, pose[None]), _like(ref_points, params[None]), _residuals_like(ref_points, res)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -482,12 +673,24 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         assert_debug(projector is not None)
         self.projector = projector
         lm = config.local_map
-        self._projective = _get(lm, "type", "kdtree_local_map") == "projective_local_map"
-        assert_debug(self._projective or _get(lm, "type", "kdtree_local_map") == "kdtree_local_map",
+        lm_type = str(_get(lm, "type", "kdtree_local_map")).replace("_mi355x", "")
+        self._projective = lm_type == "projective_local_map"
+        assert_debug(self._projective or lm_type in ("kdtree_local_map", "hashgrid_local_map"),
                      f"unknown local map type {_get(lm, 'type')}")
         gn = _get(config.alignment, "gauss_newton_config", {}) or {}
-        assert_debug(_get(config.alignment, "mode", "point_to_plane_gauss_newton") == "point_to_plane_gauss_newton",
-                     "only the point-to-plane Gauss-Newton alignment is implemented on the MI355X path")
+        mode = str(_get(config.alignment, "mode", "point_to_plane_gauss_newton")).replace("_mi355x", "")
+        assert_debug(mode in ("point_to_plane_gauss_newton", "point_to_point_gauss_newton"),
+                     f"unknown alignment mode {mode} (RIGID_ALIGNMENT, slam/odometry/alignment.py:200-208)")
+        # options the device loop does not implement are refused, not ignored
+        assert_debug(int(_get(gn, "max_iters", 1)) == 1,
+                     "gauss_newton_config.max_iters must be 1: every ICP iteration runs one Gauss-Newton step "
+                     "(the reference's configurations, config/slam/odometry/alignment/*.yaml)")
+        self._point_to_point = mode == "point_to_point_gauss_newton"
+        assert_debug(not (self._point_to_point and self._projective),
+                     "the point-to-point alignment runs against the kd-tree style local map only")
+        assert_debug(not (self._point_to_point and bool(_get(config.alignment, "initialize_with_svd", False))),
+                     "initialize_with_svd is available at the RigidAlignment seam (PointToPointAlignment), not inside "
+                     "the device-resident loop")
         dev_index = 0
         if device is not None and getattr(device, "index", None) is not None:
             dev_index = device.index
@@ -501,7 +704,11 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self.device = self.ctx.device
         self.local_map = ProjectiveLocalMap(self.ctx, int(_get(lm, "normals_kernel_size", 5))) if self._projective \
             else HashGridLocalMap(self.ctx)
-        self.rigid_alignment = PointToPlaneAlignment(self.ctx)
+        if self._point_to_point:
+            self.ctx.set_cost("point_to_point_gauss_newton")
+            self.rigid_alignment = PointToPointAlignment(self.ctx)
+        else:
+            self.rigid_alignment = PointToPlaneAlignment(self.ctx)
         self.gn_max_iters = config.max_num_alignments
         self._sample_pointcloud = False
         self.relative_poses: List[np.ndarray] = []

@@ -102,7 +102,7 @@ def test_kitti_sequence_round_trip(tmp_path):
     np.testing.assert_allclose(item["numpy_pc"], want, atol=1e-6)
     assert item["numpy_pc"].dtype == np.float32
     vm = item["vertex_map"]
-    assert vm.is_cuda and tuple(vm.shape) == (3, 16, 256)
+    assert not vm.is_cuda and tuple(vm.shape) == (3, 16, 256)  # CPU items: the reference DataLoader pins them
     ovm = O.build_projection_map(item["numpy_pc"], 16, 256, 3.0, -24.0)
     assert (np.abs(vm.cpu().numpy() - ovm).max(axis=0) > 0).sum() <= 2
     # ground truth comes back in the lidar frame

@@ -598,7 +598,9 @@ def test_point_to_point_alignment(torch_cuda, O, name):
     scheme, sigma, svd = g[f"{name}_cfg"]
     ctx = _ctx(scheme=str(scheme), sigma=float(sigma))
     algo = PointToPointAlignment(ctx, initialize_with_svd=bool(int(svd)))
-    pose, params, loss = algo.align(g["ref"], g["tgt"])
+    pose, params, residuals = algo.align(g["ref"], g["tgt"])
+    assert residuals.shape == (1, g["ref"].shape[0])  # the residual vector (w r)^2 per row, like the reference
+    loss = float(residuals.astype(np.float64).sum())
     # vs the reference's own float32 result (its normal equations are float32, ours float64)
     np.testing.assert_allclose(params[0], g[f"{name}_params"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(pose[0], g[f"{name}_pose"], atol=5e-5)
@@ -610,8 +612,10 @@ def test_point_to_point_alignment(torch_cuda, O, name):
     np.testing.assert_allclose(loss, l64, rtol=1e-5)
     # device-resident inputs give the same bits
     r_t, t_t = torch_cuda.from_numpy(g["ref"]).cuda(), torch_cuda.from_numpy(g["tgt"]).cuda()
-    pose_d, params_d, _ = algo.align(r_t[None], t_t[None])
-    assert np.array_equal(params_d[0].numpy(), params[0])
+    pose_d, params_d, res_d = algo.align(r_t[None], t_t[None])
+    assert params_d.is_cuda and res_d.is_cuda  # results live where the inputs live
+    assert np.array_equal(params_d[0].cpu().numpy(), params[0])
+    assert np.array_equal(res_d.cpu().numpy(), residuals)
 
 
 def test_weighted_procrustes(torch_cuda, O):

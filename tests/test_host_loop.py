@@ -9,57 +9,7 @@ import torch
 import icp_oracle as O
 
 
-class OracleContext:
-    """`IcpContext` protocol used by MI355XICPFrameToModel / HashGridLocalMap, computed by oracle/icp_oracle.py."""
-    device = torch.device("cpu")
-
-    def __init__(self, height, width, up_fov, down_fov, max_num_alignments, threshold_delta_pose, scheme, sigma,
-                 local_map_size, num_neighbors_normals, **kwargs):
-        self.hw = (int(height), int(width), float(up_fov), float(down_fov))
-        self.lm = O.KdTreeLocalMapOracle(local_map_size, num_neighbors_normals, workers=1)
-        self.reg = O.ICPFrameToModelOracle(O.ICPOracleConfig(
-            max_num_alignments=max_num_alignments, threshold_delta_pose=threshold_delta_pose, scheme=scheme, sigma=sigma,
-            height=height, width=width, local_map_size=local_map_size))
-        self.reg.local_map = self.lm
-        self.calls = []
-
-    def use_torch_stream(self):
-        pass
-
-    @staticmethod
-    def _np(a):
-        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-
-    def project(self, pc, **kwargs):
-        h, w, up, down = self.hw
-        return torch.from_numpy(O.build_projection_map(self._np(pc).reshape(-1, 3).astype(np.float32), h, w, up, down))
-
-    def map_init(self):
-        self.lm.init()
-
-    def map_update(self, rel_pose, new_points=None, skip_null=False):
-        self.calls.append("insert" if new_points is not None else "move")
-        pts = None if new_points is None else self._np(new_points).reshape(-1, 3)
-        if pts is not None and skip_null:
-            pts = pts[np.abs(pts).max(axis=1) > 0]
-        self.lm.update(np.asarray(rel_pose, np.float32), pts)
-        return 0 if pts is None else int(pts.shape[0])
-
-    def map_update_vertex_map(self, rel_pose, vmap):
-        self.calls.append("insert_vmap")
-        self.lm.update(np.asarray(rel_pose, np.float32), None, self._np(vmap))
-        return int(self.lm.num_elements[-1])
-
-    def register(self, points, init_pose=None, skip_null=False):
-        from pylidar_slam_amd.engine import RegisterResult
-        pts = self._np(points).reshape(-1, 3).astype(np.float32)
-        pts = pts[~np.isnan(pts).any(axis=1)]
-        if skip_null:
-            pts = pts[np.abs(pts).max(axis=1) > 0]
-        init = np.eye(4, dtype=np.float32) if init_pose is None else np.asarray(init_pose, np.float32)
-        params, pose = self.reg.register_new_frame(pts, init)
-        tr = self.reg.traces[-1]
-        return RegisterResult(pose, params, len(tr.dx), False, pts.shape[0], 0, np.array(tr.loss), np.array(tr.dx))
+from oracle_context import OracleContext  # noqa: E402
 
 
 @pytest.mark.parametrize("run", ["A_numpy_ls", "B_tensor_gm"])
