@@ -253,6 +253,17 @@ void* icp_normal_equations_ptr(icp_ctx* ctx); /* device pointer, 32 doubles */
 /* use caller-owned device memory (e.g. a torch tensor RCCL can reduce in place) for the 32-double vector */
 int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
 
+/* ---- multi-GPU, map-sharded normal estimation (BASELINE configs[3]: 1M-point map over 8 GPUs) ------
+ * KdTreeLocalMap.__get_normals (slam/odometry/local_map.py:397-422) costs O(map) per map update once the map is much
+ * larger than the scan.  Every rank keeps the whole map (queries stay local) but estimates only the normals of the points
+ * whose 1-metre spatial bucket hashes to it: icp_map_normals_owned fills normals_by_index [M,4] float (device memory of
+ * the caller, e.g. a torch tensor; nx, ny, nz, 1 at the ORIGINAL index of every owned point, zeros elsewhere), the
+ * caller sums the arrays of all ranks (one RCCL all-reduce: every index has exactly one non-zero contribution, so the
+ * sum is exact) and icp_map_normals_install scatters the result into this rank's normal cache, after which
+ * registrations run the fused path.  world = 1 reduces to the eager single-GPU estimation (same values). */
+int icp_map_normals_owned(icp_ctx* ctx, int32_t rank, int32_t world, float* normals_by_index);
+int icp_map_normals_install(icp_ctx* ctx, const float* normals_by_index);
+
 /* ---- profiling hooks ---------------------------------------------------------------------------------------------
  * Accumulated HIP-event time (ms) and launch count of the dominant kernel (the per-iteration nearest-neighbour
  * search) since the last reset; measured on the context's stream.  `enable` is a bit mask: 1 = search kernel,

@@ -1360,6 +1360,23 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
     return ICP_OK;
 }
 
+// ---- map-sharded normals --------------------------------------------------------------------------------------------
+int icp_map_normals_owned(icp_ctx* ctx, int32_t rank, int32_t world, float* normals_by_index) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !normals_by_index || world < 1 || rank < 0 || rank >= world) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    return launch_normals_owned(ctx, rank, world, normals_by_index);
+}
+
+int icp_map_normals_install(icp_ctx* ctx, const float* normals_by_index) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !normals_by_index) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    return launch_normals_install(ctx, normals_by_index);
+}
+
 // ---- profiling ------------------------------------------------------------------------------------------------------
 int icp_profile_enable(icp_ctx* ctx, int enable) {
     DeviceGuard device_guard(ctx);

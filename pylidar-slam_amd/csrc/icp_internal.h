@@ -237,6 +237,9 @@ int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, qu
 int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
 int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager mode)
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
+// map-sharded normals: the owned share by original index (zeros elsewhere) / install the all-reduced array
+int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev);
+int launch_normals_install(icp_ctx* ctx, const float* by_index_dev);
 // before a grid rebuild: nn_cache of the last registration -> seeds of the next frame (`evicted` oldest points dropped;
 // indices_survive = false when the map is replaced wholesale)
 int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive);

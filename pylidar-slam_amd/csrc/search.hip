@@ -881,6 +881,56 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Map-sharded normal estimation (multi-GPU, SURVEY.md §8e "Map-sharded"; BASELINE configs[3]: 1M-point map on 8 GPUs).
+// Every rank holds the whole map and its grid (the 1-NN queries stay local), but estimates the normals only of the
+// points whose spatial bucket it owns; the results travel BY ORIGINAL MAP INDEX (the cell-sorted order differs from rank
+// to rank: the counting sort's within-cell order is not deterministic), are summed over the ranks by one collective
+// (every index has exactly one owner, the other ranks contribute zeros: the sum is exact) and scattered back into the
+// rank's own cell-sorted normal cache.  Ownership must not depend on anything rank-local (the auto-tuned cell edge is):
+// it is the hash of the point's 1-metre bucket.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline int bucket_owner(float x, float y, float z, int world) {
+    const unsigned long long key = pack_cell(cell_coord(x, 1.0f), cell_coord(y, 1.0f), cell_coord(z, 1.0f));
+    return (int)(hash_cell(key) % (unsigned)world);
+}
+
+template <int KN, int NL>
+__global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int max_rings, int rank, int world,
+                                                               float4* __restrict__ by_index) {
+    constexpr int PTS = NRM_THREADS / NL;
+    __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
+    __shared__ float covs[PTS][7];
+    __shared__ int owned[PTS];
+    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
+    const int s = blockIdx.x * PTS + lq;
+    bool mine = false;
+    if (s < g.m) {
+        const float4 P = g.pts[s];
+        mine = bucket_owner(P.x, P.y, P.z, world) == rank;  // group-uniform
+        if (mine) estimate_cov<KN, NL>(g, s, sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+    }
+    if (sub == 0) owned[lq] = mine ? 1 : 0;
+    __syncthreads();
+    const int s2 = blockIdx.x * PTS + threadIdx.x;
+    if (threadIdx.x < PTS && s2 < g.m && owned[threadIdx.x]) {
+        float nx, ny, nz;
+        const float* c = covs[threadIdx.x];
+        smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
+        by_index[__float_as_int(g.pts[s2].w)] = make_float4(nx, ny, nz, 1.f);
+    }
+}
+
+// normals by original index -> this rank's cell-sorted cache
+__global__ void k_normals_install(const float4* __restrict__ pts, int m, const float4* __restrict__ by_index,
+                                  float4* __restrict__ normals, int* __restrict__ nflag) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    const float4 n = by_index[__float_as_int(pts[s].w)];
+    normals[s] = make_float4(n.x, n.y, n.z, 1.f);
+    nflag[s] = 1;
+}
+
 // generic k (rare): top-k list in scratch memory
 __global__ __launch_bounds__(128) void k_normals_generic(GridView g, RegState* __restrict__ st,
                                                          const int* __restrict__ worklist, int kn,
@@ -1073,6 +1123,40 @@ int launch_normals_all(icp_ctx* ctx) {
     else
         launch_normals_all_t<4>(ctx, kn, g);
     prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    ctx->normals_ready = true;
+    ctx->normals_eager_count += ctx->map_m;
+    return ICP_OK;
+}
+
+int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev) {
+    const int kn = ctx->cfg.num_neighbors_normals + 1;
+    if (kn != 11 && kn != 6 && kn != 21) {
+        ctx->error = "map-sharded normals support num_neighbors_normals = 5, 10 or 20";
+        return ICP_ERR_INVALID_ARGUMENT;
+    }
+    const int64_t m = ctx->map_m;
+    ICP_HIP(ctx, hipMemsetAsync(by_index_dev, 0, (size_t)m * sizeof(float4), ctx->stream));
+    const GridView g = make_view(ctx);
+    const int blocks = (int)((m + NRM_THREADS / 4 - 1) / (NRM_THREADS / 4));
+    const int rings = knn_fine_rings(ctx);
+    float4* out = (float4*)by_index_dev;
+    const int tok = prof_begin(ctx, 2);
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals_owned<11, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals_owned<6, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
+    else
+        hipLaunchKernelGGL((k_normals_owned<21, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int launch_normals_install(icp_ctx* ctx, const float* by_index_dev) {
+    const int m = (int)ctx->map_m;
+    hipLaunchKernelGGL(k_normals_install, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
+                       m, (const float4*)by_index_dev, ctx->normals.as<float4>(), ctx->nflag.as<int>());
     ICP_HIP(ctx, hipGetLastError());
     ctx->normals_ready = true;
     ctx->normals_eager_count += ctx->map_m;

@@ -70,6 +70,8 @@ EXPORTED_SYMBOLS = {
     "icp_set_option": (_INT, [_P, C.c_char_p, C.c_double]),
     "icp_set_alignment": (_INT, [_P, C.c_int32, C.c_float, C.c_int32, C.c_float]),
     "icp_set_cost": (_INT, [_P, C.c_int32]),
+    "icp_map_normals_owned": (_INT, [_P, C.c_int32, C.c_int32, _P]),
+    "icp_map_normals_install": (_INT, [_P, _P]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_project_pixels": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_kitti_correct_scan": (_INT, [_P, _P, _I64, _INT, _INT, _P, _INT]),

@@ -538,6 +538,22 @@ class IcpContext:
                                            C.byref(res), losses, dxs))
         return self._result(res, losses, dxs)
 
+    # ---- multi-GPU: map-sharded normals ------------------------------------------------------------------------------
+    def map_normals_owned(self, rank: int, world: int) -> torch.Tensor:
+        """[M,4] float32 device tensor: (nx, ny, nz, 1) at the original index of every map point whose spatial bucket
+        this rank owns, zeros elsewhere — to be summed over the ranks and handed to `map_normals_install`."""
+        self.use_torch_stream()
+        out = torch.empty((self.map_size(), 4), dtype=torch.float32, device=self.device)
+        self._check(self._lib.icp_map_normals_owned(self._h, int(rank), int(world), out.data_ptr()))
+        return out
+
+    def map_normals_install(self, normals_by_index: torch.Tensor):
+        self.use_torch_stream()
+        t = normals_by_index.to(self.device, torch.float32).contiguous()
+        if tuple(t.shape) != (self.map_size(), 4):
+            raise AssertionError(f"expected [{self.map_size()}, 4] normals, got {tuple(t.shape)}")
+        self._check(self._lib.icp_map_normals_install(self._h, t.data_ptr()))
+
     # ---- multi-GPU seam ----------------------------------------------------------------------------------------------
     def normal_equations_tensor(self) -> torch.Tensor:
         """A torch-owned [32] f64 device vector installed as the context's normal-equation buffer, so that

@@ -72,6 +72,20 @@ class OracleEngine:
     def register_end(self):
         return self.pose.copy(), np.array(self.losses)
 
+    # map-sharded normals (engine protocol of `sharded_map_normals`): ownership by index parity stands in for the spatial
+    # bucket hash of the HIP engine — the driver only relies on "every index has exactly one owner"
+    def map_normals_owned(self, rank, world):
+        m = self.lm.model.shape[0]
+        out = torch.zeros((m, 4), dtype=torch.float32)
+        mine = np.arange(m)[np.arange(m) % world == rank]
+        out[mine, :3] = torch.from_numpy(self.O.knn_normals(self.lm.model, self.lm.tree, mine, self.lm.k)
+                                         .astype(np.float32))
+        out[mine, 3] = 1.0
+        return out
+
+    def map_normals_install(self, normals_by_index):
+        self.installed = normals_by_index.clone()
+
 
 def _workload():
     from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
@@ -86,10 +100,15 @@ def _worker(rank, world, port, out):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pylidar_slam_amd.distributed import shard_bounds, sharded_register
+    from pylidar_slam_amd.distributed import shard_bounds, sharded_map_normals, sharded_register
     model, scan = _workload()
     b, e = shard_bounds(scan.shape[0], world, rank)
     eng = OracleEngine(model, iters=4)
+    sharded_map_normals(eng)  # owner-computed normals, summed by original index over the ranks
+    assert float(eng.installed[:, 3].min()) == 1.0 and float(eng.installed[:, 3].max()) == 1.0
+    full = torch.from_numpy(eng.O.knn_normals(eng.lm.model, eng.lm.tree, np.arange(model.shape[0]), eng.lm.k)
+                            .astype(np.float32))
+    assert torch.equal(eng.installed[:, :3], full)  # exactly the single-process normals on every rank
     pose, losses = sharded_register(eng, scan[b:e], None, 4)
     gathered = [torch.zeros(16, dtype=torch.float32) for _ in range(world)]
     dist.all_gather(gathered, torch.from_numpy(pose.reshape(-1).copy()))
