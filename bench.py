@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--scheme", default="geman_mcclure")
     ap.add_argument("--sigma", type=float, default=0.3)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
+    ap.add_argument("--exchange", choices=["library", "collective"], default="library",
+                    help="--mode sharded: exchange of the normal equations per ICP iteration inside the library "
+                         "(icp_exchange_*: peer-written inboxes, the whole loop enqueued by one icp_register_launch) or "
+                         "by a torch.distributed all-reduce driven from the host (RCCL with the nccl backend)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--init", choices=["cv", "identity"], default="cv",
                     help="initial guess per frame: constant velocity = last relative pose (the reference's default, "
@@ -157,6 +161,10 @@ class Tracker:
             b, e = shard_bounds(self.n_pts, world, rank)
             self.slices = {f: s[b:e].contiguous() for f, s in self.scans.items()}
             self.n_local = e - b
+            self.in_library = False
+            if args.exchange == "library":
+                from pylidar_slam_amd.distributed import connect_exchange
+                self.in_library = connect_exchange(self.ctx)
         self.last = None
         self.cursor = 0
         self.max_err = 0.0
@@ -166,6 +174,10 @@ class Tracker:
     def step(self, f, init):
         ctx, scan = self.ctx, self.scans[f]
         ctx.project(scan, out=self.vmap)
+        if self.slices is not None and self.in_library:
+            ctx.register_launch(self.slices[f], init)  # per iteration: iteration kernel + sum / exchange / solve kernel
+            ctx.map_update(None, None)                 # every rank re-expresses its replica by the identical pose
+            return ctx.register_end()
         if self.slices is not None:
             from pylidar_slam_amd.distributed import sharded_register
             res = sharded_register(ctx, self.slices[f], init, self.args.iters)
@@ -372,7 +384,8 @@ def main():
                                    "iterations, frame = projection + registration + map re-expression/rebuild",
                        "scheme": args.scheme, "sigma": args.sigma, "cell_size_m": args.cell_size,
                        "trajectory": args.trajectory, "init": args.init, "options": args.option,
-                       "parallelism": ("points-sharded + exchange of the 6x6 normal equations per iteration" if sharded
+                       "parallelism": (f"points-sharded + exchange of the 6x6 normal equations per iteration "
+                                       f"({args.exchange})" if sharded
                                        else f"{world * S} independent sequences, {S} per GPU (replicated map, no "
                                             "collective)")},
             "ms_per_step_spread": {"min": sm[0], "median": sm[len(sm) // 2], "p90": sm[int(0.9 * (len(sm) - 1))],

@@ -33,7 +33,8 @@ typedef enum {
     ICP_ERR_INVALID_JACOBIAN = -3, /* RuntimeError("Invalid Jacobian in Gauss Newton minimization"),
                                       slam/common/optimization.py:334-336 (|det H| < 1e-7) */
     ICP_ERR_EMPTY_MAP = -4,        /* nearest-neighbour search against an empty local map */
-    ICP_ERR_NO_DEVICE = -5         /* no gfx950 device visible: the product path never falls back to the CPU */
+    ICP_ERR_NO_DEVICE = -5,        /* no gfx950 device visible: the product path never falls back to the CPU */
+    ICP_ERR_EXCHANGE = -6          /* multi-GPU exchange: a peer did not deliver its normal equations in time */
 } icp_status;
 
 typedef enum { ICP_MEM_HOST = 0, ICP_MEM_DEVICE = 1 } icp_mem;
@@ -110,6 +111,7 @@ int icp_synchronize(icp_ctx* ctx);
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
+ *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 (0)
  * The library reads no environment variables. */
 int icp_set_option(icp_ctx* ctx, const char* name, double value);
@@ -252,6 +254,24 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
 void* icp_normal_equations_ptr(icp_ctx* ctx); /* device pointer, 32 doubles */
 /* use caller-owned device memory (e.g. a torch tensor RCCL can reduce in place) for the 32-double vector */
 int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
+
+/* ---- multi-GPU exchange inside the library ("one-shot P2P write+flag all-reduce") -----------------
+ * The per-iteration exchange of the scan-sharded registration without leaving the library: after these three calls
+ * icp_register / icp_register_launch on every rank enqueue, per ICP iteration, the iteration kernel and ONE kernel that
+ * sums this rank's partial rows, writes the 32 doubles into every peer's inbox over xGMI, waits for all ranks'
+ * contributions, adds them in rank order and solves — identical poses on all ranks, no host involvement, no RCCL call.
+ *   icp_exchange_create  allocates this rank's inbox (uncached device memory) and returns its IPC handle (64 bytes,
+ *                        hipIpcMemHandle_t) for the caller to all-gather over its own side channel (torch.distributed
+ *                        `all_gather_object`, MPI, a file);
+ *   icp_exchange_connect opens the `world` handles (rank order; the own entry is ignored) and switches the context to
+ *                        exchange mode; every rank must then issue the same sequence of registrations;
+ *   icp_exchange_destroy leaves exchange mode and releases the mappings.
+ * A peer that does not deliver within the budget (option "exchange_timeout_ms", default 5000) ends the registration
+ * with ICP_ERR_EXCHANGE instead of hanging the GPU.  world <= 16. */
+#define ICP_EXCHANGE_HANDLE_BYTES 64
+int icp_exchange_create(icp_ctx* ctx, int32_t rank, int32_t world, void* handle_out);
+int icp_exchange_connect(icp_ctx* ctx, const void* handles);
+int icp_exchange_destroy(icp_ctx* ctx);
 
 /* ---- multi-GPU, map-sharded normal estimation (BASELINE configs[3]: 1M-point map over 8 GPUs) ------
  * KdTreeLocalMap.__get_normals (slam/odometry/local_map.py:397-422) costs O(map) per map update once the map is much

@@ -269,6 +269,8 @@ static int init_state(icp_ctx* ctx, const float* init_pose) {
     return ICP_OK;
 }
 
+static void exchange_release(icp_ctx* ctx);
+
 // ---- lifecycle ------------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -337,6 +339,8 @@ void icp_destroy(icp_ctx* ctx) {
     if (ctx->host_result) (void)hipHostFree(ctx->host_result);
     if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
     if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
+    exchange_release(ctx);
+    ctx->x_seq.release();
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -372,6 +376,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
+    else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
         ctx->search_stats = iv != 0;
@@ -1288,6 +1293,8 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     if (ctx->prof.enabled) prof_collect(ctx);
     if (st.status == ICP_ERR_INVALID_JACOBIAN)
         return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
+    if (st.status == ICP_ERR_EXCHANGE)
+        return fail(ctx, ICP_ERR_EXCHANGE, "multi-GPU exchange: a peer did not deliver its normal equations in time");
     return st.status;
 }
 
@@ -1357,6 +1364,71 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr) {
     int rc = ensure_state(ctx);
     if (rc) return rc;
     ctx->neq = device_ptr ? (double*)device_ptr : ctx->neq_own.as<double>();
+    return ICP_OK;
+}
+
+// ---- in-library exchange --------------------------------------------------------------------------------------------
+static void exchange_release(icp_ctx* ctx) {
+    for (int r = 0; r < EXCHANGE_MAX_RANKS; ++r) {
+        if (ctx->x_peer[r]) (void)hipIpcCloseMemHandle(ctx->x_peer[r]);
+        ctx->x_peer[r] = nullptr;
+    }
+    if (ctx->x_inbox) (void)hipFree(ctx->x_inbox);
+    ctx->x_inbox = nullptr;
+    ctx->exchange_on = false;
+}
+
+int icp_exchange_create(icp_ctx* ctx, int32_t rank, int32_t world, void* handle_out) {
+    DeviceGuard device_guard(ctx);
+    static_assert(sizeof(hipIpcMemHandle_t) == ICP_EXCHANGE_HANDLE_BYTES, "IPC handle size");
+    if (!ctx || !handle_out || world < 1 || world > EXCHANGE_MAX_RANKS || rank < 0 || rank >= world)
+        return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration || ctx->result_pending) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    exchange_release(ctx);
+    const size_t bytes = (size_t)2 * world * sizeof(ExchangeSlot);
+    ICP_HIP(ctx, hipExtMallocWithFlags(&ctx->x_inbox, bytes, hipDeviceMallocUncached));
+    ICP_HIP(ctx, hipMemset(ctx->x_inbox, 0, bytes));
+    ICP_HIP(ctx, ctx->x_seq.reserve(64));
+    ICP_HIP(ctx, hipMemset(ctx->x_seq.ptr, 0, 64));
+    ICP_HIP(ctx, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    ICP_HIP(ctx, hipIpcGetMemHandle(&h, ctx->x_inbox));
+    memcpy(handle_out, &h, sizeof(h));
+    memset(&ctx->xview, 0, sizeof(ctx->xview));
+    ctx->xview.rank = rank;
+    ctx->xview.world = world;
+    ctx->xview.seq = ctx->x_seq.as<unsigned long long>();
+    ctx->xview.inbox[rank] = (ExchangeSlot*)ctx->x_inbox;
+    return ICP_OK;
+}
+
+int icp_exchange_connect(icp_ctx* ctx, const void* handles) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !handles) return ICP_ERR_INVALID_ARGUMENT;
+    if (!ctx->x_inbox) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "icp_exchange_create first");
+    const int world = ctx->xview.world, rank = ctx->xview.rank;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)r * ICP_EXCHANGE_HANDLE_BYTES, sizeof(h));
+        void* p = nullptr;
+        ICP_HIP(ctx, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        ctx->x_peer[r] = p;
+        ctx->xview.inbox[r] = (ExchangeSlot*)p;
+    }
+    ctx->exchange_on = true;
+    return ICP_OK;
+}
+
+int icp_exchange_destroy(icp_ctx* ctx) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration || ctx->result_pending) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    exchange_release(ctx);
     return ICP_OK;
 }
 

@@ -560,6 +560,89 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-GPU: final sum + ALL-REDUCE over the ranks + solve in one launch (icp_exchange_*).
+//
+// The message is 256 bytes: an RCCL ring all-reduce costs tens of microseconds of latency per ICP iteration and — driven
+// from the host — three enqueues and a stream hand-off.  Here the block that has just summed this rank's partial rows
+// writes its 32 doubles into slot [parity][rank] of every rank's inbox (its own included; peers' inboxes are mapped
+// through IPC, the stores travel over xGMI as system-scope write-through stores), drains them, publishes the tag,
+// waits for the `world` tags of this exchange in its OWN inbox (relaxed system-scope polls with s_sleep, bounded by a
+// wall-clock budget) and adds the slots in RANK ORDER, so every rank forms the identical sum and applies the identical
+// solve: poses stay bit-identical across ranks without a broadcast.
+// Slot reuse: parity = exchange number & 1.  A rank can write exchange s + 2 only after it completed s + 1, which needs
+// this rank's s + 1 contribution, which is sent after this rank has read every slot of s: two parities suffice.
+// On a timeout (a peer died or never launched) the registration stops with ICP_ERR_EXCHANGE; later launches are no-ops.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __restrict__ partials, int nblocks,
+                                                             RegState* __restrict__ st, AlignParams ap,
+                                                             double* __restrict__ neq, double* __restrict__ loss_hist,
+                                                             float* __restrict__ dx_hist, int hist_cap,
+                                                             ExchangeView x) {
+    const int done = st->done;
+    int it = 0;
+    float pose_in[16];
+    if (threadIdx.x < 64) {
+        it = st->iter;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+    }
+    __shared__ double total[NEQ];
+    __shared__ int arrived;
+    sum_partials_block(partials, nblocks, total);
+    if (threadIdx.x == 0) arrived = 1;
+    __syncthreads();
+    if (done) return;  // identical on every rank (same state after the same solves): nobody exchanges
+    const unsigned long long seq = *x.seq + 1;  // number of THIS exchange (1, 2, ..): identical on every rank
+    const int par = (int)(seq & 1ull);
+    // ---- publish: payload into every inbox, drained, then the tags
+    if ((int)threadIdx.x < NEQ * x.world) {
+        const int p = threadIdx.x / NEQ, e = threadIdx.x % NEQ;
+        __hip_atomic_store(&x.inbox[p][par * x.world + x.rank].v[e], total[e], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < x.world) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&x.inbox[threadIdx.x][par * x.world + x.rank].tag, seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        // ---- wait for rank `threadIdx.x`'s contribution in the own inbox
+        const ExchangeSlot* mine = &x.inbox[x.rank][par * x.world + threadIdx.x];
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&mine->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (wall_clock64() - t0 > x.timeout_ticks) {
+                arrived = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    if (!arrived) {  // block-uniform
+        if (threadIdx.x == 0) {
+            st->status = ICP_ERR_EXCHANGE;
+            st->done = 1;
+            st->iter = it + 1;
+        }
+        return;
+    }
+    // ---- the same fixed-order sum on every rank
+    if (threadIdx.x < NEQ) {
+        double s = 0.0;
+        for (int r = 0; r < x.world; ++r)
+            s += __hip_atomic_load(&x.inbox[x.rank][par * x.world + r].v[threadIdx.x], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        total[threadIdx.x] = s;
+        neq[threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) *x.seq = seq;
+    __syncthreads();
+    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
+}
+
 // align() on given correspondences: writes params = x0 + dx [6], pose[16] = build_pose_matrix(params) (f32) and loss
 // into `out` (device, 6 + 16 floats; loss double)
 struct Params6 {
@@ -611,9 +694,17 @@ int launch_reduce(icp_ctx* ctx) {
 
 // final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
 int launch_sum_solve(icp_ctx* ctx, int blocks) {
-    hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
-                       ctx->dx_hist, ctx->hist_cap);
+    if (ctx->exchange_on) {
+        ExchangeView x = ctx->xview;
+        x.timeout_ticks = (long long)(ctx->exchange_timeout_ms * 1.0e5);  // 100 MHz
+        hipLaunchKernelGGL(k_sum_exchange_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(),
+                           blocks, reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
+                           ctx->hist_cap, x);
+    } else {
+        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+                           reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
+                           ctx->hist_cap);
+    }
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -633,10 +724,9 @@ int launch_reduce_solve(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        make_align_params(ctx), ctx->partials.as<double>());
-    hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                       reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
-                       ctx->dx_hist, ctx->hist_cap);
+    const int rc = launch_sum_solve(ctx, blocks);
     prof_end(ctx, tok);
+    if (rc) return rc;
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -723,11 +813,10 @@ int launch_reduce_p2p(icp_ctx* ctx, bool solve) {
     hipLaunchKernelGGL(k_reduce_p2p_nn, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx), linearise_euler(nullptr),
                        make_align_params(ctx), ctx->partials.as<double>());
-    if (solve)
-        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
-                           reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
-                           ctx->hist_cap);
-    else
+    if (solve) {
+        const int rc = launch_sum_solve(ctx, blocks);
+        if (rc) return rc;
+    } else
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
                            reg_state(ctx), 1, ctx->neq);
     prof_end(ctx, tok);

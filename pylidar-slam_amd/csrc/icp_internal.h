@@ -89,6 +89,25 @@ struct RegState {
 
 static constexpr size_t STATE_BLOCK = 256;  // bytes reserved for the RegState at the head of the state allocation
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-GPU exchange of the packed normal equations inside the library (include/icp_mi355x.h, icp_exchange_*): every
+// rank owns an INBOX in its own HBM with one slot per rank and parity; a rank publishes its 32 doubles by writing them
+// straight into slot [parity][its rank] of EVERY peer's inbox (peer-mapped over xGMI) followed by a tag, then waits for
+// the tags of all ranks in its own inbox and adds the slots up in rank order — the same sum on every rank, bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int EXCHANGE_MAX_RANKS = 16;
+struct alignas(64) ExchangeSlot {
+    double v[32];
+    unsigned long long tag;  // sequence number of the exchange the payload belongs to (0: never written)
+    unsigned long long pad[7];
+};
+struct ExchangeView {
+    ExchangeSlot* inbox[EXCHANGE_MAX_RANKS];  // inbox[r] = rank r's inbox ([2][world] slots) as mapped in THIS process
+    unsigned long long* seq;                  // device counter of completed exchanges (own memory)
+    int rank, world;
+    long long timeout_ticks;                  // 100 MHz wall-clock ticks to wait for the peers
+};
+
 struct AlignParams {
     int scheme;
     float sigma;
@@ -200,6 +219,13 @@ struct icp_ctx {
     void* host_result = nullptr;
     size_t host_result_bytes = 0;
     hipEvent_t result_event = nullptr;
+    // ---- in-library multi-GPU exchange (icp_exchange_*)
+    bool exchange_on = false;
+    icp::ExchangeView xview{};
+    void* x_inbox = nullptr;          // own inbox (uncached device memory, exported through IPC)
+    void* x_peer[icp::EXCHANGE_MAX_RANKS] = {};  // peers' inboxes opened through IPC (nullptr for the own rank)
+    icp::DeviceBuffer x_seq;
+    double exchange_timeout_ms = 5000.0;  // option "exchange_timeout_ms"
     hipEvent_t switch_event = nullptr;  // orders a change of stream (icp_set_stream) behind the work of the old one
     // ---- scratch for projection / sampling / io
     icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
@@ -248,7 +274,7 @@ int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive);
 AlignParams make_align_params(const icp_ctx* ctx);
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
-int launch_sum_solve(icp_ctx* ctx, int blocks);
+int launch_sum_solve(icp_ctx* ctx, int blocks);  // (with an exchange connected: + the all-reduce over the ranks)
 int launch_sum_partials(icp_ctx* ctx, int blocks);
 // fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
 int launch_iterate_fused(icp_ctx* ctx, int* blocks_out);

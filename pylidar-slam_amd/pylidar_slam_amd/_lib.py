@@ -23,6 +23,7 @@ ICP_ERR_HIP = -2
 ICP_ERR_INVALID_JACOBIAN = -3
 ICP_ERR_EMPTY_MAP = -4
 ICP_ERR_NO_DEVICE = -5
+ICP_ERR_EXCHANGE = -6
 
 STATUS_MESSAGES = {
     ICP_ERR_INVALID_ARGUMENT: "invalid argument",
@@ -30,6 +31,7 @@ STATUS_MESSAGES = {
     ICP_ERR_INVALID_JACOBIAN: "Invalid Jacobian in Gauss Newton minimization",
     ICP_ERR_EMPTY_MAP: "the local map is empty",
     ICP_ERR_NO_DEVICE: "no MI355X (gfx950) device visible — the MI355X ICP path has no CPU fallback",
+    ICP_ERR_EXCHANGE: "multi-GPU exchange: a peer did not deliver its normal equations in time",
 }
 
 # names of the reference's `_LS_SCHEME` members (slam/common/optimization.py:210-226) -> icp_scheme
@@ -70,6 +72,9 @@ EXPORTED_SYMBOLS = {
     "icp_set_option": (_INT, [_P, C.c_char_p, C.c_double]),
     "icp_set_alignment": (_INT, [_P, C.c_int32, C.c_float, C.c_int32, C.c_float]),
     "icp_set_cost": (_INT, [_P, C.c_int32]),
+    "icp_exchange_create": (_INT, [_P, C.c_int32, C.c_int32, _P]),
+    "icp_exchange_connect": (_INT, [_P, _P]),
+    "icp_exchange_destroy": (_INT, [_P]),
     "icp_map_normals_owned": (_INT, [_P, C.c_int32, C.c_int32, _P]),
     "icp_map_normals_install": (_INT, [_P, _P]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),

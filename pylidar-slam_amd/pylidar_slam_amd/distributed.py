@@ -11,7 +11,7 @@ The reference has no multi-GPU code at all; this is the MI355X-side addition.
 """
 from typing import Optional, Tuple
 
-__all__ = ["shard_bounds", "sharded_register", "sharded_map_normals", "NEQ_SIZE"]
+__all__ = ["shard_bounds", "sharded_register", "sharded_map_normals", "connect_exchange", "NEQ_SIZE"]
 
 NEQ_SIZE = 32
 
@@ -25,9 +25,29 @@ def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
     return begin, min(n, begin + per)
 
 
+def connect_exchange(engine, group=None) -> bool:
+    """Switches `engine` (an `IcpContext`) to the in-library exchange: the IPC handles of the per-rank inboxes are
+    all-gathered over `group` once, after which `engine.register(local_points, ...)` alone registers a scan that is
+    sharded over the ranks — per ICP iteration ONE kernel sums this rank's rows, writes them into every peer's inbox
+    over xGMI, waits for the others and solves (`k_sum_exchange_solve`), with no collective call and no host step in the
+    loop.  Returns False (and changes nothing) when torch.distributed is not initialised or the world size is 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    handle = engine.exchange_create(rank, world)
+    handles = [None] * world
+    dist.all_gather_object(handles, handle, group=group)
+    engine.exchange_connect(handles)
+    dist.barrier(group)  # every inbox is mapped everywhere before the first registration writes into one
+    return True
+
+
 def sharded_register(engine, local_points, init_pose=None, iterations: Optional[int] = None, group=None,
                      skip_null: bool = False):
-    """Registers one scan whose rows are spread over the ranks of `group`.
+    """Registers one scan whose rows are spread over the ranks of `group` with a torch.distributed all-reduce (RCCL
+    with backend "nccl") per iteration — the portable driver; `connect_exchange` + `engine.register` is the one that
+    keeps the whole loop on the devices.
 
     `engine` is an `IcpContext` (or anything with the same five calls): register_begin / iteration_accumulate /
     normal_equations_tensor / iteration_solve / register_end.  `local_points` is this rank's slice of the scan.

@@ -22,6 +22,10 @@ class InvalidJacobianError(RuntimeError):
     """RuntimeError("Invalid Jacobian in Gauss Newton minimization") of slam/common/optimization.py:336."""
 
 
+class ExchangeTimeoutError(RuntimeError):
+    """A peer rank did not deliver its normal equations within `exchange_timeout_ms` (in-library multi-GPU exchange)."""
+
+
 @dataclass
 class RegisterResult:
     pose: np.ndarray  # [4,4] f32
@@ -104,6 +108,8 @@ class IcpContext:
             raise InvalidJacobianError("Invalid Jacobian in Gauss Newton minimization")
         if rc == _lib.ICP_ERR_INVALID_ARGUMENT:
             raise AssertionError(msg)
+        if rc == _lib.ICP_ERR_EXCHANGE:
+            raise ExchangeTimeoutError(msg)
         raise RuntimeError(f"libicp_mi355x: {msg} ({rc})")
 
     def use_torch_stream(self):
@@ -537,6 +543,22 @@ class IcpContext:
         self._check(self._lib.icp_register(self._h, p, n, mem, TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init,
                                            C.byref(res), losses, dxs))
         return self._result(res, losses, dxs)
+
+    # ---- multi-GPU: exchange of the normal equations inside the library ----------------------------------------------
+    def exchange_create(self, rank: int, world: int) -> bytes:
+        """Allocates this rank's inbox; returns its 64-byte IPC handle, to be all-gathered by the caller."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.icp_exchange_create(self._h, int(rank), int(world), buf))
+        return bytes(buf.raw)
+
+    def exchange_connect(self, handles):
+        """`handles`: the `world` handles in rank order.  From here on every registration on this context exchanges its
+        normal equations with the peers inside the library (all ranks must issue the same registrations)."""
+        blob = b"".join(bytes(h) for h in handles)
+        self._check(self._lib.icp_exchange_connect(self._h, C.c_char_p(blob)))
+
+    def exchange_destroy(self):
+        self._check(self._lib.icp_exchange_destroy(self._h))
 
     # ---- multi-GPU: map-sharded normals ------------------------------------------------------------------------------
     def map_normals_owned(self, rank: int, world: int) -> torch.Tensor:

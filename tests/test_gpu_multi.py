@@ -170,3 +170,75 @@ def test_hip_engine_world_size_2_on_one_gpu(torch_cuda, tmp_path):
     np.testing.assert_allclose(got["pose"], ref.pose, atol=1e-6)
     np.testing.assert_allclose(got["losses"], ref.losses, rtol=1e-9)
     np.testing.assert_allclose(got["dx"], ref.dx, atol=1e-7)
+
+
+# ---- in-library exchange (peer-written inboxes instead of a collective) ---------------------------------------------
+def _rank_main_exchange(rank, world, port, out):
+    for p in (os.path.join(ROOT, "pylidar-slam_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pylidar_slam_amd.distributed import connect_exchange, shard_bounds, sharded_map_normals
+    from pylidar_slam_amd.engine import ExchangeTimeoutError, IcpContext
+    model, scan = _small_problem()
+    ctx = IcpContext(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                     sigma=0.3)
+    ctx.set_option("exchange_timeout_ms", 4000)
+    ctx.map_set(torch.from_numpy(model).cuda())
+    sharded_map_normals(ctx)
+    assert connect_exchange(ctx)
+    b, e = shard_bounds(scan.shape[0], world, rank)
+    mine = torch.from_numpy(scan[b:e]).cuda()
+    res = ctx.register(mine)            # ONE call: every iteration and its exchange enqueued by the library
+    res2 = ctx.register(mine, res.pose)  # a second registration: the exchange numbering carries on
+    poses = [torch.zeros(16) for _ in range(world)]
+    dist.all_gather(poses, torch.from_numpy(res2.pose.reshape(-1).copy()))
+    timed_out = False
+    dist.barrier()
+    if rank == 0:  # the peer does not take part in a third registration: bounded wait, clean error, no hang
+        ctx.set_option("exchange_timeout_ms", 300)
+        try:
+            ctx.register(mine)
+        except ExchangeTimeoutError:
+            timed_out = True
+        np.savez(out, pose=res.pose, losses=res.losses, dx=res.dx, pose2=res2.pose,
+                 all=np.stack([p.numpy() for p in poses]), targets=res.num_targets, timed_out=timed_out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_library_exchange_world_size_2_on_one_gpu(torch_cuda, tmp_path):
+    """The per-iteration exchange behind the C ABI (icp_exchange_*): two processes on the one GPU map each other's
+    inbox through IPC, `icp_register` on each rank enqueues iteration kernel + sum/exchange/solve kernel per iteration,
+    nothing else.  Same bits on both ranks, the single-process result up to the association of the float64 sums, and a
+    peer that stays away produces ICP_ERR_EXCHANGE after the configured wait instead of a hung GPU."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    mp.start_processes(_rank_main_exchange, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    assert np.array_equal(got["all"][0], got["all"][1])
+    assert bool(got["timed_out"])
+    model, scan = _small_problem()
+    single = _ctx(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                  sigma=0.3)
+    single.map_set(model)
+    ref = single.register(scan)
+    assert int(got["targets"]) == scan.shape[0] and len(got["losses"]) == 10
+    np.testing.assert_allclose(got["pose"], ref.pose, atol=1e-6)
+    np.testing.assert_allclose(got["losses"], ref.losses, rtol=1e-9)
+    np.testing.assert_allclose(got["pose2"], single.register(scan, ref.pose).pose, atol=1e-6)
+    # world size 1 through the same kernel = the plain registration, bit for bit
+    solo = _ctx(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                sigma=0.3)
+    solo.map_set(model)
+    solo.exchange_connect([solo.exchange_create(0, 1)])
+    r = solo.register(scan)
+    assert np.array_equal(r.pose, ref.pose) and np.array_equal(r.losses, ref.losses)
+    solo.exchange_destroy()
+    assert np.array_equal(solo.register(scan).pose, ref.pose)
