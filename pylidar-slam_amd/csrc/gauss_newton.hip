@@ -11,6 +11,7 @@
 // (bit-reproducible run to run).  No MFMA: this is a gather + reduce, not a dense contraction.
 #include "gn_device.h"
 #include "icp_internal.h"
+#include "solve_device.h"
 
 namespace icp {
 
@@ -309,225 +310,6 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // K4: solve + pose update (one thread)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float sy, float cz, float sz, float* R);
-
-__device__ inline void euler_to_mat_f32(float ex, float ey, float ez, float* R) {
-    euler_trig_to_mat_f32(cosf(ex), sinf(ex), cosf(ey), sinf(ey), cosf(ez), sinf(ez), R);
-}
-
-__device__ inline void build_pose_f32(const float* p, float* T) {  // slam/common/pose.py:120-144
-    float R[9];
-    euler_to_mat_f32(p[3], p[4], p[5], R);
-    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = p[0];
-    T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = p[1];
-    T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
-    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
-}
-
-// Cholesky H = L L^T in f64 with fully unrolled static indexing (everything stays in registers): returns det(H)
-// (0 if a pivot is not positive: H = J^T J is PSD, so that only happens for a numerically singular system) and solves
-// H x = b.
-__device__ inline double solve6(double A[6][6], double* b, double* x) {
-    double L[6][6], rinv[6];
-    double det = 1.0;
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double d = A[j][j];
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (k < j) d -= L[j][k] * L[j][k];
-        if (!(d > 0.0)) ok = false;
-        const double ljj = sqrt(d);
-        L[j][j] = ljj;
-        det *= d;
-        const double inv = 1.0 / ljj;
-        rinv[j] = inv;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (i > j) {
-                double v = A[i][j];
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    if (k < j) v -= L[i][k] * L[j][k];
-                L[i][j] = v * inv;
-            }
-        }
-    }
-    double y[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = b[i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (k < i) v -= L[i][k] * y[k];
-        y[i] = v * rinv[i];  // 1 / L[i][i], already formed for the column scaling
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double v = y[i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (k > i) v -= L[k][i] * x[k];
-        x[i] = v * rinv[i];
-    }
-    return ok ? det : 0.0;
-}
-
-// Solves one Gauss-Newton step from the packed normal equations.  Returns status; dx (f32) and loss are written.
-__device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double* loss, int* stopped) {
-    *stopped = 0;
-    const double r2 = neq[28];
-    if (sqrt(r2) < 1.0e-7) {  // optimization.py:323-327: return x unchanged, loss = res * res (unweighted)
-        for (int a = 0; a < 6; ++a) dx[a] = 0.f;
-        *loss = r2;
-        *stopped = 1;
-        return ICP_OK;
-    }
-    double H[6][6], g[6], x[6];
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = a; b < 6; ++b) {
-            H[a][b] = neq[k];
-            H[b][a] = neq[k];
-            ++k;
-        }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) g[a] = neq[21 + a];
-    const double det = solve6(H, g, x);
-    *loss = neq[27];
-    if (!(fabs(det) >= 1.0e-7)) {  // optimization.py:334-336 (also catches NaN)
-        for (int a = 0; a < 6; ++a) dx[a] = 0.f;
-        return ICP_ERR_INVALID_JACOBIAN;
-    }
-    for (int a = 0; a < 6; ++a) dx[a] = (float)(-x[a]);  // dx = -H^-1 J^T r (:338)
-    return ICP_OK;
-}
-
-// rotation matrix from the sines / cosines of the three Euler angles: Rz(ez) @ Ry(ey) @ Rx(ex)
-// (torch_euler_to_mat, slam/common/rotation.py:144-150), float32
-__device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float sy, float cz, float sz, float* R) {
-    const float a00 = cy, a01 = sy * sx, a02 = sy * cx;
-    const float a10 = 0.f, a11 = cx, a12 = -sx;
-    const float a20 = -sy, a21 = cy * sx, a22 = cy * cx;
-    R[0] = cz * a00 - sz * a10;
-    R[1] = cz * a01 - sz * a11;
-    R[2] = cz * a02 - sz * a12;
-    R[3] = sz * a00 + cz * a10;
-    R[4] = sz * a01 + cz * a11;
-    R[5] = sz * a02 + cz * a12;
-    R[6] = a20;
-    R[7] = a21;
-    R[8] = a22;
-}
-
-// sines and cosines of three angles, one angle per lane (lane % 3), gathered into every lane of the wave: three
-// independent libm chains run side by side instead of six calls in a row on one lane
-__device__ inline void wave_sincos3(float e0, float e1, float e2, float* sn, float* cs) {
-    const int a = (int)(threadIdx.x & 63) % 3;
-    const float ang = a == 0 ? e0 : (a == 1 ? e1 : e2);
-    const float s = sinf(ang), c = cosf(ang);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        sn[k] = __shfl(s, k, 64);
-        cs[k] = __shfl(c, k, 64);
-    }
-}
-
-__device__ inline void wave_build_pose_f32(const float* p, float* T) {  // slam/common/pose.py:120-144
-    float sn[3], cs[3], R[9];
-    wave_sincos3(p[3], p[4], p[5], sn, cs);
-    euler_trig_to_mat_f32(cs[0], sn[0], cs[1], sn[1], cs[2], sn[2], R);
-    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = p[0];
-    T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = p[1];
-    T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p[2];
-    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
-}
-
-__device__ inline void wave_from_pose_f32(const float* T, float* p) {  // pose.py:188-207, rotation.py:253-270
-    const float r00 = T[0], r10 = T[4], r20 = T[8], r21 = T[9], r22 = T[10], r11 = T[5], r12 = T[6];
-    const float sy = sqrtf(r00 * r00 + r10 * r10);
-    const bool regular = !(sy < 1.0e-6f);
-    const int a = (int)(threadIdx.x & 63) % 3;  // one atan2 per lane
-    float y, x;
-    if (a == 0) {
-        y = regular ? r21 : -r12;
-        x = regular ? r22 : r11;
-    } else if (a == 1) {
-        y = -r20;
-        x = sy;
-    } else {
-        y = r10;
-        x = r00;
-    }
-    const float e = atan2f(y, x);
-    p[0] = T[3];
-    p[1] = T[7];
-    p[2] = T[11];
-    p[3] = __shfl(e, 0, 64);
-    p[4] = __shfl(e, 1, 64);
-    p[5] = regular ? __shfl(e, 2, 64) : 0.f;
-}
-
-// One Gauss-Newton step + the pose update of register_new_frame, executed by ALL 64 lanes of one wave: the f64 Cholesky
-// runs redundantly (identical in every lane), the trigonometry of the pose algebra — most of the serial time — is
-// spread one angle per lane; lane 0 writes the state.  `it` / `pose_in`: st->iter and st->pose as read by the caller
-// (k_sum_solve fetches them while the partial rows are still in flight).
-__device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
-                                        double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
-                                        int it, const float* pose_in) {
-    const bool writer = (threadIdx.x & 63) == 0;
-    float dx[6];
-    double loss;
-    int stopped;
-    const int status = gauss_newton_from_neq(neq, dx, &loss, &stopped);
-    if (writer) {
-        st->n_worklist = 0;
-        st->n_targets = (int)neq[29];
-        if (it < hist_cap) {
-            loss_hist[it] = loss;
-            for (int a = 0; a < 6; ++a) dx_hist[6 * it + a] = dx[a];
-        }
-        st->iter = it + 1;
-    }
-    if (status != ICP_OK) {
-        if (writer) {
-            st->status = status;
-            st->done = 1;
-        }
-        return;
-    }
-    // if delta_pose.norm() < threshold: break     (icp_odometry.py:292) — also taken by the residual guard (dx = 0)
-    float nrm2 = 0.f;
-    for (int a = 0; a < 6; ++a) nrm2 += dx[a] * dx[a];
-    if (sqrtf(nrm2) < ap.threshold_delta_pose || stopped) {
-        if (writer) {
-            st->done = 1;
-            st->converged = 1;
-        }
-        return;
-    }
-    // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
-    float D[16], P[16], prm[6], T[16];
-    wave_build_pose_f32(dx, D);
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            float s = 0.f;
-            for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * pose_in[4 * k2 + c];
-            P[4 * r + c] = s;
-        }
-    wave_from_pose_f32(P, prm);
-    wave_build_pose_f32(prm, T);
-    if (writer) {
-        for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = pose_in[k2];
-        for (int a = 0; a < 6; ++a) st->params[a] = prm[a];
-        for (int k2 = 0; k2 < 16; ++k2) st->pose[k2] = T[k2];
-        if (it + 1 >= ap.max_iters) st->done = 1;
-    }
-}
-
 __global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
                                               double* __restrict__ loss_hist, float* __restrict__ dx_hist,
                                               int hist_cap) {

@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused iteration kernel (every needed normal is ready): the search above + the point-to-plane row of each query +
 // the per-block partial normal equations, in one launch — no nn_pos round trip, no second pass over the targets.
+// (Measured and dropped in round 2: solving iteration k in the prologue of launch k + 1 — every workgroup redundantly,
+// group rows published with agent-scope stores and a ticket per 32 workgroups — instead of the separate single-block
+// sum-and-solve launch: 638 vs 516 + 154 us per frame of kernel time, no gain in frame time, 11 % slower with four
+// sequences per GPU.  The solve launch costs 5.4 us with ONE partial row and 7.9 us with 1024: it is launch and
+// cold-load latency, which moving the work does not remove.)
 // 128 queries per block: their 9-float rows go to LDS, then 4 x 30 threads each own one packed element of a quarter of
 // the queries and add up its products in f64 in a fixed order (bit-reproducible), one partial row per block.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -697,6 +702,9 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
                 }
             }
         } else {
+            // (looking the surviving shell cells up four at a time — 4 table loads in flight instead of one dependent probe
+            // after the other — was measured in round 2: the extra live registers cost two waves of occupancy, 227 vs
+            // 181 us)
             const int side = 2 * r + 1, total = side * side * side;
             for (int c = sub; c < total; c += NL) {
                 const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
