@@ -1,10 +1,11 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel from PMC counters (separate passes, --kernel-trace only; MI355X_MICROARCH.md §HBM)
 # usage: tools/pmc.sh <kernel-name-substring>  -> gpurun_out/pmc_<name>.json
-R=$PWD; K=${1:-k_search}
+R=$PWD; K=${1:-k_iterate_compact}
+HEAD_SHA=$(cat $R/gpurun_out/.head_sha 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 100 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $R/gpurun_out/pmc_$C.log 2>&1
+  timeout 100 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --loop-steps 0 > $R/gpurun_out/pmc_$C.log 2>&1
 done
 cd $R && python - <<PY
 import csv, glob, json
@@ -18,7 +19,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals.append(float(row["Counter_Value"]))
     out[c] = {"launches": len(vals), "mean": sum(vals) / max(1, len(vals))}
 fetch_kb, write_kb = out["FETCH_SIZE"]["mean"], out["WRITE_SIZE"]["mean"]
-res = {"kernel": "$K", "counters": out, "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3, separate "
+res = {"kernel": "$K", "head": "$HEAD_SHA",
+       "workload": "bench.py default (C2, untracked-map ping-pong), 6 timed frames = 120 launches",
+       "counters": out, "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3, separate "
        "--pmc passes). gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B requests at 64 B for "
        "16-B-per-lane loads, which is what every load of this kernel is (float4 targets, float4 map points / normals, int2 "
        "rows) -> doubled; WRITE_SIZE is uncalibrated and taken as is. Infinity-Cache hits are counted, so this is "
