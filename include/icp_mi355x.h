@@ -248,6 +248,13 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
  * ICPFrameToModel.__update_map, icp_odometry.py:379) overlaps the host's wait in icp_register_end, which then blocks on
  * the registration only.  With threshold_delta_pose > 0 the launches behind an early stop are device-side no-ops. */
 int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]);
+/* the same with the initial guess = the pose of the previous registration on this context, READ ON THE DEVICE: the
+ * constant-velocity initialisation (`ConstantVelocityInitialization`, slam/initialization.py:103-119 — the last relative
+ * pose) without the host in the loop.  Up to two launched registrations may await their icp_register_end (which returns
+ * them oldest first), so a frame loop can enqueue frame t + 1 (and the map update by the device-resident pose of frame
+ * t) before it has collected the pose of frame t: the GPU never idles between frames while the host still receives
+ * every pose, one frame later. */
+int icp_register_launch_from_last(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode);
 int icp_iteration_accumulate(icp_ctx* ctx); /* search + normals + reduce into the 32-double device vector */
 int icp_iteration_solve(icp_ctx* ctx);      /* 6x6 solve + pose update from the (possibly all-reduced) vector */
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);

@@ -73,9 +73,11 @@ struct Pose16 {
     float m[16];
 };
 
-__global__ void k_state_init(RegState* st, Pose16 init) {
+// keep_pose: the initial guess is the pose the state already holds — the result of the previous registration, i.e. the
+// constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip
+__global__ void k_state_init(RegState* st, Pose16 init, int keep_pose) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = init.m[k];
+    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = keep_pose ? st->pose[k] : init.m[k];
     for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
     st->iter = 0;
     st->done = 0;
@@ -256,7 +258,7 @@ static int ensure_state(icp_ctx* ctx) {
     return ICP_OK;
 }
 
-static int init_state(icp_ctx* ctx, const float* init_pose) {
+static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = false) {
     Pose16 p;
     if (init_pose) {
         memcpy(p.m, init_pose, sizeof(p.m));
@@ -264,7 +266,7 @@ static int init_state(icp_ctx* ctx, const float* init_pose) {
         memset(p.m, 0, sizeof(p.m));
         p.m[0] = p.m[5] = p.m[10] = p.m[15] = 1.f;
     }
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -336,8 +338,10 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig};
     for (DeviceBuffer* b : bufs) b->release();
-    if (ctx->host_result) (void)hipHostFree(ctx->host_result);
-    if (ctx->result_event) (void)hipEventDestroy(ctx->result_event);
+    for (auto& r : ctx->rslot) {
+        if (r.host) (void)hipHostFree(r.host);
+        if (r.event) (void)hipEventDestroy(r.event);
+    }
     if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
     exchange_release(ctx);
     ctx->x_seq.release();
@@ -747,7 +751,7 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     DeviceGuard device_guard(ctx);
     if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
-    if (ctx->in_registration || ctx->result_pending)
+    if (ctx->in_registration || ctx->result_pending())
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -1127,11 +1131,13 @@ int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* 
 }
 
 // ---- registration ---------------------------------------------------------------------------------------------------
-int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
-                       const float init_pose[16]) {
-    DeviceGuard device_guard(ctx);
+static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
+                          const float init_pose[16], bool from_last) {
     if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    if (from_last && !ctx->have_device_pose)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "no previous registration on this context to start from");
     int rc = ensure_state(ctx);
     if (rc) return rc;
     const void* in;
@@ -1141,7 +1147,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
     if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
-    if ((rc = init_state(ctx, init_pose))) return rc;
+    if ((rc = init_state(ctx, init_pose, from_last))) return rc;
     ctx->have_device_pose = true;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
@@ -1151,6 +1157,13 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     return ICP_OK;
+}
+
+int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
+                       const float init_pose[16]) {
+    DeviceGuard device_guard(ctx);
+    if (ctx && ctx->result_pending()) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "collect the pending result first");
+    return register_begin(ctx, xyz, n, mem, target_mode, init_pose, false);
 }
 
 // the fused search + rows kernel needs every normal it may touch: the eager schedule
@@ -1185,59 +1198,72 @@ static size_t state_bytes(const icp_ctx* ctx) {
     return STATE_BLOCK + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
 }
 
-// the grid statistics about to be read back belong to the current build; a later build starts a new pending set
-static void snapshot_stats(icp_ctx* ctx) {
-    ctx->stats_at_launch = ctx->stats_pending;
-    ctx->stats_m_at_launch = ctx->stats_m_pending;
-    ctx->stats_h_at_launch = ctx->stats_h_pending;
-    ctx->stats_pending = false;
-}
-
 static int enqueue_result_copy(icp_ctx* ctx) {
+    if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
+    icp_ctx::ResultSlot& r = ctx->rslot[(ctx->r_head + ctx->r_count) & 1];
     const size_t sb = state_bytes(ctx), need = sb + 16;
-    if (need > ctx->host_result_bytes) {
-        if (ctx->host_result) (void)hipHostFree(ctx->host_result);
-        ctx->host_result = nullptr;
-        ctx->host_result_bytes = 0;
-        ICP_HIP(ctx, hipHostMalloc(&ctx->host_result, need, hipHostMallocDefault));
-        ctx->host_result_bytes = need;
+    if (need > r.bytes) {
+        if (r.host) (void)hipHostFree(r.host);
+        r.host = nullptr;
+        r.bytes = 0;
+        ICP_HIP(ctx, hipHostMalloc(&r.host, need, hipHostMallocDefault));
+        r.bytes = need;
     }
-    if (!ctx->result_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->result_event, hipEventDisableTiming));
-    char* h = (char*)ctx->host_result;
+    if (!r.event) ICP_HIP(ctx, hipEventCreateWithFlags(&r.event, hipEventDisableTiming));
+    char* h = (char*)r.host;
     ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));  // state + histories
-    snapshot_stats(ctx);
-    if (ctx->stats_at_launch)
-        ICP_HIP(ctx, hipMemcpyAsync(h + sb, ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
-    ICP_HIP(ctx, hipEventRecord(ctx->result_event, ctx->stream));
-    ctx->result_pending = true;
+    // the grid statistics about to be read back belong to the current build; a later build starts a new pending set
+    r.stats = ctx->stats_pending;
+    r.stats_m = ctx->stats_m_pending;
+    r.stats_h = ctx->stats_h_pending;
+    ctx->stats_pending = false;
+    if (r.stats) ICP_HIP(ctx, hipMemcpyAsync(h + sb, ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
+    r.eager_normals = ctx->normals_eager_count;
+    ctx->normals_eager_count = 0;
+    ctx->r_count += 1;
     return ICP_OK;
 }
 
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx);
-    if (!ctx || !ctx->in_registration || !result) return ICP_ERR_INVALID_ARGUMENT;
-    ctx->in_registration = false;
+    if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
     RegState st;
     int stats[4] = {0, 0, 0, 0};
-    const bool async = ctx->result_pending;
-    if (!async) snapshot_stats(ctx);
-    const bool had_stats = ctx->stats_at_launch;
-    if (async) {  // copies were enqueued right behind the last iteration: wait for those only
-        ctx->result_pending = false;
-        ICP_HIP(ctx, hipEventSynchronize(ctx->result_event));
-        memcpy(&st, ctx->host_result, sizeof(st));
-        memcpy(stats, (const char*)ctx->host_result + state_bytes(ctx), sizeof(stats));
+    const bool async = ctx->result_pending();
+    bool had_stats;
+    int64_t stats_m, eager;
+    float stats_h;
+    const char* pinned = nullptr;
+    if (async) {  // copies were enqueued right behind the last iteration: wait for those only (the OLDEST result)
+        icp_ctx::ResultSlot& r = ctx->rslot[ctx->r_head];
+        ctx->r_head ^= 1;
+        ctx->r_count -= 1;
+        ICP_HIP(ctx, hipEventSynchronize(r.event));
+        pinned = (const char*)r.host;
+        memcpy(&st, pinned, sizeof(st));
+        memcpy(stats, pinned + state_bytes(ctx), sizeof(stats));
+        had_stats = r.stats;
+        stats_m = r.stats_m;
+        stats_h = r.stats_h;
+        eager = r.eager_normals;
     } else {
+        ctx->in_registration = false;
+        had_stats = ctx->stats_pending;
+        stats_m = ctx->stats_m_pending;
+        stats_h = ctx->stats_h_pending;
+        ctx->stats_pending = false;
+        eager = ctx->normals_eager_count;
+        ctx->normals_eager_count = 0;
         ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         if (had_stats)
             ICP_HIP(ctx, hipMemcpyAsync(stats, ctx->grid_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (ctx->stats_at_launch) {
+    if (had_stats) {
         ctx->occupied_cells = stats[0];
-        ctx->stats_m = ctx->stats_m_at_launch;
-        ctx->stats_h = ctx->stats_h_at_launch;
-        ctx->stats_at_launch = false;
+        ctx->stats_m = stats_m;
+        ctx->stats_h = stats_h;
     }
     if (ctx->search_stats) {
         std::vector<char> raw(DBG_BYTES);
@@ -1269,8 +1295,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
             (void)hipMemset(ctx->dbg_counts.ptr, 0, DBG_BYTES);
         }
     }
-    st.normals_computed += ctx->normals_eager_count;
-    ctx->normals_eager_count = 0;
+    st.normals_computed += eager;
     memcpy(result->pose, st.pose, sizeof(st.pose));
     memcpy(result->params, st.params, sizeof(st.params));
     result->iterations = st.iter;
@@ -1280,7 +1305,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     result->normals_computed = st.normals_computed;
     const int k = st.iter < ctx->hist_cap ? st.iter : ctx->hist_cap;
     if (async) {
-        const char* lh = (const char*)ctx->host_result + STATE_BLOCK;
+        const char* lh = pinned + STATE_BLOCK;
         if (k > 0 && loss_per_iter_out) memcpy(loss_per_iter_out, lh, (size_t)k * sizeof(double));
         if (k > 0 && dx_per_iter_out)
             memcpy(dx_per_iter_out, lh + (size_t)ctx->hist_cap * sizeof(double), (size_t)k * 6 * sizeof(float));
@@ -1327,18 +1352,27 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
     return ICP_OK;
 }
 
-int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]) {
-    DeviceGuard device_guard(ctx);
+static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
+                           const float init_pose[16], bool from_last) {
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
-    int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
+    if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
+    int rc = register_begin(ctx, xyz, n, mem, target_mode, init_pose, from_last);
     if (rc) return rc;
     // every iteration is enqueued; launches behind an early stop see `done` on the device and return immediately
-    if ((rc = enqueue_iterations(ctx, false))) return rc;
-    if ((rc = enqueue_result_copy(ctx))) {
-        ctx->in_registration = false;
-        return rc;
-    }
-    return ICP_OK;
+    rc = enqueue_iterations(ctx, false);
+    if (!rc) rc = enqueue_result_copy(ctx);
+    ctx->in_registration = false;  // nothing left to enqueue for it: the result waits in its slot
+    return rc;
+}
+
+int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]) {
+    DeviceGuard device_guard(ctx);
+    return register_launch(ctx, xyz, n, mem, target_mode, init_pose, false);
+}
+
+int icp_register_launch_from_last(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode) {
+    DeviceGuard device_guard(ctx);
+    return register_launch(ctx, xyz, n, mem, target_mode, nullptr, true);
 }
 
 int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
@@ -1383,7 +1417,7 @@ int icp_exchange_create(icp_ctx* ctx, int32_t rank, int32_t world, void* handle_
     static_assert(sizeof(hipIpcMemHandle_t) == ICP_EXCHANGE_HANDLE_BYTES, "IPC handle size");
     if (!ctx || !handle_out || world < 1 || world > EXCHANGE_MAX_RANKS || rank < 0 || rank >= world)
         return ICP_ERR_INVALID_ARGUMENT;
-    if (ctx->in_registration || ctx->result_pending) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    if (ctx->in_registration || ctx->result_pending()) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     int rc = ensure_state(ctx);
     if (rc) return rc;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1426,7 +1460,7 @@ int icp_exchange_connect(icp_ctx* ctx, const void* handles) {
 int icp_exchange_destroy(icp_ctx* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
-    if (ctx->in_registration || ctx->result_pending) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    if (ctx->in_registration || ctx->result_pending()) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     exchange_release(ctx);
     return ICP_OK;

@@ -173,9 +173,6 @@ struct icp_ctx {
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
     float stats_h = 0.f, stats_h_pending = 0.f;  // cell edge of the build the figure was measured on
-    bool stats_at_launch = false;      // a grid-stats copy travels with the result being read back
-    int64_t stats_m_at_launch = 0;
-    float stats_h_at_launch = 0.f;
     // ---- registration
     icp::DeviceBuffer targets;         // staged copy of host targets
     const float* tgt_ptr = nullptr;    // device pointer of the current targets
@@ -213,12 +210,22 @@ struct icp_ctx {
     int reduce_blocks = 0;
     bool in_registration = false;
     // asynchronous result hand-off (icp_register_launch): state + grid stats + histories copied to pinned host memory
-    // behind the last iteration, `result_event` recorded after the copies
+    // behind the last iteration, an event recorded after the copies.  Two slots: a second registration may be launched
+    // (icp_register_launch_from_last: its initial guess is read on the device) before the first one's result has been
+    // collected, so the GPU never waits for the host between frames
     bool have_device_pose = false;   // RegState holds the pose of a finished / enqueued registration
-    bool result_pending = false;
-    void* host_result = nullptr;
-    size_t host_result_bytes = 0;
-    hipEvent_t result_event = nullptr;
+    struct ResultSlot {
+        void* host = nullptr;
+        size_t bytes = 0;
+        hipEvent_t event = nullptr;
+        bool stats = false;          // a grid-stats copy travels with this result
+        int64_t stats_m = 0;
+        float stats_h = 0.f;
+        int64_t eager_normals = 0;   // normals estimated eagerly for this registration
+    } rslot[2];
+    int r_head = 0;                  // oldest pending slot
+    int r_count = 0;                 // results launched and not yet collected (0..2)
+    bool result_pending() const { return r_count > 0; }
     // ---- in-library multi-GPU exchange (icp_exchange_*)
     bool exchange_on = false;
     icp::ExchangeView xview{};

@@ -107,6 +107,7 @@ EXPORTED_SYMBOLS = {
     "icp_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_register_begin": (_INT, [_P, _P, _I64, _INT, _INT, _P]),
     "icp_register_launch": (_INT, [_P, _P, _I64, _INT, _INT, _P]),
+    "icp_register_launch_from_last": (_INT, [_P, _P, _I64, _INT, _INT]),
     "icp_iteration_accumulate": (_INT, [_P]),
     "icp_iteration_solve": (_INT, [_P]),
     "icp_register_end": (_INT, [_P, C.POINTER(IcpRegisterResult), _P, _P]),

@@ -589,20 +589,27 @@ class IcpContext:
     def register_begin(self, points: Array, init_pose=None, skip_null: bool = False):
         self._bind(points)
         p, mem, keep = _ptr_mem(points)
-        self._keep_targets = keep
+        self._keep_targets = [keep]
         init = _pose16(init_pose if init_pose is not None else np.eye(4))
         self._check(self._lib.icp_register_begin(self._h, p, int(keep.shape[0]), mem,
                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init))
 
     def register_launch(self, points: Array, init_pose=None, skip_null: bool = False):
         """Enqueue a whole registration without waiting; `register_end()` later blocks on it alone, so work enqueued in
-        between (e.g. `map_update(None)`) overlaps the host's wait."""
+        between (e.g. `map_update(None)`) overlaps the host's wait.  `init_pose="last"`: the initial guess is the pose of
+        the previous registration, read on the device (constant-velocity initialisation without a host round trip) — with
+        it up to two registrations may be in flight, `register_end()` returning them oldest first."""
         self._bind(points)
         p, mem, keep = _ptr_mem(points)
-        self._keep_targets = keep
+        self._keep_targets = (getattr(self, "_keep_targets", None) or [])[-1:] + [keep]
+        mode = TARGETS_SKIP_NULL if skip_null else TARGETS_ALL
+        if isinstance(init_pose, str):
+            if init_pose != "last":
+                raise AssertionError(f"unknown initial pose {init_pose!r}")
+            self._check(self._lib.icp_register_launch_from_last(self._h, p, int(keep.shape[0]), mem, mode))
+            return
         init = _pose16(init_pose if init_pose is not None else np.eye(4))
-        self._check(self._lib.icp_register_launch(self._h, p, int(keep.shape[0]), mem,
-                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, init))
+        self._check(self._lib.icp_register_launch(self._h, p, int(keep.shape[0]), mem, mode, init))
 
     def iteration_accumulate(self):
         self._check(self._lib.icp_iteration_accumulate(self._h))
@@ -616,7 +623,6 @@ class IcpContext:
         dxs = (C.c_float * (6 * cap))()
         res = IcpRegisterResult()
         self._check(self._lib.icp_register_end(self._h, C.byref(res), losses, dxs))
-        self._keep_targets = None
         return self._result(res, losses, dxs)
 
     # ---- profiling ---------------------------------------------------------------------------------------------------

@@ -217,3 +217,57 @@ def test_failed_registration_leaves_the_map_where_it_was(torch_cuda):
     scans, _ = _scans(16, 128, 2)
     good.map_set(scans[0])
     assert good.register(scans[1]).iterations == 4
+
+
+def test_two_frames_in_flight_equal_the_synchronous_loop(torch_cuda):
+    """`icp_register_launch_from_last`: the constant-velocity guess (= the previous result) is read on the device, so
+    frame t + 1 and the map update by the pose of frame t are enqueued before the pose of frame t is collected.  Same
+    poses, losses and final map, bit for bit, as the loop that takes every pose through the host; results come back
+    oldest first; a third launch without collecting is refused."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 9)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    kw = dict(height=32, width=1024, max_num_alignments=8, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3)
+    dscans = [torch.from_numpy(s).cuda() for s in scans]
+    sync, pipe = IcpContext(**kw), IcpContext(**kw)
+    for c in (sync, pipe):
+        c.map_set(model)
+    # synchronous reference loop: every pose goes through the host
+    want, last = [], None
+    for f in range(4, 9):
+        sync.register_launch(dscans[f], last)
+        sync.map_update(None, None)
+        r = sync.register_end()
+        want.append(r)
+        last = r.pose
+    # pipelined: first frame as above, then two in flight
+    got = []
+    pipe.register_launch(dscans[4], None)
+    pipe.map_update(None, None)
+    got.append(pipe.register_end())
+    pending = 0
+    for f in range(5, 9):
+        pipe.register_launch(dscans[f], "last")
+        pipe.map_update(None, None)
+        pending += 1
+        if pending == 2:
+            got.append(pipe.register_end())
+            pending -= 1
+    pipe.register_launch(dscans[4], "last")  # two pending now
+    with pytest.raises(AssertionError):
+        pipe.register_launch(dscans[5], "last")
+    while len(got) < 5:
+        got.append(pipe.register_end())
+    extra = pipe.register_end()
+    assert extra.iterations == 8
+    with pytest.raises(AssertionError):
+        pipe.register_end()  # nothing pending any more
+    for a, b in zip(got, want):
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.losses, b.losses) and np.array_equal(a.dx, b.dx)
+    fresh = IcpContext(**kw)
+    fresh.map_set(model)
+    with pytest.raises(AssertionError):
+        fresh.register_launch(dscans[4], "last")  # no previous registration to start from
