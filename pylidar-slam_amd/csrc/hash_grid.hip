@@ -195,8 +195,10 @@ __global__ void k_build_rows(const GridEntry* __restrict__ table, unsigned int m
                 slot = (slot + 1) & mask;
             }
         }
-        rows[(size_t)j * ROW_STRIDE + c] = out;
-        if (c == 26) rows[(size_t)j * ROW_STRIDE + 27] = make_int2(0, 0);  // padding entry
+        // rows are indexed by the table SLOT of their cell: a query fetches entry and row together (no row-id hop)
+        const size_t base = (size_t)slot_of_cell[j] * ROW_STRIDE;
+        rows[base + c] = out;
+        if (c == 26) rows[base + 27] = make_int2(0, 0);  // padding entry
     }
 }
 
@@ -306,7 +308,6 @@ __global__ __launch_bounds__(1024) void k_grid_scan_sums(unsigned long long* __r
 __global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restrict__ table, long long n,
                                                              unsigned int tsize, int m,
                                                              const unsigned long long* __restrict__ sums,
-                                                             int* __restrict__ row_of_slot,
                                                              int* __restrict__ slot_of_cell) {
     __shared__ unsigned long long lds[16];
     const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
@@ -326,9 +327,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restri
             const int start = (int)(unsigned)(off & 0xffffffffull);
             if (i < (long long)tsize) {
                 table[i].start = start;
-                const int r = (v[k] >> 32) ? (int)(off >> 32) : -1;  // row id of an occupied fine cell
-                row_of_slot[i] = r;
-                if (r >= 0) slot_of_cell[r] = (int)i;
+                if (v[k] >> 32) slot_of_cell[(int)(off >> 32)] = (int)i;  // dense list of the occupied fine cells
             } else {
                 table[i].start = start - m;  // the fine level holds exactly m points
             }
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restri
 __global__ void k_grid_scatter2(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
                                 const int* __restrict__ slot_of, const int* __restrict__ rank_of,
                                 const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
-                                const int* __restrict__ row_of_slot, float4* __restrict__ sorted,
+                                float4* __restrict__ sorted,
                                 float4* __restrict__ csorted, float4* __restrict__ normals, int* __restrict__ nflag,
                                 int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,7 +348,7 @@ __global__ void k_grid_scatter2(const float* __restrict__ xyz, int m, const Grid
     const int pos = table[slot].start + rank_of[i];
     const int cpos = table[cslot_of[i]].start + crank_of[i];
     const float4 p = make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
-    row_of_pos[pos] = row_of_slot[slot];
+    row_of_pos[pos] = slot;  // rows are indexed by slot
     pos_of_orig[i] = pos;
     sorted[pos] = p;
     csorted[cpos] = p;
@@ -383,11 +382,10 @@ int build_grid(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->slot_of.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->rank_of.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->worklist.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->row_of_slot.reserve((size_t)tsize * sizeof(int)));
     ICP_HIP(ctx, ctx->slot_of_cell.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->row_of_pos.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->pos_of_orig.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->rows.reserve((size_t)m * ROW_STRIDE * sizeof(int2)));  // worst case: one cell per point
+    ICP_HIP(ctx, ctx->rows.reserve((size_t)tsize * ROW_STRIDE * sizeof(int2)));  // one row per table slot (sparse)
     ctx->table_size = tsize;
     GridEntry* table = ctx->table.as<GridEntry>();
     const float* xyz = ctx->map_xyz[ctx->map_cur].as<float>();
@@ -427,7 +425,7 @@ int build_grid(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_grid_tile_sums, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, sums);
     hipLaunchKernelGGL(k_grid_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, ncells_dev);
     hipLaunchKernelGGL(k_grid_apply, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, sums,
-                       ctx->row_of_slot.as<int>(), ctx->slot_of_cell.as<int>());
+                       ctx->slot_of_cell.as<int>());
     {
         long long want = ((long long)m * 27 + 255) / 256;
         const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
@@ -436,7 +434,7 @@ int build_grid(icp_ctx* ctx) {
     }
     hipLaunchKernelGGL(k_grid_scatter2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, table,
                        ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                       ctx->crank_of.as<int>(), ctx->row_of_slot.as<int>(), ctx->sorted_pts.as<float4>(),
+                       ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(),
                        ctx->csorted.as<float4>(), ctx->normals.as<float4>(), ctx->nflag.as<int>(),
                        ctx->row_of_pos.as<int>(), ctx->pos_of_orig.as<int>());
     ctx->ctable_ptr = table + tsize;

@@ -29,10 +29,11 @@ struct GridView {
     const float4* pts;   // cell-sorted map points: (x, y, z, bits(original index))
     int m;               // number of map points
     // neighbour rows: for every occupied cell the (start, count) of its 27-neighbourhood (index = (oz+1)*9+(oy+1)*3+
-    // (ox+1), own cell at 13), so that a query in an occupied cell needs ONE hash probe instead of 27
-    const int* row_of_slot;  // table slot -> row (-1 if the slot is free)
-    const int2* rows;        // [cells][ROW_STRIDE]
-    const int* row_of_pos;   // cell-sorted point position -> row of its cell
+    // (ox+1), own cell at 13), so that a query in an occupied cell needs ONE hash probe instead of 27.  Indexed by the
+    // table slot of the cell (sparse: only the rows of occupied slots are ever written or read), so the entry and the
+    // row of a query's cell are fetched in the same round
+    const int2* rows;        // [table slots][ROW_STRIDE]
+    const int* row_of_pos;   // cell-sorted point position -> slot (= row) of its cell
     // coarse level (cell edge COARSE_FACTOR * h, hashed, own cell-sorted copy of the points): takes over when a query is
     // farther than `max_rings` fine cells from the map, so that the exhaustive scan stays a last resort
     const GridEntry* ctable;
@@ -155,7 +156,7 @@ struct icp_ctx {
     icp::DeviceBuffer normals;         // float4[M] (by cell-sorted position)
     icp::DeviceBuffer nflag;           // int[M]: 0 none, 2 queued, 1 ready
     icp::DeviceBuffer slot_of, rank_of;  // int[M] temporaries of the build
-    icp::DeviceBuffer row_of_slot, slot_of_cell, rows, row_of_pos;
+    icp::DeviceBuffer slot_of_cell, rows, row_of_pos;
     icp::DeviceBuffer csorted, pos_of_orig, cslot_of, crank_of;  // coarse level (its table follows the fine one)
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;

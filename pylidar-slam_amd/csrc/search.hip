@@ -59,12 +59,15 @@ __device__ inline void group_min4(Best& b) {
 
 __device__ inline void scan_strided4(const GridView& g, int start, int count, int sub, float px, float py, float pz,
                                      Best& b) {
+    // 4 independent loads per lane and round (16 candidates per group): a cell of ~10 points is one round
     const int last = start + count - 1;
-    for (int k = start + sub; k <= last; k += 8) {
-        const int k1 = min(k + 4, last);
-        const float4 q0 = g.pts[k], q1 = g.pts[k1];
+    for (int k = start + sub; k <= last; k += 16) {
+        const int k1 = min(k + 4, last), k2 = min(k + 8, last), k3 = min(k + 12, last);
+        const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
         consider(q0, k, px, py, pz, b);
         consider(q1, k1, px, py, pz, b);
+        consider(q2, k2, px, py, pz, b);
+        consider(q3, k3, px, py, pz, b);
     }
 }
 
@@ -131,25 +134,29 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-    // own cell: entry and row id of the first slot are fetched together (a first-probe hit is the common case)
+    // own cell: the entry of the first slot and — rows are indexed by slot — this lane's 7 row entries are fetched
+    // together (a first-probe hit is the common case; the speculative row is simply reloaded after a collision)
     const unsigned long long key = pack_cell(cx, cy, cz);
     unsigned int slot = hash_cell(key) & g.mask;
     GridEntry e = g.table[slot];
-    int row = g.row_of_slot[slot];
+    int2 cell[7];
+    {
+        const int2* __restrict__ r = g.rows + (size_t)slot * ROW_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
+    }
     if (e.key != key && e.key != GRID_EMPTY) {
         while (true) {
             slot = (slot + 1) & g.mask;
             e = g.table[slot];
             if (e.key == key || e.key == GRID_EMPTY) break;
         }
-        row = g.row_of_slot[slot];
+        const int2* __restrict__ r = g.rows + (size_t)slot * ROW_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
     }
     if (e.key == key) {
         // ---- row path
-        const int2* __restrict__ r = g.rows + (size_t)row * ROW_STRIDE;
-        int2 cell[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) cell[k] = r[sub * 7 + k];
         scan_strided4(g, e.start, e.count, sub, px, py, pz, b);
         group_min4(b);
         int nl = 0;
@@ -1033,7 +1040,6 @@ static GridView make_view(icp_ctx* ctx) {
     g.inv_h = 1.0f / ctx->cell_h;
     g.pts = ctx->sorted_pts.as<float4>();
     g.m = (int)ctx->map_m;
-    g.row_of_slot = ctx->row_of_slot.as<int>();
     g.rows = ctx->rows.as<int2>();
     g.row_of_pos = ctx->row_of_pos.as<int>();
     g.ctable = ctx->ctable_ptr;
