@@ -438,7 +438,7 @@ def main():
             achieved = BYTES_PER_POINT_ITER * n_local / avg_s
             traffic, source = pmc_traffic()
             out["roofline"] = {"bound": "hbm",
-                               "kernel": "k_iterate_rows (per-iteration fused kernel: transform + exact 1-NN in the "
+                               "kernel": "k_iterate_compact (per-iteration fused kernel: transform + exact 1-NN in the "
                                          "voxel-hash grid + point-to-plane rows + per-block partial normal equations)",
                                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,

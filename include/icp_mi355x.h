@@ -79,7 +79,7 @@ typedef struct {
     int32_t local_map_size;
     int32_t num_neighbors_normals;
     /* MI355X-side knobs (no reference counterpart) */
-    float cell_size;   /* voxel-hash cell edge in metres; <= 0: auto-tuned towards ~6 map points per occupied cell.
+    float cell_size;   /* voxel-hash cell edge in metres; <= 0: auto-tuned towards ~10 map points per occupied cell.
                           Search results never depend on it (the search is exact), only speed does */
     int32_t max_rings; /* fine-level rings searched before the coarse level / exhaustive fallback (default 2; exactness is kept either way) */
     int32_t device;    /* HIP device ordinal */
@@ -172,8 +172,9 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* s
  * update), evict the oldest cloud beyond local_map_size, rebuild the search structure and clear the normal cache.
  * *inserted_out (optional) = number of rows appended.  rel_pose = NULL: the pose of the last registration on this
  * context, read on the device (no host round trip; valid after icp_register / icp_register_launch).  If that
- * registration stopped on ICP_ERR_INVALID_JACOBIAN the pose is its last valid iterate (the reference raises before it
- * would touch the map: a caller that wants that order calls icp_register_end first and passes the pose). */
+ * registration stopped on an error (ICP_ERR_INVALID_JACOBIAN, ICP_ERR_EXCHANGE) the map is NOT moved and the new cloud
+ * is inserted as it stands (the reference raises before it would touch the map; the error itself reaches the caller
+ * through icp_register_end). */
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out);
 /* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */

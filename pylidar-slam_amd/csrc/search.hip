@@ -882,7 +882,7 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
 // 27-cell candidates staged once in LDS, brute-force top-k per point: 137 us for the ring-1 part alone + 166 us for the
 // unsettled points, vs 154 us here).
 template <int KN, int NL>
-__global__ __launch_bounds__(NRM_THREADS) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
+__global__ __launch_bounds__(NRM_THREADS, 5) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
     constexpr int PTS = NRM_THREADS / NL;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];

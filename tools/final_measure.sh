@@ -1,8 +1,18 @@
 #!/bin/bash
-# round-end measurement batch on one box: GPU tests, bench line (with cpu_baseline), kernel stats, HBM counters, scenarios
-mkdir -p gpurun_out
-timeout 200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 300 python bench.py --steps 112 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json; echo
-timeout 200 ./tools/prof.sh ${TAG:-r01_u} > /dev/null; head -12 gpurun_out/${TAG:-r01_u}_stats.txt
-timeout 260 ./tools/pmc.sh k_iterate_rows | tail -c 400; echo
-timeout 200 python tools/scenarios.py 2>&1 | grep "^S[123]"
+# end-of-round measurements: full bench line, throughput mode, round-1 trajectory, kernel trace -> gpurun_out/<dir>
+set -u
+OUT=gpurun_out/${1:-final}; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err; tail -c 600 $OUT/bench_line.json; echo
+for s in 2 4 8; do timeout 300 python bench.py --sequences-per-gpu $s --no-cpu-baseline --loop-steps 0 > $OUT/bench_s$s.json 2> $OUT/bench_s$s.err; done
+timeout 300 python bench.py --trajectory pingpong_r01 --no-cpu-baseline --loop-steps 0 > $OUT/bench_r01traj.json 2> $OUT/bench_r01traj.err
+timeout 300 python bench.py --pipeline 2 --no-cpu-baseline --loop-steps 0 > $OUT/bench_pipe2.json 2> $OUT/bench_pipe2.err
+for f in $OUT/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get("roofline",{})
+    print(f"{sys.argv[1]:42s} {d['value']:8.1f} scans/s {d['ms_per_step']:.3f} ms iter-kernel {r.get('avg_launch_us',0):.1f} us frac {r.get('frac',0):.4f} loop {d.get('loop',{}).get('value',0):.0f} cpu {d.get('cpu_baseline',{}).get('value',0):.3f}")
+except Exception as e: print(sys.argv[1],"FAILED",e)
+PY
+done
+bash tools/gpu_trace.sh ${1:-final}
