@@ -377,13 +377,14 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     if (k == "nn_cache") ctx->use_nn_cache = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
+    else if (k == "wave_misses") ctx->wave_misses = iv < 0 ? 0 : (int)iv;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
-        ctx->search_stats = iv != 0;
+        ctx->search_stats = (int)iv;  // 1: path counters + phase stamps, 2: stamps only (no atomics)
         if (ctx->search_stats) {  // 16 path counters + 4 phase timestamps per workgroup and iteration
             ICP_HIP(ctx, ctx->dbg_counts.reserve(DBG_BYTES));
             ICP_HIP(ctx, hipMemsetAsync(ctx->dbg_counts.ptr, 0, DBG_BYTES, ctx->stream));
@@ -1277,20 +1278,30 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
             for (int it = 0; it < st.iter && it < 24 && nb > 0 && nb <= 1024; ++it) {
                 const long long* t = tall + 4 * (size_t)it * 1024;
                 if (t[0] == 0) continue;
+                const long long MASK = (1ll << 48) - 1;
                 long long first = t[0], last_start = t[0], last_end = t[3];
-                double a = 0, b = 0, r = 0, amax = 0, bmax = 0;
+                double a = 0, b = 0, r = 0, amax = 0, bmax = 0, rmax = 0;
+                int bmax_miss = 0, with_miss = 0, total_miss = 0, b_over2 = 0, b_over5 = 0;
                 for (int i = 0; i < nb; ++i) {
                     const long long* q = t + 4 * i;
+                    const long long t1 = q[1] & MASK;
+                    const int miss = (int)(q[1] >> 48);
                     if (q[0] < first) first = q[0];
                     if (q[0] > last_start) last_start = q[0];
                     if (q[3] > last_end) last_end = q[3];
-                    const double da = (q[1] - q[0]) * 0.01, db = (q[2] - q[1]) * 0.01, dr = (q[3] - q[2]) * 0.01;
+                    const double da = (t1 - q[0]) * 0.01, db = (q[2] - t1) * 0.01, dr = (q[3] - q[2]) * 0.01;
                     a += da; b += db; r += dr;
                     if (da > amax) amax = da;
-                    if (db > bmax) bmax = db;
+                    if (db > bmax) { bmax = db; bmax_miss = miss; }
+                    if (dr > rmax) rmax = dr;
+                    with_miss += miss > 0;
+                    total_miss += miss;
+                    b_over2 += db > 2.0;
+                    b_over5 += db > 5.0;
                 }
-                fprintf(stderr, "[icp phases] it %2d: blocks=%d start skew %.2f us, span %.2f us; phase A mean %.2f max %.2f, phase B mean %.2f max %.2f, reduce mean %.2f us\n",
-                        it, nb, (last_start - first) * 0.01, (last_end - first) * 0.01, a / nb, amax, b / nb, bmax, r / nb);
+                fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
+                        it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / nb, amax, b / nb, bmax, bmax_miss,
+                        b_over2, b_over5, total_miss, with_miss, r / nb, rmax);
             }
             (void)hipMemset(ctx->dbg_counts.ptr, 0, DBG_BYTES);
         }

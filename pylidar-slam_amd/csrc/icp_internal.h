@@ -41,7 +41,8 @@ struct GridView {
     float ch, cinv_h;
     const float4* cpts;
     const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
-    int* dbg;                // dev-only path counters (env ICP_SEARCH_STATS), nullptr in production
+    int* dbg;                // dev-only path counters (option "search_stats" = 1), nullptr in production
+    long long* stamps;       // dev-only phase timestamps (option "search_stats" = 1 | 2), nullptr in production
 };
 static constexpr float COARSE_FACTOR = 4.0f;
 static constexpr int COARSE_RINGS = 6;
@@ -188,6 +189,7 @@ struct icp_ctx {
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
+    int wave_misses = 24;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
     int search_stats = 0;              // "search_stats": count which path resolved each query (dev)

@@ -249,6 +249,135 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     return b;
 }
 
+__device__ inline void wave_min64(Best& b) {
+#pragma unroll
+    for (int o = 1; o <= 32; o <<= 1) {
+        const float d2 = __shfl_xor(b.d2, o, 64);
+        const int idx = __shfl_xor(b.idx, o, 64);
+        const int pos = __shfl_xor(b.pos, o, 64);
+        float sec = fminf(b.second, __shfl_xor(b.second, o, 64));
+        if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
+        if (better(d2, idx, b.d2, b.idx)) {
+            b.d2 = d2;
+            b.idx = idx;
+            b.pos = pos;
+        }
+        b.second = sec;
+    }
+}
+
+// One query searched by a WHOLE WAVE (the fused iteration kernel uses it for workgroups with few cache misses: in the
+// late iterations a handful of queries search at all, and the slowest of them sets the duration of the launch — a
+// 4-lane search is a chain of ~20 dependent memory round trips, 12-13 us by the in-kernel timers).  Here the chain is
+// three: (1) table entry + the 27 row entries, one per lane; (2) ALL surviving candidates at once — the cells that pass
+// the box test against the seed are laid end to end (prefix sum over the lanes, cell of candidate j found by a 5-step
+// search in LDS) and dealt out 2 x 64 per round; (3) the winner's normal.  Same minimum, same tie-break.
+// An empty own cell costs one hashed probe per lane instead of the row; a search that ring 1 does not settle goes on to
+// the 98 cells of ring 2, at most two hashed probes per lane.
+// `wl` = 64 ints of LDS private to the wave.  Returns false (b undefined) when ring 2 does not settle the search either:
+// the caller hands the query to the generic 4-lane path (coarse level, exhaustive scan).
+__device__ inline bool search_rows_wave(const GridView& g, float px, float py, float pz, int lane, int max_rings,
+                                        int* __restrict__ wl, float seed_d2, int seed_idx, int seed_pos, Best& b) {
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float h = g.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const unsigned long long key = pack_cell(cx, cy, cz);
+    unsigned int slot = hash_cell(key) & g.mask;
+    const int c = min(lane, 27);  // entry 27 is the (0, 0) padding
+    GridEntry e = g.table[slot];
+    int2 rc = g.rows[(size_t)slot * ROW_STRIDE + c];
+    if (e.key != key && e.key != GRID_EMPTY) {  // wave-uniform
+        while (true) {
+            slot = (slot + 1) & g.mask;
+            e = g.table[slot];
+            if (e.key == key || e.key == GRID_EMPTY) break;
+        }
+        rc = g.rows[(size_t)slot * ROW_STRIDE + c];
+    }
+    if (e.key != key) {
+        // own cell empty (no row): the 26 neighbours by hashed probes, one per lane
+        rc = make_int2(0, 0);
+        if (lane < 27 && lane != 13) {
+            int start, count;
+            if (grid_lookup(g, cx + c % 3 - 1, cy + (c / 3) % 3 - 1, cz + c / 9 - 1, start, count))
+                rc = make_int2(start, count);
+        }
+    }
+    b.d2 = seed_d2;
+    b.idx = seed_idx;
+    b.pos = seed_pos;
+    b.second = INFINITY;
+    int cnt = 0;
+    if (lane < 27) {
+        const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h), gz = axis_gap(c / 9 - 1, fz, h);
+        const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+        cnt = rc.y;
+        if (cnt > 0 && gap2 > seed_d2) {
+            b.second = gap2;  // every point of a pruned cell is at least that far
+            cnt = 0;
+        }
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o <= 16; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 31, 64);  // lanes 27..31 add nothing
+    const int excl = incl - cnt;
+    if (lane < 32) {
+        wl[lane] = excl;
+        wl[32 + lane] = rc.x - excl;  // candidate j of cell c sits at position j + wl[32 + c]
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j0 = 0; j0 < total; j0 += 128) {
+        const int ja = j0 + lane, jb = j0 + 64 + lane;
+        int ca = 0, cb = 0;
+#pragma unroll
+        for (int s2 = 16; s2 > 0; s2 >>= 1) {
+            if (wl[ca + s2] <= ja) ca += s2;
+            if (wl[cb + s2] <= jb) cb += s2;
+        }
+        const int pa = ja + wl[32 + ca], pb = jb + wl[32 + cb];
+        float4 qa, qb;
+        if (ja < total) qa = g.pts[pa];
+        if (jb < total) qb = g.pts[pb];
+        if (ja < total) consider(qa, pa, px, py, pz, b);
+        if (jb < total) consider(qb, pb, px, py, pz, b);
+    }
+    wave_min64(b);
+    float bound = h + edge;
+    if (b.d2 <= bound * bound * 0.999999f) {
+        b.second = fminf(b.second, bound * bound * 0.999999f);  // nothing outside the 27-cell block is closer
+        return true;
+    }
+    if (max_rings < 2) return false;
+    // ring 2 of the fine level: the 98 shell cells of the 5x5x5 block by hashed probes, at most two per lane
+    for (int s5 = lane; s5 < 125; s5 += 64) {
+        const int ox = s5 % 5 - 2, oy = (s5 / 5) % 5 - 2, oz = s5 / 25 - 2;
+        if (max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz) < 2) continue;  // rings 0 and 1: done
+        const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+        const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+        if (gap2 > b.d2) {
+            b.second = fminf(b.second, gap2);
+            continue;
+        }
+        int start, count;
+        if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
+            for (int k = start; k < start + count; ++k) consider(g.pts[k], k, px, py, pz, b);  // rare: kept small
+    }
+    wave_min64(b);
+    bound = 2.f * h + edge;
+    if (!(b.d2 <= bound * bound * 0.999999f)) return false;
+    b.second = fminf(b.second, bound * bound * 0.999999f);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* __restrict__ tgt, int n, int mode,
                                                      int transform, RegState* __restrict__ st, int max_rings,
                                                      int* __restrict__ nn_pos, int* __restrict__ nflag,
@@ -335,6 +464,7 @@ struct IterInputs {
     const int* frame_seed;   // original map index per query or nullptr
     double* partials;
     int n, mode, max_rings, use_cache;
+    int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
 };
 
 // MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
@@ -353,8 +483,8 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
     // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
     // counters
     long long* stamps = nullptr;
-    if (g.dbg && gridDim.x <= 1024 && st->iter < 24)
-        stamps = reinterpret_cast<long long*>(g.dbg + 16) + 4 * ((size_t)st->iter * 1024 + blockIdx.x);
+    if (g.stamps && gridDim.x <= 1024 && st->iter < 24)
+        stamps = g.stamps + 4 * ((size_t)st->iter * 1024 + blockIdx.x);
     if (threadIdx.x == 0) {
         nmiss = 0;
         if (stamps) stamps[0] = wall_clock64();
@@ -424,11 +554,50 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0) {
-        stamps[1] = wall_clock64();
-        atomicAdd(&g.dbg[6], nmiss);
-        atomicAdd(&g.dbg[8 + min(st->iter, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
+        stamps[1] = wall_clock64() | ((long long)nmiss << 48);  // the block's miss count rides in the top bits
+        if (g.dbg) {
+            atomicAdd(&g.dbg[6], nmiss);
+            atomicAdd(&g.dbg[8 + min(st->iter, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
+        }
     }
-    // ---- phase B: the misses, 4 lanes each, dense over the block's groups
+    // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
+    // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
+    if (nmiss > 0 && nmiss <= in.wave_misses) {  // block-uniform
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, listed = nmiss;
+        int* wl = reinterpret_cast<int*>(&cellstack[0][0]) + wave * 64;  // the cell stacks are idle until B2
+        for (int m = wave; m < listed; m += IT_THREADS / 64) {
+            const float4 mp = miss_p[m];
+            const int4 ms = miss_seed[m];
+            Best b;
+            if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b)) continue;
+            if (lane == 0) {
+                const int lq = __float_as_int(mp.w);
+                in.nn_cache[q0 + lq] = make_int2(b.pos, __float_as_int(sqrtf(b.second) * 0.999999f));
+                if (b.pos >= 0) {
+                    const float4 q = g.pts[b.pos];
+                    const float4 nn = in.normals[b.pos];
+                    float row[9];
+                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                }
+                miss_seed[m].w = 1;  // settled
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = 0;
+            for (int m = 0; m < listed; ++m)
+                if (!miss_seed[m].w) {
+                    miss_p[k] = miss_p[m];
+                    miss_seed[k] = miss_seed[m];
+                    ++k;
+                }
+            nmiss = k;
+        }
+        __syncthreads();
+    }
+    // ---- phase B2: the misses, 4 lanes each, dense over the block's groups
     {
         const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
         if (grp < nmiss) {  // group-uniform
@@ -1048,7 +1217,8 @@ static GridView make_view(icp_ctx* ctx) {
     g.cinv_h = 1.0f / g.ch;
     g.cpts = ctx->csorted.as<float4>();
     g.pos_of_orig = ctx->pos_of_orig.as<int>();
-    g.dbg = ctx->search_stats ? ctx->dbg_counts.as<int>() : nullptr;
+    g.dbg = ctx->search_stats == 1 ? ctx->dbg_counts.as<int>() : nullptr;
+    g.stamps = ctx->search_stats ? reinterpret_cast<long long*>(ctx->dbg_counts.as<int>() + 16) : nullptr;
     return g;
 }
 
@@ -1196,6 +1366,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     in.mode = ctx->tgt_mode;
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
+    in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
     if (ctx->iterate_dense)
         hipLaunchKernelGGL(k_iterate_compact<8>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
                            reg_state(ctx), make_align_params(ctx));
