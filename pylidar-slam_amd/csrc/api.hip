@@ -1270,8 +1270,8 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         std::vector<char> raw(DBG_BYTES);
         if (hipMemcpy(raw.data(), ctx->dbg_counts.ptr, DBG_BYTES, hipMemcpyDeviceToHost) == hipSuccess) {
             const int* c = (const int*)raw.data();
-            fprintf(stderr, "[icp stats] N=%lld M=%lld h=%.3f iters=%d ring1=%d need_ring2=%d need_ring3=%d fine_failed=%d exhaustive=%d own_empty=%d misses=%d by-iteration(0-2,3-5,..)=%d,%d,%d,%d,%d,%d,%d\n",
-                    (long long)ctx->tgt_n, (long long)ctx->map_m, ctx->cell_h, st.iter, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8], c[9], c[10], c[11], c[12], c[13], c[14]);
+            fprintf(stderr, "[icp stats] N=%lld M=%lld h=%.3f iters=%d ring1=%d need_ring2=%d need_ring3=%d fine_failed=%d exhaustive=%d own_empty=%d misses=%d by-iteration(0-2,3-5,..)=%d,%d,%d,%d,%d,%d,%d knn: beyond ring 1 %d, beyond the fine rings %d\n",
+                    (long long)ctx->tgt_n, (long long)ctx->map_m, ctx->cell_h, st.iter, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[7], c[15]);
             // phase timestamps per iteration launch (100 MHz wall clock -> us)
             const long long* tall = (const long long*)(c + 16);
             const int nb = (int)((ctx->tgt_n * 4 + 511) / 512);

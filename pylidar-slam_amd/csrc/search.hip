@@ -847,13 +847,19 @@ __device__ inline void knn_rings(const GridView& g, float px, float py, float pz
 template <int KN, int NL>
 __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m);
 
-// kNN counterpart of `coop_rings`: rings r_begin..r_end of one level by the 4 lanes of a map point.  `m` is the merged
-// list so far (identical in the 4 lanes); per ring lane 0 continues from it, the others from empty lists, every lane
-// inserts its share of the ring, and the lists are merged again.  Keys carry original indices, so fine and coarse
-// levels mix freely.  Returns true when the k-th neighbour is provably exact on this level.
-template <int KN, int NL>
-__device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end,
-                                      TopK<KN>& m) {
+static constexpr int NRM_THREADS = 256;
+
+// kNN counterpart of `coop_rings` for a WHOLE WAVE: rings r_begin..r_end of one level around a map point.  `m` is the
+// merged list so far (identical in all lanes); per ring lane 0 continues from it, the others from empty lists.  The cells
+// of a ring are taken 64 at a time, one hashed probe per lane; the candidates of the cells that pass the box test are
+// then laid end to end (prefix sum over the lanes, cell of candidate j found by a 6-step search in LDS) and dealt out
+// evenly — a coarse cell of a thousand points costs every lane sixteen candidates instead of one lane a thousand.
+// `limit` = a squared distance beyond which nothing can be among the k nearest (k points are already known inside it).
+// Keys carry original indices, so fine and coarse levels mix freely.  `wl` = 128 ints of LDS private to the wave.
+// Returns true when the k-th neighbour is provably exact on this level.
+template <int KN>
+__device__ inline bool wave_knn_rings(const GridView& lv, float px, float py, float pz, int lane, int r_begin, int r_end,
+                                      float limit, TopK<KN>& m, int* __restrict__ wl) {
     const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
     const float h = lv.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -862,37 +868,64 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
     for (int r = r_begin; r <= r_end; ++r) {
         TopK<KN> t;
-        if (sub == 0) {
+        if (lane == 0) {
             t = m;
         } else {
             t.init();
         }
-        const float kth = m.kth();
-        int start, count;
-        if (r == 0) {
-            if (grid_lookup(lv, cx, cy, cz, start, count)) {
-                for (int k = start + sub; k < start + count; k += NL) {
-                    const float4 q = lv.pts[k];
-                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-                    t.insert(make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w)));
-                }
-            }
-        } else {
-            // (looking the surviving shell cells up four at a time — 4 table loads in flight instead of one dependent probe
-            // after the other — was measured in round 2: the extra live registers cost two waves of occupancy, 227 vs
-            // 181 us)
-            const int side = 2 * r + 1, total = side * side * side;
-            for (int c = sub; c < total; c += NL) {
+        const float kth = fminf(m.kth(), limit);
+        const int side = 2 * r + 1, total = side * side * side;
+        for (int c0 = 0; c0 < total; c0 += 64) {  // wave-uniform trip count
+            const int c = c0 + lane;
+            int start = 0, count = 0;
+            if (c < total) {
                 const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
                 const int mx = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
-                if (mx < r) continue;
-                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth) continue;
-                if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
-                    scan_cell_knn<KN>(lv, start, count, px, py, pz, t);
+                if (mx == r) {  // the shell only: the interior belongs to the previous rings
+                    const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                    if (!(fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth) &&
+                        !grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
+                        count = 0;
+                }
             }
+            int incl = count;
+#pragma unroll
+            for (int o = 1; o <= 32; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const int cand = __shfl(incl, 63, 64);
+            const int excl = incl - count;
+            wl[lane] = excl;
+            wl[64 + lane] = start - excl;  // candidate j of the cell of lane l sits at position j + wl[64 + l]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j0 = 0; j0 < cand; j0 += 128) {
+                const int ja = j0 + lane, jb = j0 + 64 + lane;
+                int ca = 0, cb = 0;
+#pragma unroll
+                for (int s2 = 32; s2 > 0; s2 >>= 1) {
+                    if (wl[ca + s2] <= ja) ca += s2;
+                    if (wl[cb + s2] <= jb) cb += s2;
+                }
+                const int pa = ja + wl[64 + ca], pb = jb + wl[64 + cb];
+                float4 qa, qb;
+                if (ja < cand) qa = lv.pts[pa];
+                if (jb < cand) qb = lv.pts[pb];
+                if (ja < cand) {
+                    const unsigned long long key = point_key(qa, px, py, pz);
+                    if (!(key_d2(key) > limit)) t.insert(key);
+                }
+                if (jb < cand) {
+                    const unsigned long long key = point_key(qb, px, py, pz);
+                    if (!(key_d2(key) > limit)) t.insert(key);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the next round overwrites wl
         }
-        merge_group<KN, NL>(t, m);
+        merge_group<KN, 64>(t, m);
         const float bound = (float)r * h + edge;
         if (m.kth() <= bound * bound * 0.999999f) return true;
     }
@@ -907,8 +940,8 @@ __device__ inline bool coop_knn_rings(const GridView& lv, float px, float py, fl
 // pops".  Only if the k-th neighbour is not provably inside ring 1 does lane 0 continue with the hashed rings / coarse
 // level.  4x the waves and ~1/4 of the serial insert chain of a one-lane-per-point search; same result.
 template <int KN, int NL>
-__device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_rings, float* __restrict__ cov,
-                                    int2* __restrict__ stack, int stride) {
+__device__ inline bool estimate_cov(const GridView& g, int s, int sub, float* __restrict__ cov, int2* __restrict__ stack,
+                                    int stride, TopK<KN>& m) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     TopK<KN> t;
@@ -974,23 +1007,72 @@ __device__ inline void estimate_cov(const GridView& g, int s, int sub, int max_r
             k += 4;
         }
     }
-    TopK<KN> m;
     merge_group<KN, NL>(t, m);
     const float bound1 = h + edge;
-    bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
-    if (!exact) {
-        // fine rings 2..max_rings, then the coarse level, each ring split over the 4 lanes
-        exact = max_rings >= 2 && coop_knn_rings<KN, NL>(g, px, py, pz, sub, 2, max_rings, m);
-        if (!exact && g.ctable) {
-            m.init();  // the coarse rings start at ring 0 and re-find the fine results: starting empty avoids duplicates
-            exact = coop_knn_rings<KN, NL>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, m);
-        }
-        if (!exact && sub == 0) {  // farther than COARSE_RINGS coarse cells from k map points: exhaustive
-            m.init();
-            scan_cell_knn<KN>(g, 0, g.m, px, py, pz, m);
-        }
+    const bool exact = m.kth() <= bound1 * bound1 * 0.999999f;  // group-uniform: m is shared
+    if (exact && sub == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+    return exact;
+}
+
+// The points ring 1 does not settle (isolated points: 1-2 % of a LiDAR map) are finished by a WHOLE WAVE each: a few of
+// them per launch walked the hashed rings and the coarse level with 4 lanes — 25 dependent probes per lane and ring,
+// coarse cells of hundreds of points — and set the duration of the kernel (the same tail as in the iteration kernel).
+// `m` = the merged list after ring 1 (identical in every lane).  Fine rings 2..max_rings, the coarse level, then the
+// exhaustive scan, every one split over the 64 lanes; lane 0 writes the covariance.
+template <int KN>
+__device__ inline void finish_cov_wave(const GridView& g, int s, int lane, int max_rings, TopK<KN>& m,
+                                       float* __restrict__ cov, int* __restrict__ wl) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    if (g.dbg && lane == 0) atomicAdd(&g.dbg[7], 1);
+    bool exact = max_rings >= 2 && wave_knn_rings<KN>(g, px, py, pz, lane, 2, max_rings, INFINITY, m, wl);
+    if (g.dbg && lane == 0 && !exact) atomicAdd(&g.dbg[15], 1);
+    if (!exact && g.ctable) {
+        // the coarse rings start at ring 0 and re-find the fine results: the list starts empty (no duplicates), but what
+        // the fine rings found still bounds the search — k points are known within its k-th distance
+        const float limit = m.kth();
+        m.init();
+        exact = wave_knn_rings<KN>(coarse_view(g), px, py, pz, lane, 0, COARSE_RINGS, limit, m, wl);
     }
-    if (sub == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+    if (!exact) {  // farther than COARSE_RINGS coarse cells from k map points: exhaustive
+        TopK<KN> t;
+        t.init();
+        m.init();
+        for (int k = lane; k < g.m; k += 64) t.insert(point_key(g.pts[k], px, py, pz));
+        merge_group<KN, 64>(t, m);
+    }
+    if (lane == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+}
+
+// the unsettled points of a block wait in LDS: point, slot of its covariance, merged list after ring 1
+template <int KN, int PTS>
+struct PendingKnn {
+    unsigned long long key[PTS][KN];
+    int s[PTS];
+    int lq[PTS];
+    int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
+    int n;
+};
+
+template <int KN, int PTS>
+__device__ inline void pend_push(PendingKnn<KN, PTS>& p, int s, int lq, const TopK<KN>& m) {
+    const int k = atomicAdd(&p.n, 1);
+    p.s[k] = s;
+    p.lq[k] = lq;
+#pragma unroll
+    for (int j = 0; j < KN; ++j) p.key[k][j] = m.key[j];
+}
+
+// every thread of the block calls (between two barriers of the caller)
+template <int KN, int PTS>
+__device__ inline void pend_finish(const GridView& g, PendingKnn<KN, PTS>& p, int max_rings, float (*covs)[7]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < p.n; k += NRM_THREADS / 64) {
+        TopK<KN> m;
+#pragma unroll
+        for (int j = 0; j < KN; ++j) m.key[j] = p.key[k][j];
+        finish_cov_wave<KN>(g, p.s[k], lane, max_rings, m, covs[p.lq[k]], p.wl[wave]);
+    }
 }
 
 // merge of the NL lanes' sorted lists: k rounds of "group-min of the heads, the winner pops" (t is consumed)
@@ -1017,8 +1099,6 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 // Block = NRM_THREADS / NL map points x NL lanes: the groups leave their covariances in LDS, then the first threads
 // (whole waves, every lane busy) run the Jacobi eigen-solves — a group would otherwise spend the ~1.5k-instruction solve
 // with one lane in NL active.
-static constexpr int NRM_THREADS = 256;
-
 // lazy schedule: the map points queued by the search of this iteration (a no-op once the registration is done; the
 // count feeds `normals_computed`)
 template <int KN, int NL>
@@ -1029,12 +1109,21 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
     if (st->done) return;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
+    __shared__ PendingKnn<KN, PTS> pend;
     const int nw = st->n_worklist;
     const int sub = threadIdx.x % NL, lq = threadIdx.x / NL;
     for (int base = blockIdx.x * PTS; base < nw; base += gridDim.x * PTS) {  // block-uniform trip count
+        if (threadIdx.x == 0) pend.n = 0;
+        __syncthreads();
         const int w = base + lq;
-        if (w < nw)
-            estimate_cov<KN, NL>(g, worklist[w], sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+        if (w < nw) {
+            TopK<KN> m;
+            const int s = worklist[w];
+            if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+                pend_push(pend, s, lq, m);
+        }
+        __syncthreads();
+        pend_finish(g, pend, max_rings, covs);
         __syncthreads();
         if (threadIdx.x < PTS && base + (int)threadIdx.x < nw)
             normal_from_cov(covs[threadIdx.x], worklist[base + threadIdx.x], normals, nflag);
@@ -1051,15 +1140,23 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
 // 27-cell candidates staged once in LDS, brute-force top-k per point: 137 us for the ring-1 part alone + 166 us for the
 // unsettled points, vs 154 us here).
 template <int KN, int NL>
-__global__ __launch_bounds__(NRM_THREADS, 5) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
+__global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
     constexpr int PTS = NRM_THREADS / NL;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
-    const int lq = threadIdx.x / NL;
+    __shared__ PendingKnn<KN, PTS> pend;
+    if (threadIdx.x == 0) pend.n = 0;
+    __syncthreads();
+    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
     const int s = blockIdx.x * PTS + lq;
-    if (s < g.m)
-        estimate_cov<KN, NL>(g, s, threadIdx.x % NL, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+    if (s < g.m) {
+        TopK<KN> m;
+        if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+            pend_push(pend, s, lq, m);
+    }
+    __syncthreads();
+    pend_finish(g, pend, max_rings, covs);
     __syncthreads();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
@@ -1086,15 +1183,24 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int m
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
     __shared__ int owned[PTS];
+    __shared__ PendingKnn<KN, PTS> pend;
+    if (threadIdx.x == 0) pend.n = 0;
+    __syncthreads();
     const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
     const int s = blockIdx.x * PTS + lq;
     bool mine = false;
     if (s < g.m) {
         const float4 P = g.pts[s];
         mine = bucket_owner(P.x, P.y, P.z, world) == rank;  // group-uniform
-        if (mine) estimate_cov<KN, NL>(g, s, sub, max_rings, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS);
+        if (mine) {
+            TopK<KN> m;
+            if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+                pend_push(pend, s, lq, m);
+        }
     }
     if (sub == 0) owned[lq] = mine ? 1 : 0;
+    __syncthreads();
+    pend_finish(g, pend, max_rings, covs);
     __syncthreads();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m && owned[threadIdx.x]) {
