@@ -179,7 +179,8 @@ __global__ void k_vmap_points(const float* __restrict__ vmap, int npix, float th
 
 }  // namespace icp
 
-static constexpr size_t DBG_BYTES = 64 + 24 * 1024 * 4 * sizeof(long long);  // dev statistics ("search_stats")
+static constexpr size_t DBG_ITER_BYTES = 64 + 24 * 1024 * 4 * sizeof(long long);
+static constexpr size_t DBG_BYTES = DBG_ITER_BYTES + 8192 * 4 * sizeof(long long);  // dev statistics ("search_stats"): + the normal kernel's blocks
 
 // ---- helpers --------------------------------------------------------------------------------------------------------
 // Every entry point runs on the context's device and leaves the calling thread's current device as it found it (a
@@ -1302,6 +1303,31 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
                         it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / nb, amax, b / nb, bmax, bmax_miss,
                         b_over2, b_over5, total_miss, with_miss, r / nb, rmax);
+            }
+            {   // eager normal estimation: 4 stamps per block (start, ring 1 done, stragglers done, eigen done)
+                const long long* t = (const long long*)(raw.data() + DBG_ITER_BYTES);
+                const int nb = (int)((ctx->map_m + 63) / 64);
+                if (nb > 0 && nb <= 8192 && t[0] != 0) {
+                    long long first = t[0], last_end = t[3];
+                    double a = 0, b = 0, e = 0, amax = 0, bmax = 0;
+                    int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = 0; i < nb; ++i) {
+                        const long long* q = t + 4 * i;
+                        if (q[0] < first) first = q[0];
+                        if (q[3] > last_end) last_end = q[3];
+                        const double da = (q[1] - q[0]) * 0.01, db = (q[2] - q[1]) * 0.01, de = (q[3] - q[2]) * 0.01;
+                        a += da; b += db; e += de;
+                        if (da > amax) amax = da;
+                        if (db > bmax) bmax = db;
+                        int bin = (int)((q[3] - q[0]) * 0.01 / 10.0);
+                        hist[bin > 7 ? 7 : bin]++;
+                    }
+                    long long last_start = first;
+                    for (int i = 0; i < nb; ++i) if (t[4 * i] > last_start) last_start = t[4 * i];
+                    fprintf(stderr, "[icp normals] blocks=%d span %.1f us (last block starts at %.1f); ring 1 mean %.1f max %.1f; stragglers mean %.1f max %.1f; eigen mean %.1f; block duration histogram (10 us bins): %d %d %d %d %d %d %d %d\n",
+                            nb, (last_end - first) * 0.01, (last_start - first) * 0.01, a / nb, amax, b / nb, bmax, e / nb,
+                            hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+                }
             }
             (void)hipMemset(ctx->dbg_counts.ptr, 0, DBG_BYTES);
         }

@@ -1146,7 +1146,11 @@ __global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(Gr
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
     __shared__ PendingKnn<KN, PTS> pend;
-    if (threadIdx.x == 0) pend.n = 0;
+    long long* stamps = (g.stamps && gridDim.x <= 8192 && NL == 4) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
+    if (threadIdx.x == 0) {
+        pend.n = 0;
+        if (stamps) stamps[0] = wall_clock64();
+    }
     __syncthreads();
     const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
     const int s = blockIdx.x * PTS + lq;
@@ -1156,10 +1160,13 @@ __global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(Gr
             pend_push(pend, s, lq, m);
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
     pend_finish(g, pend, max_rings, covs);
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
