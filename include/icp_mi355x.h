@@ -111,6 +111,7 @@ int icp_synchronize(icp_ctx* ctx);
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "wave_misses" n (24)            workgroups with up to n cache misses search each of them with a whole wave
+ *   "narrow_from" n (6; -1: never)  from ICP iteration n on the fused kernel runs with 128 instead of 512 threads per block
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 (0)

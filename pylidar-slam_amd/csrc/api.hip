@@ -378,6 +378,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     if (k == "nn_cache") ctx->use_nn_cache = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
+    else if (k == "narrow_from") ctx->narrow_from = (int)iv;
     else if (k == "wave_misses") ctx->wave_misses = iv < 0 ? 0 : (int)iv;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;

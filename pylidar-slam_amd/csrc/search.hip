@@ -470,12 +470,15 @@ struct IterInputs {
 // MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
 // 131 072-point scan) resident in one round at 64 VGPRs (some spilled dwords), 6 allows 80 VGPRs (3 blocks per CU, a
 // quarter of the blocks in a second round)
-template <int MINW>
-__global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
-                                                                      RegState* __restrict__ st, AlignParams ap) {
+// THREADS = 512 (a 4-lane group for every query of the block: the early iterations, where most queries search) or 128
+// (one lane per query, two waves: the late iterations, where a handful of queries search and six of the eight waves
+// would only be launched to wait at the barriers).  Same queries per block, same partial rows, same bits.
+template <int MINW, int THREADS>
+__global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
+                                                                   RegState* __restrict__ st, AlignParams ap) {
     __shared__ float rowbuf[IT_QUERIES][9];
     __shared__ double part[4][NEQ];
-    __shared__ int2 cellstack[7][IT_THREADS];
+    __shared__ int2 cellstack[7][THREADS];
     __shared__ float4 miss_p[IT_QUERIES];   // transformed target + bits(query slot)
     __shared__ int4 miss_seed[IT_QUERIES];  // bits(seed d2), seed index, seed position
     __shared__ int nmiss;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
     if (nmiss > 0 && nmiss <= in.wave_misses) {  // block-uniform
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, listed = nmiss;
         int* wl = reinterpret_cast<int*>(&cellstack[0][0]) + wave * 64;  // the cell stacks are idle until B2
-        for (int m = wave; m < listed; m += IT_THREADS / 64) {
+        for (int m = wave; m < listed; m += THREADS / 64) {
             const float4 mp = miss_p[m];
             const int4 ms = miss_seed[m];
             Best b;
@@ -599,12 +602,13 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
     }
     // ---- phase B2: the misses, 4 lanes each, dense over the block's groups
     {
-        const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-        if (grp < nmiss) {  // group-uniform
+        const int sub = threadIdx.x & 3;
+        // (a loop with a single trip in the 512-thread build — written as one there: the loop form costs it spills)
+        for (int grp = threadIdx.x >> 2; grp < nmiss; grp += THREADS / 4) {  // group-uniform
             const float4 mp = miss_p[grp];
             const int4 ms = miss_seed[grp];
             const Best b = search_rows_group(g, mp.x, mp.y, mp.z, sub, in.max_rings, &cellstack[0][threadIdx.x],
-                                             IT_THREADS, __int_as_float(ms.x), ms.y, ms.z);
+                                             THREADS, __int_as_float(ms.x), ms.y, ms.z);
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
                 in.nn_cache[q0 + lq] = make_int2(b.pos, __float_as_int(sqrtf(b.second) * 0.999999f));
@@ -617,6 +621,7 @@ __global__ __launch_bounds__(IT_THREADS, MINW) void k_iterate_compact(GridView g
                     for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
                 }
             }
+            if (THREADS >= 4 * IT_QUERIES) break;  // a group for every query: one trip
         }
     }
     __syncthreads();
@@ -1480,12 +1485,17 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
     in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
-    if (ctx->iterate_dense)
-        hipLaunchKernelGGL(k_iterate_compact<8>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
-                           reg_state(ctx), make_align_params(ctx));
+    // from iteration `narrow_from` on (few NN-cache misses expected) the 128-thread build: a wrong guess costs time only
+    const bool narrow = use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
+    if (narrow)
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_QUERIES>), dim3(blocks), dim3(IT_QUERIES), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
+    else if (ctx->iterate_dense)
+        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
     else
-        hipLaunchKernelGGL(k_iterate_compact<6>, dim3(blocks), dim3(IT_THREADS), 0, ctx->stream, make_view(ctx), in,
-                           reg_state(ctx), make_align_params(ctx));
+        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;

@@ -313,6 +313,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
     variants = {"default": {}, "nocache": {"nn_cache": 0}, "cache_noseed": {"nn_cache": 1},
                 "sparse_build": {"iterate_dense": 0},
                 "no_wave_search": {"wave_misses": 0},
+                "never_narrow": {"narrow_from": -1}, "narrow_early": {"narrow_from": 1},
                 "wave_search_always": {"wave_misses": 128},
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
