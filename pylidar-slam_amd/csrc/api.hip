@@ -250,6 +250,8 @@ static int ensure_state(icp_ctx* ctx) {
         ICP_HIP(ctx, ctx->state.reserve(STATE_BLOCK + (size_t)newcap * (sizeof(double) + 6 * sizeof(float))));
         ctx->hist_cap = newcap;
         ctx->have_device_pose = false;  // a fresh allocation holds no registration result
+        ctx->stats_pending = false;     // ... and no grid statistics
+        ICP_HIP(ctx, hipMemsetAsync(ctx->state.ptr, 0, STATE_BLOCK, ctx->stream));
         ctx->loss_hist = (double*)(ctx->state.as<char>() + STATE_BLOCK);
         ctx->dx_hist = (float*)(ctx->state.as<char>() + STATE_BLOCK + (size_t)newcap * sizeof(double));
     }
@@ -333,7 +335,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->neq_own,    &ctx->zbuf,    &ctx->stage_in,   &ctx->stage_out,
                             &ctx->stage_out2, &ctx->flags,      &ctx->scan_a,  &ctx->scan_b,     &ctx->sort_tmp,
                             &ctx->keys_a,     &ctx->keys_b,     &ctx->vals_a,  &ctx->vals_b,     &ctx->counter,
-                            &ctx->grid_stats, &ctx->tgt4,       &ctx->slot_of_cell,
+                            &ctx->tgt4,       &ctx->slot_of_cell,
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cslot_of,
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
@@ -1196,7 +1198,7 @@ int icp_iteration_solve(icp_ctx* ctx) {
 }
 
 // layout of the pinned result block: the device state allocation verbatim (RegState | pad | loss[hist_cap] |
-// dx[6 * hist_cap]) followed by int stats[4]
+// dx[6 * hist_cap])
 static size_t state_bytes(const icp_ctx* ctx) {
     return STATE_BLOCK + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
 }
@@ -1204,7 +1206,7 @@ static size_t state_bytes(const icp_ctx* ctx) {
 static int enqueue_result_copy(icp_ctx* ctx) {
     if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
     icp_ctx::ResultSlot& r = ctx->rslot[(ctx->r_head + ctx->r_count) & 1];
-    const size_t sb = state_bytes(ctx), need = sb + 16;
+    const size_t sb = state_bytes(ctx), need = sb;
     if (need > r.bytes) {
         if (r.host) (void)hipHostFree(r.host);
         r.host = nullptr;
@@ -1220,7 +1222,6 @@ static int enqueue_result_copy(icp_ctx* ctx) {
     r.stats_m = ctx->stats_m_pending;
     r.stats_h = ctx->stats_h_pending;
     ctx->stats_pending = false;
-    if (r.stats) ICP_HIP(ctx, hipMemcpyAsync(h + sb, ctx->grid_stats.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
     r.eager_normals = ctx->normals_eager_count;
     ctx->normals_eager_count = 0;
@@ -1232,7 +1233,6 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     DeviceGuard device_guard(ctx);
     if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
     RegState st;
-    int stats[4] = {0, 0, 0, 0};
     const bool async = ctx->result_pending();
     bool had_stats;
     int64_t stats_m, eager;
@@ -1245,7 +1245,6 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         ICP_HIP(ctx, hipEventSynchronize(r.event));
         pinned = (const char*)r.host;
         memcpy(&st, pinned, sizeof(st));
-        memcpy(stats, pinned + state_bytes(ctx), sizeof(stats));
         had_stats = r.stats;
         stats_m = r.stats_m;
         stats_h = r.stats_h;
@@ -1259,12 +1258,10 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         eager = ctx->normals_eager_count;
         ctx->normals_eager_count = 0;
         ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-        if (had_stats)
-            ICP_HIP(ctx, hipMemcpyAsync(stats, ctx->grid_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (had_stats) {
-        ctx->occupied_cells = stats[0];
+    if (had_stats && st.grid_cells > 0) {
+        ctx->occupied_cells = st.grid_cells;
         ctx->stats_m = stats_m;
         ctx->stats_h = stats_h;
     }

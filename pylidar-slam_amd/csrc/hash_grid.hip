@@ -208,35 +208,75 @@ __global__ void k_build_rows(const GridEntry* __restrict__ table, unsigned int m
 // One 64-bit scan carries two sums at once: low word = points before the slot (cell start; the fine level holds exactly
 // m points, so coarse starts are that prefix minus m), high word = occupied FINE cells before the slot (row id).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ inline unsigned int grid_claim(GridEntry* __restrict__ table, unsigned int mask, unsigned long long key,
-                                          int* __restrict__ occupied) {
+// (the occupied cells are counted by the scan, not here: one atomic counter for ten thousand claims was two thirds of the
+// insertion kernel — 31 us)
+__device__ inline unsigned int grid_claim(GridEntry* __restrict__ table, unsigned int mask, unsigned long long key) {
     unsigned int slot = hash_cell(key) & mask;
     while (true) {
         unsigned long long old = atomicCAS(&table[slot].key, GRID_EMPTY, key);
-        if (old == GRID_EMPTY) atomicAdd(occupied, 1);  // occupied cells (feeds the cell-size auto-tuning)
         if (old == GRID_EMPTY || old == key) break;
         slot = (slot + 1) & mask;
     }
     return slot;
 }
 
+// lanes of a wave that hold the same key form a group: `leader` = its lowest lane, `rank` = position of this lane in the
+// group, `size` = lanes in the group (ballots only, no memory traffic; one trip per distinct key in the wave)
+__device__ inline void wave_group_by_key(unsigned long long key, bool active, int& leader, int& rank, int& size) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    leader = lane;
+    rank = 0;
+    size = 1;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const unsigned lo = __shfl((unsigned)(key & 0xffffffffull), l, 64), hi = __shfl((unsigned)(key >> 32), l, 64);
+        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        const unsigned long long same = __ballot(active && key == k);
+        if (active && key == k) {
+            leader = l;
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            size = __popcll(same);
+        }
+        todo &= ~same;
+    }
+}
+
+// Consecutive map points are spatial neighbours (scan order), so the lanes of a wave share a handful of cells — and, on the
+// coarse level, one or two: every point claiming its cell and bumping the cell's counter by itself put hundreds of
+// same-address atomics in a row (31 us for 100 000 points).  One claim and one counter update per (wave, cell) instead:
+// the group leader adds the group's size and every lane takes base + its rank.
 __global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h, float inv_hc,
                                GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
-                               int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
-                               int* __restrict__ stats) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+                               int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < m;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (active) {
+        x = xyz[3 * i + 0];
+        y = xyz[3 * i + 1];
+        z = xyz[3 * i + 2];
+    }
     const unsigned long long key = pack_cell(cell_coord(x, inv_h), cell_coord(y, inv_h), cell_coord(z, inv_h));
     const unsigned long long ckey = pack_cell(cell_coord(x, inv_hc), cell_coord(y, inv_hc), cell_coord(z, inv_hc));
-    const unsigned int slot = grid_claim(table, tsize - 1, key, &stats[0]);
-    const unsigned int cslot = tsize + grid_claim(table + tsize, tsize - 1, ckey, &stats[2]);
-    const int r = atomicAdd(&table[slot].count, 1);    // the two rank requests are in flight together
-    const int cr = atomicAdd(&table[cslot].count, 1);
-    slot_of[i] = (int)slot;
-    rank_of[i] = r;
-    cslot_of[i] = (int)cslot;
-    crank_of[i] = cr;
+    int leader, rank, size, cleader, crank, csize;
+    wave_group_by_key(key, active, leader, rank, size);
+    wave_group_by_key(ckey, active, cleader, crank, csize);
+    const int lane = threadIdx.x & 63;
+    int slot = 0, base = 0, cslot = 0, cbase = 0;
+    if (active && leader == lane) slot = (int)grid_claim(table, tsize - 1, key);
+    if (active && cleader == lane) cslot = (int)(tsize + grid_claim(table + tsize, tsize - 1, ckey));
+    if (active && leader == lane) base = atomicAdd(&table[slot].count, size);  // the two requests are in flight together
+    if (active && cleader == lane) cbase = atomicAdd(&table[cslot].count, csize);
+    slot = __shfl(slot, leader, 64);
+    base = __shfl(base, leader, 64);
+    cslot = __shfl(cslot, cleader, 64);
+    cbase = __shfl(cbase, cleader, 64);
+    if (!active) return;
+    slot_of[i] = slot;
+    rank_of[i] = base + rank;
+    cslot_of[i] = cslot;
+    crank_of[i] = cbase + crank;
 }
 
 __device__ inline unsigned long long grid_scan_item(const GridEntry* __restrict__ table, long long i, long long n,
@@ -405,8 +445,6 @@ int build_grid(icp_ctx* ctx) {
         if (change < 0.85 || change > 1.18) ctx->cell_h = (float)wanted;
     }
     const float inv_h = 1.0f / ctx->cell_h;
-    ICP_HIP(ctx, ctx->grid_stats.reserve(16));
-    ICP_HIP(ctx, hipMemsetAsync(ctx->grid_stats.ptr, 0, 16, ctx->stream));
     ctx->normals_ready = false;
     ctx->stats_pending = true;
     ctx->stats_m_pending = m;
@@ -416,12 +454,12 @@ int build_grid(icp_ctx* ctx) {
     const int nb = (int)((n2 + SCAN_TILE - 1) / SCAN_TILE);
     ICP_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * sizeof(unsigned long long)));
     unsigned long long* sums = ctx->scan_tmp.as<unsigned long long>();
-    int* ncells_dev = ctx->grid_stats.as<int>() + 1;
+    int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
     hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, table,
                        (unsigned int)n2);
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                       ctx->crank_of.as<int>(), ctx->grid_stats.as<int>());
+                       ctx->crank_of.as<int>());
     hipLaunchKernelGGL(k_grid_tile_sums, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, sums);
     hipLaunchKernelGGL(k_grid_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, ncells_dev);
     hipLaunchKernelGGL(k_grid_apply, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, sums,

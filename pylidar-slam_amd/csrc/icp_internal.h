@@ -87,6 +87,7 @@ struct RegState {
     int n_targets;   // valid target rows (from the last reduction)
     int n_worklist;  // map points queued for normal estimation in the current iteration
     long long normals_computed;
+    int grid_cells;  // occupied fine cells of the last grid build (feeds the cell-size auto-tuning; rides home with the result)
 };
 
 static constexpr size_t STATE_BLOCK = 256;  // bytes reserved for the RegState at the head of the state allocation
@@ -168,7 +169,6 @@ struct icp_ctx {
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
     int64_t normals_eager_count = 0;
     float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
-    icp::DeviceBuffer grid_stats;      // int[4]: occupied cells of the last build
     int occupied_cells = 0;
     double target_occupancy = 10.0;    // auto-tuning target, map points per occupied cell (option "target_occupancy")
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
