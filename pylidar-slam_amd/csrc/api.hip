@@ -39,7 +39,7 @@ void DeviceBuffer::release() {
 
 int prof_begin(icp_ctx* ctx, int kind) {
     Profile& p = ctx->prof;
-    if (!p.enabled || !((p.mask >> kind) & 1)) return -1;
+    if (!p.enabled || !p.sample_now || !((p.mask >> kind) & 1)) return -1;
     const int ev = (int)p.pending.size();
     if (ev >= (int)p.pool.size()) {
         hipEvent_t a, b;
@@ -381,6 +381,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
     else if (k == "narrow_from") ctx->narrow_from = (int)iv;
+    else if (k == "profile_every") ctx->prof.every = iv < 1 ? 1 : (int)iv;
     else if (k == "wave_misses") ctx->wave_misses = iv < 0 ? 0 : (int)iv;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
@@ -1154,6 +1155,8 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
     if ((rc = init_state(ctx, init_pose, from_last))) return rc;
     ctx->have_device_pose = true;
+    // event pairs around the kernels of every `every`-th registration only: a pair costs ~2 us of stream time
+    ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations++ % ctx->prof.every) == 0;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
     if (ctx->cost == ICP_COST_POINT_TO_PLANE && !ctx->normals_ready && ctx->map_m <= 2 * n &&

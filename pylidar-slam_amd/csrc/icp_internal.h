@@ -133,6 +133,9 @@ struct DeviceBuffer {
 struct Profile {
     bool enabled = false;
     int mask = 0;  // bit0 search, bit1 reduce, bit2 normals
+    int every = 1;             // "profile_every": registrations between two timed ones
+    long long registrations = 0;
+    bool sample_now = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     struct Rec { int kind; int ev; };
     std::vector<Rec> pending;
