@@ -69,23 +69,9 @@ static void prof_collect(icp_ctx* ctx) {
 }
 
 // ---- small kernels owned by the API layer ---------------------------------------------------------------------------
-struct Pose16 {
-    float m[16];
-};
-
-// keep_pose: the initial guess is the pose the state already holds — the result of the previous registration, i.e. the
-// constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip
 __global__ void k_state_init(RegState* st, Pose16 init, int keep_pose) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = keep_pose ? st->pose[k] : init.m[k];
-    for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
-    st->iter = 0;
-    st->done = 0;
-    st->converged = 0;
-    st->status = 0;
-    st->n_targets = 0;
-    st->n_worklist = 0;
-    st->normals_computed = 0;
+    state_init(st, init.m, keep_pose);
 }
 
 // general 4x4 inverse in f64 (np.linalg.inv(relative_pose), local_map.py:346); the same code on host and device
@@ -261,7 +247,7 @@ static int ensure_state(icp_ctx* ctx) {
     return ICP_OK;
 }
 
-static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = false) {
+static Pose16 pose_or_identity(const float* init_pose) {
     Pose16 p;
     if (init_pose) {
         memcpy(p.m, init_pose, sizeof(p.m));
@@ -269,6 +255,20 @@ static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = fal
         memset(p.m, 0, sizeof(p.m));
         p.m[0] = p.m[5] = p.m[10] = p.m[15] = 1.f;
     }
+    return p;
+}
+
+// targets packed and the state initialised by one launch (a launch of its own only when there are no targets)
+static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_pose, bool keep_pose = false) {
+    const Pose16 p = pose_or_identity(init_pose);
+    if (n > 0) return prepare_targets(ctx, ctx->tgt_ptr, n, &p, keep_pose);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = false) {
+    const Pose16 p = pose_or_identity(init_pose);
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -768,8 +768,7 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     ctx->tgt_mode = ICP_TARGETS_ALL;
     ctx->have_device_pose = false;  // the search re-initialises the device state: it no longer holds a registration
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
-    if ((rc = init_state(ctx, nullptr))) return rc;
+    if ((rc = prepare_targets_and_state(ctx, n, nullptr))) return rc;
     if ((rc = launch_search_raw(ctx))) return rc;
     if (neighbor_normals_out && (rc = launch_normals(ctx))) return rc;
     void *pdev, *ndev, *idev;
@@ -951,8 +950,7 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
     ctx->tgt_ptr = (const float*)in;
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
-    if ((rc = init_state(ctx, init_pose))) return rc;
+    if ((rc = prepare_targets_and_state(ctx, n, init_pose))) return rc;
     ctx->in_registration = true;
     const int iters = ctx->cfg.max_num_alignments;
     const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
@@ -1152,8 +1150,7 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
-    if ((rc = prepare_targets(ctx, ctx->tgt_ptr, n))) return rc;
-    if ((rc = init_state(ctx, init_pose, from_last))) return rc;
+    if ((rc = prepare_targets_and_state(ctx, n, init_pose, from_last))) return rc;
     ctx->have_device_pose = true;
     // event pairs around the kernels of every `every`-th registration only: a pair costs ~2 us of stream time
     ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations++ % ctx->prof.every) == 0;

@@ -303,17 +303,22 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 // Target preparation for a registration: [n,3] rows -> float4 (x, y, z, bits(row)), one aligned 16-byte load per target
 // in the iteration kernels.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
+__global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __restrict__ out, RegState* st, Pose16 init,
+                               int keep_pose) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st && i == 0) state_init(st, init.m, keep_pose);  // the registration state, by the same launch
     if (i >= n) return;
     out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n) {
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init, bool keep_pose) {
     ICP_HIP(ctx, ctx->tgt4.reserve((size_t)(n > 0 ? n : 1) * sizeof(float4)));
     if (n <= 0) return ICP_OK;
+    Pose16 p;
+    memset(p.m, 0, sizeof(p.m));
+    if (init) p = *init;
     hipLaunchKernelGGL(k_pack_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
-                       ctx->tgt4.as<float4>());
+                       ctx->tgt4.as<float4>(), init ? reg_state(ctx) : (RegState*)nullptr, p, keep_pose ? 1 : 0);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -157,7 +157,12 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // ---------------------------------------------------------------------------------------------------------------------
 // grid build
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size) {
+// + (seed_n > 0) the neighbours the last registration left in the NN cache -> original map indices, shifted by the
+// `evicted` oldest points this update drops: the seeds of the next frame's first iteration.  Must run while the old
+// cell-sorted positions still mean something, i.e. before the scatter of this build: it shares the first launch.
+__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int2* __restrict__ nn_cache,
+                             const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
+                             int* __restrict__ seed) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < size) {
         GridEntry e;
@@ -165,6 +170,12 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size) {
         e.start = 0;
         e.count = 0;
         table[i] = e;
+    }
+    if ((int)i < seed_n) {
+        const int pos = nn_cache[i].x;
+        int o = -1;
+        if (pos >= 0 && pos < old_m) o = __float_as_int(old_pts[pos].w) - evicted;
+        seed[i] = o;
     }
 }
 
@@ -406,10 +417,20 @@ static unsigned int next_pow2(unsigned int v) {
 int build_grid(icp_ctx* ctx) {
     const int64_t m = ctx->map_m;
     ctx->grid_valid = false;
-    if (m <= 0) return ICP_OK;
+    if (m <= 0) {
+        ctx->seed_job_n = 0;  // nothing to seed against
+        ctx->seed_n = 0;
+        return ICP_OK;
+    }
     if (m > (int64_t)1 << 30) {
         ctx->error = "local map too large";
         return ICP_ERR_INVALID_ARGUMENT;
+    }
+    // the pending NN-cache -> seed conversion reads the OLD cell-sorted points: a launch of its own if they are about to be
+    // reallocated, otherwise part of the clearing launch below
+    if (ctx->seed_job_n > 0 && ctx->sorted_pts.bytes < (size_t)m * sizeof(float4)) {
+        const int rc = run_seed_job(ctx);
+        if (rc) return rc;
     }
     const unsigned int tsize = next_pow2((unsigned int)(2 * m));
     ICP_HIP(ctx, ctx->table.reserve((size_t)2 * tsize * sizeof(GridEntry)));  // fine level, then the coarse level
@@ -455,8 +476,14 @@ int build_grid(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * sizeof(unsigned long long)));
     unsigned long long* sums = ctx->scan_tmp.as<unsigned long long>();
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
-    hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, table,
-                       (unsigned int)n2);
+    {
+        const int seed_n = ctx->seed_job_n;
+        ctx->seed_job_n = 0;
+        const long long span = n2 > seed_n ? n2 : (long long)seed_n;
+        hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
+                           (unsigned int)n2, ctx->nn_cache.as<int2>(), ctx->sorted_pts.as<float4>(), seed_n,
+                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>());
+    }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                        ctx->crank_of.as<int>());

@@ -90,6 +90,20 @@ struct RegState {
     int grid_cells;  // occupied fine cells of the last grid build (feeds the cell-size auto-tuning; rides home with the result)
 };
 
+// keep_pose: the initial guess is the pose the state already holds — the result of the previous registration, i.e. the
+// constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip
+__device__ inline void state_init(RegState* st, const float* init, int keep_pose) {
+    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = keep_pose ? st->pose[k] : init[k];
+    for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
+    st->iter = 0;
+    st->done = 0;
+    st->converged = 0;
+    st->status = 0;
+    st->n_targets = 0;
+    st->n_worklist = 0;
+    st->normals_computed = 0;
+}
+
 static constexpr size_t STATE_BLOCK = 256;  // bytes reserved for the RegState at the head of the state allocation
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -242,6 +256,9 @@ struct icp_ctx {
     double exchange_timeout_ms = 5000.0;  // option "exchange_timeout_ms"
     hipEvent_t switch_event = nullptr;  // orders a change of stream (icp_set_stream) behind the work of the old one
     // ---- scratch for projection / sampling / io
+    int seed_job_n = 0, seed_job_m = 0, seed_job_evicted = 0;  // NN cache -> frame seeds, pending for the next grid build
+    const void* zbuf_clean = nullptr;  // the z-buffer allocation the resolve kernel has left all-clear, and its size
+    int zbuf_clean_pixels = 0;
     icp::DeviceBuffer zbuf, stage_in, stage_out, stage_out2, flags, scan_a, scan_b, sort_tmp, keys_a, keys_b, vals_a,
         vals_b, counter;
     // ---- projective local map (row a19)
@@ -283,6 +300,7 @@ int launch_normals_install(icp_ctx* ctx, const float* by_index_dev);
 // before a grid rebuild: nn_cache of the last registration -> seeds of the next frame (`evicted` oldest points dropped;
 // indices_survive = false when the map is replaced wholesale)
 int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive);
+int run_seed_job(icp_ctx* ctx);
 
 // ---- gauss_newton.hip
 AlignParams make_align_params(const icp_ctx* ctx);
@@ -302,7 +320,7 @@ int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, con
                            const float* mu_tgt, const float* mu_ref, double* host_out);
 
 // ---- projection.hip
-int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev);
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys = false);  // keep_keys: the z-buffer keys stay for the caller
 int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
 int kitti_correct_device(icp_ctx* ctx, const float* scan_dev, int64_t n, int stride, double* out_dev);
 
@@ -323,7 +341,12 @@ int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, doubl
 int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int64_t n, const double* rel_pose16,
                    double* out_dev);
 // targets -> float4 rows (x, y, z, bits(row)) in ctx->tgt4
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n);
+// targets -> float4 rows; with `init` the registration state is initialised by the same launch (init->m = the initial
+// guess; keep_pose: the pose the state already holds — the previous result — is the guess)
+struct Pose16 {
+    float m[16];
+};
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init = nullptr, bool keep_pose = false);
 int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                             long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
                             float* covs_dev, int* count_dev);

@@ -53,11 +53,12 @@ __global__ void k_project(const float* __restrict__ xyz, int n, ProjParams pp, u
     atomicMin(&zbuf[pix], key);
 }
 
-__global__ void k_project_resolve(const float* __restrict__ xyz, const unsigned long long* __restrict__ zbuf, int npix,
-                                  float* __restrict__ vmap, int* __restrict__ index) {
+__global__ void k_project_resolve(const float* __restrict__ xyz, unsigned long long* __restrict__ zbuf, int npix,
+                                  float* __restrict__ vmap, int* __restrict__ index, int leave_clean) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     const unsigned long long k = zbuf[p];
+    if (leave_clean && k != ~0ull) zbuf[p] = ~0ull;  // clean for the next projection: no clearing launch per frame
     float x = 0.f, y = 0.f, z = 0.f;
     int idx = -1;
     if (k != ~0ull) {
@@ -128,17 +129,22 @@ static ProjParams proj_params(const icp_ctx* ctx) {
     return pp;
 }
 
-int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev) {
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys) {
     const int npix = ctx->cfg.height * ctx->cfg.width;
     ICP_HIP(ctx, ctx->zbuf.reserve((size_t)npix * sizeof(unsigned long long)));
     unsigned long long* zb = ctx->zbuf.as<unsigned long long>();
     const ProjParams pp = proj_params(ctx);
-    hipLaunchKernelGGL(k_zbuf_clear, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, zb, npix);
+    if (ctx->zbuf_clean != zb || ctx->zbuf_clean_pixels != npix) {  // a fresh allocation / another image size
+        hipLaunchKernelGGL(k_zbuf_clear, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, zb, npix);
+        ctx->zbuf_clean = zb;
+        ctx->zbuf_clean_pixels = npix;
+    }
     if (n > 0)
         hipLaunchKernelGGL(k_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n, pp,
                            zb);
     hipLaunchKernelGGL(k_project_resolve, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, xyz_dev, zb, npix,
-                       vmap_dev, index_dev);
+                       vmap_dev, index_dev, keep_keys ? 0 : 1);
+    if (keep_keys) ctx->zbuf_clean = nullptr;  // the caller reads the (range, ~index) keys: cleared by the next projection
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -412,7 +412,7 @@ int pmap_iterate(icp_ctx* ctx, int* blocks_out) {
 int pmap_associate(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows9_dev, int* flags_dev) {
     const int npix = ctx->cfg.height * ctx->cfg.width;
     const int k_maps = (int)ctx->pm_slots.size();
-    int rc = project_device(ctx, xyz_dev, n, nullptr, nullptr);  // fills ctx->zbuf with (range, ~index) keys
+    int rc = project_device(ctx, xyz_dev, n, nullptr, nullptr, true);  // fills ctx->zbuf with (range, ~index) keys
     if (rc) return rc;
     hipLaunchKernelGGL(k_pm_assoc, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, xyz_dev, npix, k_maps,
                        ctx->zbuf.as<unsigned long long>(), ctx->pm_mv.as<float4>(), ctx->pm_mn.as<float4>(), rows9_dev,

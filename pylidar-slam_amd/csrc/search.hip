@@ -1510,13 +1510,26 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
 // nn_cache become the seeds of the next frame's first iteration.  `evicted` = oldest map points about to be dropped.
 int stash_frame_seeds(icp_ctx* ctx, int64_t evicted, bool indices_survive) {
     ctx->seed_n = 0;
+    ctx->seed_job_n = 0;
     if (!indices_survive || !ctx->frame_seed || ctx->cache_n <= 0 || ctx->cache_gen != ctx->grid_gen) return ICP_OK;
     const int n = (int)ctx->cache_n;
     ICP_HIP(ctx, ctx->seed_orig.reserve((size_t)n * sizeof(int)));
-    hipLaunchKernelGGL(k_cache_to_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nn_cache.as<int2>(),
-                       ctx->sorted_pts.as<float4>(), n, (int)ctx->cache_m, (int)evicted, ctx->seed_orig.as<int>());
-    ICP_HIP(ctx, hipGetLastError());
+    // the conversion rides in the clearing launch of the grid build that follows (build_grid -> run_seed_job)
+    ctx->seed_job_n = n;
+    ctx->seed_job_m = (int)ctx->cache_m;
+    ctx->seed_job_evicted = (int)evicted;
     ctx->seed_n = n;
+    return ICP_OK;
+}
+
+// the pending conversion as a launch of its own (the build is about to reallocate the cell-sorted points)
+int run_seed_job(icp_ctx* ctx) {
+    const int n = ctx->seed_job_n;
+    ctx->seed_job_n = 0;
+    if (n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_cache_to_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nn_cache.as<int2>(),
+                       ctx->sorted_pts.as<float4>(), n, ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>());
+    ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
