@@ -1181,9 +1181,9 @@ int icp_iteration_accumulate(icp_ctx* ctx) {
     if (!ctx || !ctx->in_registration) return ICP_ERR_INVALID_ARGUMENT;
     int rc;
     if (fused_path(ctx)) {
-        int blocks = 0;
-        if ((rc = launch_iterate_fused(ctx, &blocks))) return rc;
-        return launch_sum_partials(ctx, blocks);
+        int rows = 0, quad = 1;
+        if ((rc = launch_iterate_fused(ctx, &rows, &quad))) return rc;
+        return launch_sum_partials(ctx, rows, quad);
     }
     if ((rc = launch_search(ctx))) return rc;
     if (ctx->cost == ICP_COST_POINT_TO_POINT) return launch_reduce_p2p(ctx, false);
@@ -1281,8 +1281,11 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 long long first = t[0], last_start = t[0], last_end = t[3];
                 double a = 0, b = 0, r = 0, amax = 0, bmax = 0, rmax = 0;
                 int bmax_miss = 0, with_miss = 0, total_miss = 0, b_over2 = 0, b_over5 = 0;
+                int seen = 0;
                 for (int i = 0; i < nb; ++i) {
                     const long long* q = t + 4 * i;
+                    if (q[0] == 0) continue;  // the 512-queries-per-block shape launches a quarter of the blocks
+                    ++seen;
                     const long long t1 = q[1] & MASK;
                     const int miss = (int)(q[1] >> 48);
                     if (q[0] < first) first = q[0];
@@ -1299,8 +1302,8 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                     b_over5 += db > 5.0;
                 }
                 fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
-                        it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / nb, amax, b / nb, bmax, bmax_miss,
-                        b_over2, b_over5, total_miss, with_miss, r / nb, rmax);
+                        it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / seen, amax, b / seen, bmax, bmax_miss,
+                        b_over2, b_over5, total_miss, with_miss, r / seen, rmax);
             }
             {   // eager normal estimation: 4 stamps per block (start, ring 1 done, stragglers done, eigen done)
                 const long long* t = (const long long*)(raw.data() + DBG_ITER_BYTES);
@@ -1365,9 +1368,9 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
     const int poll = (poll_allowed && ctx->cfg.threshold_delta_pose > 0.f) ? ctx->cfg.poll_every : 0;
     for (int it = 0; it < iters; ++it) {
         if (fused_path(ctx)) {
-            int blocks = 0;
-            rc = launch_iterate_fused(ctx, &blocks);
-            if (!rc) rc = launch_sum_solve(ctx, blocks);
+            int rows = 0, quad = 1;
+            rc = launch_iterate_fused(ctx, &rows, &quad);
+            if (!rc) rc = launch_sum_solve(ctx, rows, quad);
         } else if (ctx->cost == ICP_COST_POINT_TO_POINT) {
             (rc = launch_search(ctx)) || (rc = launch_reduce_p2p(ctx, true));
         } else {

@@ -255,41 +255,47 @@ __global__ __launch_bounds__(RED_THREADS) void k_procrustes_cov(const float* __r
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
 
-// fixed-order sum of the per-block partial rows -> out[NEQ] (1024 threads: 32 row groups x 32 columns; the order of
-// the additions depends only on the launch geometry, never on timing)
-__device__ inline void sum_partials_block(const double* __restrict__ partials, int nblocks, double* out /* LDS or global */) {
+// fixed-order sum of the partial rows -> out[NEQ] (1024 threads: 32 row groups x 32 columns; the order of the additions
+// depends only on the geometry, never on timing).  Canonical order: four consecutive BASE rows form a super-row
+// (r0 + r1) + (r2 + r3) (rows past the end count as 0.0); the super-rows are added in the strided 8-accumulator pattern
+// below.  `quad` = 1: `partials` holds base rows (grouped here); 0: the producer already wrote super-rows (the
+// 512-queries-per-block shape of the fused iteration kernel: a quarter of the bytes for this single workgroup to load).
+__device__ inline double load_super_row(const double* __restrict__ partials, int nrows, int quad, int sr, int col) {
+    if (!quad) return partials[(size_t)sr * NEQ + col];
+    const int b = 4 * sr;
+    const double r0 = partials[(size_t)b * NEQ + col];
+    const double r1 = b + 1 < nrows ? partials[(size_t)(b + 1) * NEQ + col] : 0.0;
+    const double r2 = b + 2 < nrows ? partials[(size_t)(b + 2) * NEQ + col] : 0.0;
+    const double r3 = b + 3 < nrows ? partials[(size_t)(b + 3) * NEQ + col] : 0.0;
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ inline void sum_partials_block(const double* __restrict__ partials, int nrows, int quad,
+                                          double* out /* LDS or global */) {
     __shared__ double lds[32][NEQ];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int ns = quad ? (nrows + 3) / 4 : nrows;  // super-rows
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     int b = grp;
-    if (nblocks == 1024) {  // the 131072-point scan: all 32 loads of a thread in flight at once, same order of additions
-        double v[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = partials[(size_t)(grp + 32 * j) * NEQ + col];
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            s0 += v[8 * pass];
-            s1 += v[8 * pass + 1];
-            s2 += v[8 * pass + 2];
-            s3 += v[8 * pass + 3];
-            s4 += v[8 * pass + 4];
-            s5 += v[8 * pass + 5];
-            s6 += v[8 * pass + 6];
-            s7 += v[8 * pass + 7];
-        }
-        b = nblocks + grp;  // nothing left for the loops below
+    for (; b + 224 < ns; b += 256) {  // eight independent super-rows (8 or 32 loads) in flight
+        const double v0 = load_super_row(partials, nrows, quad, b, col);
+        const double v1 = load_super_row(partials, nrows, quad, b + 32, col);
+        const double v2 = load_super_row(partials, nrows, quad, b + 64, col);
+        const double v3 = load_super_row(partials, nrows, quad, b + 96, col);
+        const double v4 = load_super_row(partials, nrows, quad, b + 128, col);
+        const double v5 = load_super_row(partials, nrows, quad, b + 160, col);
+        const double v6 = load_super_row(partials, nrows, quad, b + 192, col);
+        const double v7 = load_super_row(partials, nrows, quad, b + 224, col);
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+        s4 += v4;
+        s5 += v5;
+        s6 += v6;
+        s7 += v7;
     }
-    for (; b + 224 < nblocks; b += 256) {  // eight independent loads in flight
-        s0 += partials[(size_t)b * NEQ + col];
-        s1 += partials[(size_t)(b + 32) * NEQ + col];
-        s2 += partials[(size_t)(b + 64) * NEQ + col];
-        s3 += partials[(size_t)(b + 96) * NEQ + col];
-        s4 += partials[(size_t)(b + 128) * NEQ + col];
-        s5 += partials[(size_t)(b + 160) * NEQ + col];
-        s6 += partials[(size_t)(b + 192) * NEQ + col];
-        s7 += partials[(size_t)(b + 224) * NEQ + col];
-    }
-    for (; b < nblocks; b += 32) s0 += partials[(size_t)b * NEQ + col];
+    for (; b < ns; b += 32) s0 += load_super_row(partials, nrows, quad, b, col);
     lds[grp][col] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (threadIdx.x < NEQ) {
@@ -300,11 +306,11 @@ __device__ inline void sum_partials_block(const double* __restrict__ partials, i
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partials, int nblocks,
+__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partials, int nblocks, int quad,
                                                        const RegState* __restrict__ st, int check_done,
                                                        double* __restrict__ neq) {
     if (check_done && st->done) return;
-    sum_partials_block(partials, nblocks, neq);
+    sum_partials_block(partials, nblocks, quad, neq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const d
 }
 
 // single-GPU path: final sum of the partial rows + solve + pose update in one launch
-__global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks,
+__global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks, int quad,
                                                     RegState* __restrict__ st, AlignParams ap,
                                                     double* __restrict__ neq, double* __restrict__ loss_hist,
                                                     float* __restrict__ dx_hist, int hist_cap) {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
         for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
     }
     __shared__ double total[NEQ];
-    sum_partials_block(partials, nblocks, total);
+    sum_partials_block(partials, nblocks, quad, total);
     __syncthreads();
     if (done) return;
     if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
 // this rank's s + 1 contribution, which is sent after this rank has read every slot of s: two parities suffice.
 // On a timeout (a peer died or never launched) the registration stops with ICP_ERR_EXCHANGE; later launches are no-ops.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __restrict__ partials, int nblocks,
+__global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __restrict__ partials, int nblocks, int quad,
                                                              RegState* __restrict__ st, AlignParams ap,
                                                              double* __restrict__ neq, double* __restrict__ loss_hist,
                                                              float* __restrict__ dx_hist, int hist_cap,
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __res
     }
     __shared__ double total[NEQ];
     __shared__ int arrived;
-    sum_partials_block(partials, nblocks, total);
+    sum_partials_block(partials, nblocks, quad, total);
     if (threadIdx.x == 0) arrived = 1;
     __syncthreads();
     if (done) return;  // identical on every rank (same state after the same solves): nobody exchanges
@@ -467,7 +473,7 @@ int launch_reduce(icp_ctx* ctx) {
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, ctx->sorted_pts.as<float4>(),
                        ctx->normals.as<float4>(), ctx->tgt4.as<float4>(), ctx->nn_pos.as<int>(), n, reg_state(ctx),
                        make_align_params(ctx), ctx->partials.as<double>());
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, 1,
                        reg_state(ctx), 1, ctx->neq);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
@@ -475,15 +481,15 @@ int launch_reduce(icp_ctx* ctx) {
 }
 
 // final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
-int launch_sum_solve(icp_ctx* ctx, int blocks) {
+int launch_sum_solve(icp_ctx* ctx, int blocks, int quad) {
     if (ctx->exchange_on) {
         ExchangeView x = ctx->xview;
         x.timeout_ticks = (long long)(ctx->exchange_timeout_ms * 1.0e5);  // 100 MHz
         hipLaunchKernelGGL(k_sum_exchange_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(),
-                           blocks, reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
-                           ctx->hist_cap, x);
+                           blocks, quad, reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
+                           ctx->dx_hist, ctx->hist_cap, x);
     } else {
-        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, quad,
                            reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
                            ctx->hist_cap);
     }
@@ -491,8 +497,8 @@ int launch_sum_solve(icp_ctx* ctx, int blocks) {
     return ICP_OK;
 }
 
-int launch_sum_partials(icp_ctx* ctx, int blocks) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+int launch_sum_partials(icp_ctx* ctx, int blocks, int quad) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, quad,
                        reg_state(ctx), 1, ctx->neq);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
@@ -522,7 +528,7 @@ int launch_solve(icp_ctx* ctx) {
 
 // out layout in ctx->stage_out: [0..21] floats (params, pose), then at byte 128 the loss (double), at byte 136 status (int)
 static int launch_solve_given(icp_ctx* ctx, int blocks, const float* x0) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, 1,
                        reg_state(ctx), 0, ctx->neq);
     Params6 p;
     for (int a = 0; a < 6; ++a) p.v[a] = x0 ? x0[a] : 0.f;
@@ -599,7 +605,7 @@ int launch_reduce_p2p(icp_ctx* ctx, bool solve) {
         const int rc = launch_sum_solve(ctx, blocks);
         if (rc) return rc;
     } else
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, 1,
                            reg_state(ctx), 1, ctx->neq);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
@@ -623,7 +629,7 @@ int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, con
         hipLaunchKernelGGL(k_procrustes_cov, dim3(blocks), dim3(RED_THREADS), 0, ctx->stream, tgt, ref, (int)n, mu,
                            ctx->partials.as<double>());
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks,
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, 1,
                        reg_state(ctx), 0, ctx->neq);
     ICP_HIP(ctx, hipGetLastError());
     ICP_HIP(ctx, hipMemcpyAsync(host_out, ctx->neq, NEQ * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

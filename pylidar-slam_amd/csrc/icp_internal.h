@@ -306,10 +306,10 @@ int run_seed_job(icp_ctx* ctx);
 AlignParams make_align_params(const icp_ctx* ctx);
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
-int launch_sum_solve(icp_ctx* ctx, int blocks);  // (with an exchange connected: + the all-reduce over the ranks)
-int launch_sum_partials(icp_ctx* ctx, int blocks);
+int launch_sum_solve(icp_ctx* ctx, int rows, int quad = 1);  // (with an exchange connected: + the all-reduce over the ranks)
+int launch_sum_partials(icp_ctx* ctx, int rows, int quad = 1);
 // fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
-int launch_iterate_fused(icp_ctx* ctx, int* blocks_out);
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out);  // rows written; quad: base rows (1) or super-rows (0)
 int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n,
                        float* residuals_dev);

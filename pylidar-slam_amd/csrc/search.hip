@@ -416,25 +416,37 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 static constexpr int IT_THREADS = 512;            // 128 queries x 4 lanes per block -> N/128 partial rows
 static constexpr int IT_QUERIES = IT_THREADS / 4;
 
-// per-block partial normal equations from the 9-float rows of the block's queries: 4 x 30 threads, element e of quarter
-// `qtr` of the queries, f64, fixed order (bit-reproducible); one partial row per block
+// per-block partial normal equations from the 9-float rows of the block's queries: for every 128 queries 4 x 30 threads,
+// element e of quarter `qtr` of them, f64, fixed order (bit-reproducible).  The canonical order of the whole sum
+// (gauss_newton.hip::sum_partials_block): 128 queries -> base row r = (p0 + p1) + (p2 + p3); four consecutive base rows
+// -> super-row (r0 + r1) + (r2 + r3); super-rows in the strided 8-accumulator pattern.  A block of 128 queries (Q = 128)
+// writes its base row, a block of 512 queries its super-row: a quarter of the rows for the summing kernel, same bits.
+template <int Q>
 __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials) {
-    if (threadIdx.x < 4 * NEQ) {
-        const int e = threadIdx.x & (NEQ - 1), qtr = threadIdx.x / NEQ;
+    constexpr int SUB = Q / IT_QUERIES;  // base rows per block
+    if ((int)threadIdx.x < SUB * 4 * NEQ) {
+        const int e = threadIdx.x & (NEQ - 1), qtr = (threadIdx.x / NEQ) & 3, sb = threadIdx.x / (4 * NEQ);
         double acc = 0.0;
         if (e < NEQ_USED) {
             int a, b2;
             neq_operands(e, a, b2);
-            const int j0 = qtr * (IT_QUERIES / 4);
+            const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
 #pragma unroll 8
             for (int j = 0; j < IT_QUERIES / 4; ++j) acc += (double)rowbuf[j0 + j][a] * (double)rowbuf[j0 + j][b2];
         }
-        part[qtr][e] = acc;
+        part[sb * 4 + qtr][e] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < NEQ)
-        partials[(size_t)blockIdx.x * NEQ + threadIdx.x] =
-            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < NEQ) {
+        const int e = threadIdx.x;
+        double r[SUB];
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+            r[sb] = (part[4 * sb][e] + part[4 * sb + 1][e]) + (part[4 * sb + 2][e] + part[4 * sb + 3][e]);
+        double v = r[0];
+        if (SUB == 4) v = (r[0] + r[1]) + (r[2] + r[3]);
+        partials[(size_t)blockIdx.x * NEQ + e] = v;
+    }
 }
 
 
@@ -470,17 +482,20 @@ struct IterInputs {
 // MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
 // 131 072-point scan) resident in one round at 64 VGPRs (some spilled dwords), 6 allows 80 VGPRs (3 blocks per CU, a
 // quarter of the blocks in a second round)
-// THREADS = 512 (a 4-lane group for every query of the block: the early iterations, where most queries search) or 128
-// (one lane per query, two waves: the late iterations, where a handful of queries search and six of the eight waves
-// would only be launched to wait at the barriers).  Same queries per block, same partial rows, same bits.
-template <int MINW, int THREADS>
+// Two shapes, 512 threads each:
+//   Q = 128 queries per block (a 4-lane group for every query: the early iterations, where most queries search);
+//   Q = 512 queries per block (one lane per query: the late iterations, where a handful of queries search — three
+//       quarters of the waves of the other shape would only be launched to wait at the barriers — and a quarter of the
+//       partial rows for the single workgroup that sums them).
+// Same bits either way (block_reduce_rows).
+template <int MINW, int THREADS, int Q>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                    RegState* __restrict__ st, AlignParams ap) {
-    __shared__ float rowbuf[IT_QUERIES][9];
-    __shared__ double part[4][NEQ];
+    __shared__ float rowbuf[Q][9];
+    __shared__ double part[Q / 32][NEQ];
     __shared__ int2 cellstack[7][THREADS];
-    __shared__ float4 miss_p[IT_QUERIES];   // transformed target + bits(query slot)
-    __shared__ int4 miss_seed[IT_QUERIES];  // bits(seed d2), seed index, seed position
+    __shared__ float4 miss_p[Q];   // transformed target + bits(query slot)
+    __shared__ int4 miss_seed[Q];  // bits(seed d2), seed index, seed position
     __shared__ int nmiss;
     if (st->done) return;  // block-uniform
     // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
@@ -493,9 +508,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         if (stamps) stamps[0] = wall_clock64();
     }
     __syncthreads();
-    const int q0 = blockIdx.x * IT_QUERIES;
+    const int q0 = blockIdx.x * Q;
     // ---- phase A: one lane per query
-    if (threadIdx.x < IT_QUERIES) {
+    if ((int)threadIdx.x < Q) {
         const int lq = threadIdx.x, qi = q0 + lq;
         float row[9];
 #pragma unroll
@@ -621,12 +636,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                     for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
                 }
             }
-            if (THREADS >= 4 * IT_QUERIES) break;  // a group for every query: one trip
+            if (THREADS >= 4 * Q) break;  // a group for every query: one trip
         }
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
-    block_reduce_rows(rowbuf, part, in.partials);
+    block_reduce_rows<Q>(rowbuf, part, in.partials);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
@@ -1465,12 +1480,16 @@ int launch_normals_install(icp_ctx* ctx, const float* by_index_dev) {
     return ICP_OK;
 }
 
-int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out) {
     const int n = (int)ctx->tgt_n;
-    const int blocks = n > 0 ? (int)(((long long)n * 4 + IT_THREADS - 1) / IT_THREADS) : 1;
-    ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
-    ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
     const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
+    // from iteration `narrow_from` on (few NN-cache misses expected) 512 queries per block, one lane each: a wrong guess
+    // costs time only
+    const bool narrow = use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
+    const int per_block = narrow ? IT_THREADS : IT_QUERIES;
+    const int blocks = n > 0 ? (n + per_block - 1) / per_block : 1;
+    ICP_HIP(ctx, ctx->partials.reserve((size_t)(n > 0 ? (n + IT_QUERIES - 1) / IT_QUERIES : 1) * NEQ * sizeof(double)));
+    ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
     const int tok = prof_begin(ctx, 0);
     IterInputs in;
     in.tgt = ctx->tgt4.as<float4>();
@@ -1485,16 +1504,14 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
     in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
-    // from iteration `narrow_from` on (few NN-cache misses expected) the 128-thread build: a wrong guess costs time only
-    const bool narrow = use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
     if (narrow)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_QUERIES>), dim3(blocks), dim3(IT_QUERIES), 0, ctx->stream,
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
     else if (ctx->iterate_dense)
-        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
     else
-        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
@@ -1502,7 +1519,8 @@ int launch_iterate_fused(icp_ctx* ctx, int* blocks_out) {
     ctx->cache_n = n;  // nn_cache now describes these targets against the current grid
     ctx->cache_m = ctx->map_m;
     ctx->cache_gen = ctx->grid_gen;
-    *blocks_out = blocks;
+    *rows_out = blocks;
+    *quad_out = narrow ? 0 : 1;  // base rows (summed four by four first) or super-rows already
     return ICP_OK;
 }
 
