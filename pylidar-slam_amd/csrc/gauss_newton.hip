@@ -321,9 +321,10 @@ __global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const d
                                               int hist_cap) {
     if (blockIdx.x != 0) return;
     if (st->done) return;  // wave-uniform
-    float pose_in[16];
+    float pose_in[16], params_in[6];
     for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
-    solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap, st->iter, pose_in);
+    for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
+    solve_and_update(st, neq, ap, loss_hist, dx_hist, hist_cap, st->iter, pose_in, params_in);
 }
 
 // single-GPU path: final sum of the partial rows + solve + pose update in one launch
@@ -334,18 +335,20 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     // the state words are requested first and consumed last: their latency hides behind the partial-row loads
     const int done = st->done;
     int it = 0;
-    float pose_in[16];
+    float pose_in[16], params_in[6];
     if (threadIdx.x < 64) {  // the solving wave (uniform addresses: one transaction)
         it = st->iter;
 #pragma unroll
         for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
     }
     __shared__ double total[NEQ];
     sum_partials_block(partials, nblocks, quad, total);
     __syncthreads();
     if (done) return;
     if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
-    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
+    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -369,11 +372,13 @@ __global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __res
                                                              ExchangeView x) {
     const int done = st->done;
     int it = 0;
-    float pose_in[16];
+    float pose_in[16], params_in[6];
     if (threadIdx.x < 64) {
         it = st->iter;
 #pragma unroll
         for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
     }
     __shared__ double total[NEQ];
     __shared__ int arrived;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_sum_exchange_solve(const double* __res
     }
     if (threadIdx.x == 0) *x.seq = seq;
     __syncthreads();
-    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in);
+    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in);
 }
 
 // align() on given correspondences: writes params = x0 + dx [6], pose[16] = build_pose_matrix(params) (f32) and loss

@@ -223,10 +223,7 @@ __device__ inline void solve_core(const double* __restrict__ neq, AlignParams ap
 // the step applied to a RegState in place (lane 0 of the wave writes)
 __device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
                                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
-                                        int it, const float* pose_in) {
-    float params_in[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
+                                        int it, const float* pose_in, const float* params_in) {
     SolveOut o;
     solve_core(neq, ap, it, pose_in, params_in, o);
     if ((threadIdx.x & 63) != 0) return;
