@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out/${1:-final}; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err; tail -c 600 $OUT/bench_line.json; echo
-for s in 2 4 8; do timeout 300 python bench.py --sequences-per-gpu $s --no-cpu-baseline --loop-steps 0 > $OUT/bench_s$s.json 2> $OUT/bench_s$s.err; done
+for s in 2 3 4; do timeout 300 python bench.py --sequences-per-gpu $s --no-cpu-baseline --loop-steps 0 > $OUT/bench_s$s.json 2> $OUT/bench_s$s.err; done
 timeout 300 python bench.py --trajectory pingpong_r01 --no-cpu-baseline --loop-steps 0 > $OUT/bench_r01traj.json 2> $OUT/bench_r01traj.err
 timeout 300 python bench.py --pipeline 2 --no-cpu-baseline --loop-steps 0 > $OUT/bench_pipe2.json 2> $OUT/bench_pipe2.err
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
