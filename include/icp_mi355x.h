@@ -111,10 +111,11 @@ int icp_synchronize(icp_ctx* ctx);
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "wave_misses" n (24)            workgroups with up to n cache misses search each of them with a whole wave
- *   "narrow_from" n (6; -1: never)  from ICP iteration n on the fused kernel runs with 128 instead of 512 threads per block
+ *   "narrow_from" n (6; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each (few
+ *                                   searches expected), instead of 128 with a 4-lane group each; same bits
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
- *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 (0)
+ *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 | 2 (0)
  *   "profile_every" n (1)           icp_profile_enable times the kernels of every n-th registration only (an event pair
  *                                   costs ~2 us of stream time: 40 pairs per frame are 10 % of a 0.8 ms registration)
  * The library reads no environment variables. */
