@@ -477,6 +477,56 @@ def test_c2_full_size_registration_vs_reference_and_oracle(torch_cuda, O):
         np.testing.assert_allclose(res.losses[-1], orc.traces[-1].loss[-1], rtol=1e-3)
 
 
+def test_c2_full_size_properties(torch_cuda, O):
+    """Size-independent properties at the headline size (131072-point scan, 100k-point map, 20 iterations), where the
+    oracle is too slow to be run case by case:
+      * order invariance — shuffling the scan rows or the map rows changes which workgroup sums what, not the problem:
+        same pose to float32 reduction noise;
+      * rigid equivariance — map and initial guess moved by the same rigid G: the result moves by G;
+      * fixed point — restarting from the converged pose moves it by less than the noise floor of the last iterations;
+      * every reported neighbour is a true nearest neighbour (brute force over the whole map on a sample)."""
+    scan, model = _c2_inputs()
+    rng = np.random.default_rng(11)
+
+    def register(points, map_points, init=None, iters=20):
+        ctx = _ctx(height=64, width=2048, max_num_alignments=iters, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                   sigma=0.3)
+        ctx.map_set(map_points)
+        r = ctx.register(points, init)
+        ctx.close()
+        return r
+
+    base = register(scan, model)
+    assert base.iterations == 20
+    # ---- order invariance
+    r_scan = register(scan[rng.permutation(scan.shape[0])], model)
+    r_map = register(scan, model[rng.permutation(model.shape[0])])
+    for name, r in (("scan order", r_scan), ("map order", r_map)):
+        dt, dr = O.pose_error(r.pose, base.pose)
+        assert dt < 2e-6 and dr < 2e-6, (name, dt, dr)
+        np.testing.assert_allclose(r.losses[-1], base.losses[-1], rtol=1e-5)
+    # ---- rigid equivariance
+    G = O.build_pose_matrix(np.array([1.5, -0.7, 0.2, 0.02, -0.03, 0.4], np.float32)).astype(np.float64)
+    moved = (model.astype(np.float64) @ G[:3, :3].T + G[:3, 3]).astype(np.float32)
+    r_g = register(scan, moved, init=G.astype(np.float32))
+    expect = (G @ base.pose.astype(np.float64)).astype(np.float32)
+    dt, dr = O.pose_error(r_g.pose, expect)
+    assert dt < 1e-4 and dr < 1e-4, ("equivariance", dt, dr)  # float32 re-expression of the map: ~1e-6 per coordinate
+    # ---- fixed point
+    again = register(scan, model, init=base.pose, iters=3)
+    dt, dr = O.pose_error(again.pose, base.pose)
+    assert dt < 2e-5 and dr < 2e-5, ("fixed point", dt, dr)
+    # ---- exactness of the neighbours at the converged pose
+    ctx = _ctx(height=64, width=2048)
+    ctx.map_set(model)
+    sample = (scan[::97].astype(np.float64) @ base.pose[:3, :3].astype(np.float64).T + base.pose[:3, 3]).astype(np.float32)
+    _, _, ix = ctx.nearest_neighbor_search(sample, with_normals=False, with_index=True)
+    _, bd2 = O.brute_force_nn(sample, model)
+    d2 = ((sample.astype(np.float64) - model[ix].astype(np.float64)) ** 2).sum(axis=1)
+    np.testing.assert_allclose(d2, bd2, rtol=2e-6, atol=1e-12)
+    ctx.close()
+
+
 # ---- projective local map (SURVEY §8 row a19) ---------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def golden_projective():
