@@ -75,31 +75,53 @@ __device__ inline void scan_strided4(const GridView& g, int start, int count, in
 // its candidates strided over the lanes, ring r >= 1 = the shell split over the lanes), pruned by box distance against
 // the best so far, one group reduction per ring.  Returns true as soon as the best is provably exact on this level.
 __device__ inline bool coop_rings(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end,
-                                  Best& b) {
+                                  Best& b, int2* __restrict__ stack, int stride) {
     const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
     const float h = lv.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
     const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const int lane0 = (int)(threadIdx.x & 63) & ~3;  // first lane of the group within its wave
     for (int r = r_begin; r <= r_end; ++r) {
         int start, count;
         if (r == 0) {
             if (grid_lookup(lv, cx, cy, cz, start, count)) scan_strided4(lv, start, count, sub, px, py, pz, b);
         } else {
+            // the shell's cells are PROBED one lane each, seven per lane at a time, and SCANNED by the four lanes together
+            // (16 candidates per round): a coarse cell of several hundred points used to be one lane's to walk alone
             const int side = 2 * r + 1, total = side * side * side;
-            for (int c = sub; c < total; c += 4) {
-                const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
-                const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
-                if (m < r) continue;  // interior: visited by the previous rings
-                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
-                const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
-                if (gap2 > b.d2) {
-                    b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
-                    continue;
+            for (int c0 = 0; c0 < total; c0 += 28) {  // group-uniform
+                int nl = 0;
+                for (int k = 0; k < 7; ++k) {
+                    const int c = c0 + sub + 4 * k;
+                    if (c >= total) break;
+                    const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
+                    const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+                    if (m < r) continue;  // interior: visited by the previous rings
+                    const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                    const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+                    if (gap2 > b.d2) {
+                        b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
+                        continue;
+                    }
+                    if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count)) {
+                        stack[nl * stride] = make_int2(start, count);
+                        ++nl;
+                    }
                 }
-                if (grid_lookup(lv, cx + ox, cy + oy, cz + oz, start, count))
-                    scan_cell_1nn(lv, start, count, px, py, pz, b);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int l = 0; l < 4; ++l) {
+                    const int n_l = __shfl(nl, lane0 + l, 64);  // group-uniform
+                    for (int k = 0; k < n_l; ++k) {
+                        const int2 e = stack[k * stride + (l - sub)];  // lane l's column sits next to this lane's
+                        scan_strided4(lv, e.x, e.y, sub, px, py, pz, b);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the next chunk overwrites the lists
             }
         }
         group_min4(b);
@@ -229,12 +251,12 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     if (!resolved) {
         // rings 2..max_rings of the fine level, then the coarse level (4x cells), every ring split over the 4 lanes
         if (g.dbg && sub == 0) atomicAdd(&g.dbg[2], 1);
-        resolved = max_rings >= 2 && coop_rings(g, px, py, pz, sub, 2, max_rings, b);
+        resolved = max_rings >= 2 && coop_rings(g, px, py, pz, sub, 2, max_rings, b, stack, stride);
         if (!resolved && g.ctable) {
             if (g.dbg && sub == 0) atomicAdd(&g.dbg[3], 1);
             // candidates of the coarse level carry positions of ITS point array: the winner is identified by its original
             // index (`consider` recognises the best so far by index, so meeting it again changes nothing)
-            resolved = coop_rings(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b);
+            resolved = coop_rings(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b, stack, stride);
             if (b.idx != 0x7fffffff) b.pos = g.pos_of_orig[b.idx];
         }
         if (!resolved && sub == 0) {  // farther than COARSE_RINGS coarse cells from every map point
