@@ -317,7 +317,8 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "wave_search_always": {"wave_misses": 128},
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
-                "lanes2": {"knn_lanes": 2}, "unfused": {"fuse_iteration": 0}}
+                "lanes2": {"knn_lanes": 2}, "knn_insert": {"knn_select": 0}, "knn_select": {"knn_select": 1},
+                "knn_select_lanes2": {"knn_select": 1, "knn_lanes": 2}, "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
         ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure",
@@ -357,6 +358,62 @@ def test_schedule_options_are_bit_identical(torch_cuda):
             if not np.array_equal(nrm, ref_nrm):
                 problems.append(f"{name}: normals differ ({np.abs(nrm - ref_nrm).max():.1e})")
     assert not problems, "\n".join(problems)
+
+
+def _knn_clouds():
+    """Point sets that stress the k-nearest-neighbour selection: a LiDAR map, a volume, exact duplicates (ties on the
+    k-th distance by the dozen), a lattice (every distance tied), isolated points, fewer than k + 1 points."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    rng = np.random.default_rng(21)
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 4)
+    clouds = {"lidar_map": make_fixed_map(cfg, scans, poses, ref_frame=3, num_points=30_000)}
+    clouds["volume"] = (rng.random((20_000, 3)) * np.array([30.0, 30.0, 6.0])).astype(np.float32)
+    base = (rng.normal(size=(1500, 3)) * np.array([10.0, 10.0, 1.0])).astype(np.float32)
+    clouds["duplicates"] = np.repeat(base, rng.integers(1, 24, size=base.shape[0]), axis=0)
+    ax = np.arange(24, dtype=np.float32) * 0.25
+    clouds["lattice"] = np.stack(np.meshgrid(ax, ax, ax[:12], indexing="ij"), axis=-1).reshape(-1, 3)
+    clouds["isolated"] = np.concatenate([base[:800], (rng.normal(size=(40, 3)) * 300 + 500).astype(np.float32)])
+    clouds["seven"] = base[:7].copy()
+    return clouds
+
+
+@pytest.mark.parametrize("neighbors", [10, 5, 20])
+def test_knn_selection_equals_sorted_insertion(torch_cuda, neighbors):
+    """Option "knn_select" (the k-th distance first by v_med3 lists, then the keys within it, certified by their count;
+    failures restarted by the wave path) gives the normals of the sorted-insertion search bit for bit — through the
+    sharded kernel (by original index), for two ranks, through the eager kernel of a registration and through the lazy
+    worklist kernel."""
+    for name, cloud in _knn_clouds().items():
+        out = {}
+        for sel in (0, 1):
+            ctx = _ctx(num_neighbors_normals=neighbors)
+            ctx.set_option("knn_select", sel)
+            ctx.map_set(cloud)
+            whole = ctx.map_normals_owned(0, 1).cpu().numpy()
+            halves = (ctx.map_normals_owned(0, 2) + ctx.map_normals_owned(1, 2)).cpu().numpy()
+            out[sel] = (whole, halves)
+            ctx.close()
+        assert np.array_equal(out[0][0][:, 3], np.ones(cloud.shape[0], np.float32)), name
+        assert np.isfinite(out[1][0]).all(), name
+        assert np.array_equal(out[0][0], out[1][0]), (name, np.abs(out[0][0] - out[1][0]).max())
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[0][1]), name
+        if cloud.shape[0] < 100:
+            continue
+        # eager kernel (a registration of at least half as many targets as map points) and lazy kernel (a bare search)
+        for sel in (0, 1):
+            ctx = _ctx(num_neighbors_normals=neighbors, max_num_alignments=1, threshold_delta_pose=0.0)
+            ctx.set_option("knn_select", sel)
+            ctx.map_set(cloud)
+            _, lazy, ix = ctx.nearest_neighbor_search(cloud[::3], with_index=True)
+            np.testing.assert_array_equal(lazy, out[0][0][ix, :3], err_msg=f"{name} lazy sel={sel}")
+            try:
+                ctx.register(cloud)  # eager normals of every map point, whatever becomes of the degenerate alignment
+            except RuntimeError:
+                pass
+            _, eager, ix = ctx.nearest_neighbor_search(cloud, with_index=True)
+            np.testing.assert_array_equal(eager, out[0][0][ix, :3], err_msg=f"{name} eager sel={sel}")
+            ctx.close()
 
 
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
