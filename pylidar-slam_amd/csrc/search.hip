@@ -1096,10 +1096,6 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, float* __
 // covariance as estimate_cov, bit for bit.
 // Returns 1: settled by ring 1, covariance written; 0: not settled, `m` (lane sub == 0) holds the merged list; -1: restart.
 // ---------------------------------------------------------------------------------------------------------------------
-// the 27 cells of a row (index (oz+1)*9 + (oy+1)*3 + (ox+1)) nearest first: own cell, 6 faces, 12 edges, 8 corners
-__constant__ unsigned char KNN_CELL_ORDER[27] = {13, 4,  10, 12, 14, 16, 22, 1,  3,  5,  7,  9,  11, 15,
-                                                 17, 19, 21, 23, 25, 0,  2,  6,  8,  18, 20, 24, 26};
-
 template <int KN, int PTS>
 struct SelectBuf {
     static constexpr int CAP = KN + 3;
@@ -1115,7 +1111,7 @@ __device__ inline void wave_lds_sync() {
 
 template <int KN, int NL, int PTS>
 __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int lq, float* __restrict__ cov,
-                                          int2* __restrict__ stack, int stride, SelectBuf<KN, PTS>& sel, TopK<KN>& m) {
+                                          SelectBuf<KN, PTS>& sel, TopK<KN>& m) {
     constexpr int CAP = SelectBuf<KN, PTS>::CAP;
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
@@ -1126,54 +1122,65 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
     const int2* __restrict__ r = g.rows + (size_t)g.row_of_pos[s] * ROW_STRIDE;
+    const int2 own = r[13];
     constexpr int CPL = ROW_STRIDE / NL;  // row entries per lane (entry 27 is padding)
+    const int2* __restrict__ rl = r + sub * CPL;  // this lane's row entries
     int2 cell[CPL];
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) cell[k] = r[sub * CPL + k];
+    for (int k = 0; k < CPL; ++k) cell[k] = rl[k];
     if (sub == 0) sel.n[lq] = 0;
-    // the row goes to LDS: every lane of the group reads every entry from there (entry c sits in the column of lane c / CPL)
-    int total = 0;  // candidates behind this lane's row entries
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        stack[k * stride] = cell[k];
-        if (sub * CPL + k < 27 && cell[k].y > 0) total += cell[k].y;
-    }
-    wave_lds_sync();
-    // EVERY cell is scanned by the NL lanes together, strided (lane `sub` takes points sub, sub + NL, ..): the lanes of a
-    // group read consecutive 16-byte points — one cache line per group and load instead of one per lane.  (One cell per
-    // lane, walked alone, made every wave-wide load touch 64 lines: the kernel was bound by the L1's line rate, not by
-    // issue.)  The cells come in the order own, faces, edges, corners; the bound that prunes them is shared by the
-    // group: each lane sees an even sample of every cell, so with J = ceil(KN / NL) the largest of the lanes' J-th
-    // smallest distances has >= KN points within it.
-    constexpr int W = 4;                   // candidates per lane and trip
-    constexpr int J = (KN + NL - 1) / NL;
-    const float gxm = fx, gxp = h - fx, gym = fy, gyp = h - fy, gzm = fz, gzp = h - fz;
-    auto cell_gap2 = [&](int c) {
-        const int ox = c % 3, oy = (c / 3) % 3, oz = c / 9;  // 0, 1, 2 <-> offsets -1, 0, +1
-        const float gx = ox == 1 ? 0.f : (ox == 0 ? gxm : gxp), gy = oy == 1 ? 0.f : (oy == 0 ? gym : gyp),
-                    gz = oz == 1 ? 0.f : (oz == 0 ? gzm : gzp);
-        return fmaf(gx, gx, fmaf(gy, gy, gz * gz));
-    };
+    const int own_last = own.x + own.y - 1;
     // ---- pass 1: distances only
     TopD<KN> t;
     t.init();
-    float bound = INFINITY;
-    for (int oi = 0; oi < 27; ++oi) {
-        const int c = KNN_CELL_ORDER[oi];
-        const int2 e = stack[(c % CPL) * stride + (c / CPL - sub)];
-        if (e.y <= 0 || cell_gap2(c) > bound) continue;  // group-uniform
-        const int last = e.x + e.y - 1;
-        for (int k = e.x + sub; k <= last; k += W * NL) {
-            float4 q[W];
+    for (int k = own.x + sub; k <= own_last; k += 4 * NL) {
+        const bool v1 = k + NL <= own_last, v2 = k + 2 * NL <= own_last, v3 = k + 3 * NL <= own_last;
+        const float4 q0 = g.pts[k], q1 = g.pts[v1 ? k + NL : k], q2 = g.pts[v2 ? k + 2 * NL : k],
+                     q3 = g.pts[v3 ? k + 3 * NL : k];
+        t.insert(point_d2(q0, px, py, pz));
+        t.insert(v1 ? point_d2(q1, px, py, pz) : INFINITY);
+        t.insert(v2 ? point_d2(q2, px, py, pz) : INFINITY);
+        t.insert(v3 ? point_d2(q3, px, py, pz) : INFINITY);
+    }
+    // the lane's occupied neighbour cells as a bit mask; their (start, count) is fetched again from the row (a cache hit)
+    // when the walk reaches them — a list in LDS cost 14 KB per workgroup, i.e. the occupancy that lets the whole map be
+    // resident in ONE round of workgroups (the kernel used to last two workgroup lifetimes for 1.2 rounds of work)
+    unsigned live = 0;
+    int total = 0;  // candidates behind this lane's row entries (the own cell counts once, with entry 13)
 #pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, last)];
-#pragma unroll
-            for (int i = 0; i < W; ++i) t.insert(k + i * NL <= last ? point_d2(q[i], px, py, pz) : INFINITY);
+    for (int k = 0; k < CPL; ++k) {
+        const int c = sub * CPL + k;
+        if (c >= 27 || cell[k].y <= 0) continue;
+        total += cell[k].y;
+        if (c != 13) live |= 1u << k;
+    }
+    {
+        unsigned todo = live;
+        int st = 0, cnt = 0, k = 0;
+        for (;;) {
+            if (k >= cnt) {
+                if (!todo) break;
+                const int kk = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                const int c = sub * CPL + kk;
+                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                            gz = axis_gap(c / 9 - 1, fz, h);
+                // this lane alone already knows KN points within its k-th distance: the merged k-th is no larger
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.kth()) continue;
+                const int2 e = rl[kk];
+                st = e.x;
+                cnt = e.y;
+                k = 0;
+            }
+            const int last = st + cnt - 1, k0 = st + k;
+            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
+            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+            t.insert(point_d2(q0, px, py, pz));
+            t.insert(k1 != k0 ? point_d2(q1, px, py, pz) : INFINITY);
+            t.insert(k2 != k1 ? point_d2(q2, px, py, pz) : INFINITY);
+            t.insert(k3 != k2 ? point_d2(q3, px, py, pz) : INFINITY);
+            k += 4;
         }
-        float b = t.d[J - 1];
-#pragma unroll
-        for (int o = 1; o < NL; o <<= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
-        bound = b;  // never grows: the lists only improve
     }
 #pragma unroll
     for (int o = 1; o < NL; o <<= 1) {  // butterfly: afterwards every lane of the group holds the same merged list
@@ -1185,33 +1192,62 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
         total += __shfl_xor(total, o, 64);
     }
     const float T = t.kth();  // group-uniform; +inf when the 27 cells hold fewer than KN points
+    wave_lds_sync();          // the cleared counter before the first append
     // ---- pass 2: the keys with d2 <= T
-    for (int oi = 0; oi < 27; ++oi) {
-        const int c = KNN_CELL_ORDER[oi];
-        const int2 e = stack[(c % CPL) * stride + (c / CPL - sub)];
-        if (e.y <= 0 || cell_gap2(c) > T) continue;  // every point of the cell is farther than T
-        const int last = e.x + e.y - 1;
-        for (int k = e.x + sub; k <= last; k += W * NL) {
-            float4 q[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, last)];
-            float d[W];
-            int add = 0;
-#pragma unroll
-            for (int i = 0; i < W; ++i) {
-                d[i] = point_d2(q[i], px, py, pz);
-                if (!(k + i * NL <= last && d[i] <= T)) d[i] = -1.f;  // marks "not a member" (distances are >= 0)
-                add += d[i] >= 0.f ? 1 : 0;
+    for (int k = own.x + sub; k <= own_last; k += 4 * NL) {
+        const bool v1 = k + NL <= own_last, v2 = k + 2 * NL <= own_last, v3 = k + 3 * NL <= own_last;
+        const float4 q0 = g.pts[k], q1 = g.pts[v1 ? k + NL : k], q2 = g.pts[v2 ? k + 2 * NL : k],
+                     q3 = g.pts[v3 ? k + 3 * NL : k];
+        const float d0 = point_d2(q0, px, py, pz), d1 = point_d2(q1, px, py, pz), d2 = point_d2(q2, px, py, pz),
+                    d3 = point_d2(q3, px, py, pz);
+        const bool a0 = d0 <= T, a1 = v1 && d1 <= T, a2 = v2 && d2 <= T, a3 = v3 && d3 <= T;
+        const int add = (int)a0 + (int)a1 + (int)a2 + (int)a3;
+        if (add) {
+            int slot = atomicAdd(&sel.n[lq], add);
+            if (a0 && slot < CAP) sel.key[lq][slot] = make_key(d0, __float_as_int(q0.w));
+            slot += (int)a0;
+            if (a1 && slot < CAP) sel.key[lq][slot] = make_key(d1, __float_as_int(q1.w));
+            slot += (int)a1;
+            if (a2 && slot < CAP) sel.key[lq][slot] = make_key(d2, __float_as_int(q2.w));
+            slot += (int)a2;
+            if (a3 && slot < CAP) sel.key[lq][slot] = make_key(d3, __float_as_int(q3.w));
+        }
+    }
+    {
+        unsigned todo = live;
+        int st = 0, cnt = 0, k = 0;
+        for (;;) {
+            if (k >= cnt) {
+                if (!todo) break;
+                const int kk = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                const int c = sub * CPL + kk;
+                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
+                            gz = axis_gap(c / 9 - 1, fz, h);
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > T) continue;  // every point of the cell is farther than T
+                const int2 e = rl[kk];
+                st = e.x;
+                cnt = e.y;
+                k = 0;
             }
+            const int last = st + cnt - 1, k0 = st + k;
+            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
+            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
+            const float d0 = point_d2(q0, px, py, pz), d1 = point_d2(q1, px, py, pz), d2 = point_d2(q2, px, py, pz),
+                        d3 = point_d2(q3, px, py, pz);
+            const bool a0 = d0 <= T, a1 = k1 != k0 && d1 <= T, a2 = k2 != k1 && d2 <= T, a3 = k3 != k2 && d3 <= T;
+            const int add = (int)a0 + (int)a1 + (int)a2 + (int)a3;
             if (add) {
                 int slot = atomicAdd(&sel.n[lq], add);
-#pragma unroll
-                for (int i = 0; i < W; ++i)
-                    if (d[i] >= 0.f) {
-                        if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
-                        ++slot;
-                    }
+                if (a0 && slot < CAP) sel.key[lq][slot] = make_key(d0, __float_as_int(q0.w));
+                slot += (int)a0;
+                if (a1 && slot < CAP) sel.key[lq][slot] = make_key(d1, __float_as_int(q1.w));
+                slot += (int)a1;
+                if (a2 && slot < CAP) sel.key[lq][slot] = make_key(d2, __float_as_int(q2.w));
+                slot += (int)a2;
+                if (a3 && slot < CAP) sel.key[lq][slot] = make_key(d3, __float_as_int(q3.w));
             }
+            k += 4;
         }
     }
     wave_lds_sync();
@@ -1240,6 +1276,8 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
     for (int u = 0; u < OWN; ++u)
         if (sub + NL * u < n) sel.key[lq][rank[u]] = mine[u];
     wave_lds_sync();
+    if (sub == 0)  // the list stays in LDS for the wave path (a point ring 1 does not settle): pad it to KN keys
+        for (int j = n; j < KN; ++j) sel.key[lq][j] = KEY_EMPTY;
 #pragma unroll
     for (int j = 0; j < KN; ++j) m.key[j] = j < n ? sel.key[lq][j] : KEY_EMPTY;
     const float bound1 = h + edge;
@@ -1348,7 +1386,7 @@ __device__ inline void estimate_point(const GridView& g, int s, int sub, int lq,
                                       SelectBuf<KN, SEL ? PTS : 1>& sel) {
     TopK<KN> m;
     if constexpr (SEL) {
-        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], stack, NRM_THREADS, sel, m);
+        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m);
         if (settled <= 0 && sub == 0) pend_push(pend, s, lq, m, settled < 0);
     } else {
         if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], stack, NRM_THREADS, m) && sub == 0) pend_push(pend, s, lq, m);
@@ -1415,6 +1453,62 @@ __global__ __launch_bounds__(NRM_THREADS, nrm_waves(KN, NL, SEL)) void k_normals
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
     pend_finish(g, pend, max_rings, covs);
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+    const int s2 = blockIdx.x * PTS + threadIdx.x;
+    if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+}
+
+// The eager kernel of the selection path (4 lanes per point).  What it is built around: with 5 waves per SIMD 1280 of the
+// 1563 workgroups of a 100 000-point map were resident at once, so the launch lasted TWO workgroup lifetimes for 1.2
+// rounds of work.  Here the per-lane cell lists are bit masks and the wave path reads its starting list from the
+// selection buffer: 12 KB of LDS and (for k <= 10) 72 registers -> 7 waves per SIMD, 1792 workgroups resident — one round.
+template <int KN>
+struct PendingIds {
+    int s[NRM_THREADS / 4];
+    int tag[NRM_THREADS / 4];
+    int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
+    int n;
+};
+
+template <int KN>
+__global__ __launch_bounds__(NRM_THREADS, KN <= 11 ? 7 : 4) void k_normals_select(GridView g, int max_rings,
+                                                                                 float4* __restrict__ normals,
+                                                                                 int* __restrict__ nflag) {
+    constexpr int NL = 4, PTS = NRM_THREADS / NL;
+    __shared__ float covs[PTS][7];
+    __shared__ SelectBuf<KN, PTS> sel;
+    __shared__ PendingIds<KN> pend;
+    long long* stamps = (g.stamps && gridDim.x <= 8192) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
+    if (threadIdx.x == 0) {
+        pend.n = 0;
+        if (stamps) stamps[0] = wall_clock64();
+    }
+    __syncthreads();
+    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
+    const int s = blockIdx.x * PTS + lq;
+    if (s < g.m) {
+        TopK<KN> m;
+        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m);
+        if (settled <= 0 && sub == 0) {
+            const int k = atomicAdd(&pend.n, 1);
+            pend.s[k] = s;
+            pend.tag[k] = lq | (settled < 0 ? PEND_RESTART : 0);
+        }
+    }
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < pend.n; k += NRM_THREADS / 64) {
+            const int tag = pend.tag[k], plq = tag & (PEND_RESTART - 1);
+            TopK<KN> m;
+#pragma unroll
+            for (int j = 0; j < KN; ++j) m.key[j] = sel.key[plq][j];  // the sorted, padded list of ring 1
+            finish_cov_wave<KN>(g, pend.s[k], lane, max_rings, m, covs[plq], pend.wl[wave], (tag & PEND_RESTART) != 0);
+        }
+    }
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
@@ -1652,7 +1746,16 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (ctx->knn_select) {  // the neighbourhood by selection (estimate_cov_select)
+    if (ctx->knn_select && NL == 4) {  // the neighbourhood by selection (estimate_cov_select), one round of workgroups
+        if (kn == 11)
+            hipLaunchKernelGGL((k_normals_select<11>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        else if (kn == 6)
+            hipLaunchKernelGGL((k_normals_select<6>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        else
+            hipLaunchKernelGGL((k_normals_select<21>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        return;
+    }
+    if (ctx->knn_select) {
         if (kn == 11)
             hipLaunchKernelGGL((k_normals_all<11, NL, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
         else if (kn == 6)
