@@ -1130,17 +1130,33 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
     for (int k = 0; k < CPL; ++k) cell[k] = rl[k];
     if (sub == 0) sel.n[lq] = 0;
     const int own_last = own.x + own.y - 1;
+    constexpr int W = 8;  // candidates per trip: a lane left alone on its SIMD waits a memory round trip per trip
     // ---- pass 1: distances only
     TopD<KN> t;
     t.init();
-    for (int k = own.x + sub; k <= own_last; k += 4 * NL) {
-        const bool v1 = k + NL <= own_last, v2 = k + 2 * NL <= own_last, v3 = k + 3 * NL <= own_last;
-        const float4 q0 = g.pts[k], q1 = g.pts[v1 ? k + NL : k], q2 = g.pts[v2 ? k + 2 * NL : k],
-                     q3 = g.pts[v3 ? k + 3 * NL : k];
-        t.insert(point_d2(q0, px, py, pz));
-        t.insert(v1 ? point_d2(q1, px, py, pz) : INFINITY);
-        t.insert(v2 ? point_d2(q2, px, py, pz) : INFINITY);
-        t.insert(v3 ? point_d2(q3, px, py, pz) : INFINITY);
+    for (int k = own.x + sub; k <= own_last; k += W * NL) {
+        float4 q[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
+#pragma unroll
+        for (int i = 0; i < W; ++i) t.insert(k + i * NL <= own_last ? point_d2(q[i], px, py, pz) : INFINITY);
+    }
+    // a dense own cell (>= KN points) bounds T before any neighbour cell is read: in dense regions — where a point has a
+    // thousand candidates in its 27 cells, and whose workgroups set the duration of the launch — nearly all of them are
+    // pruned by this.  Lane 0 carries the merged own-cell list on, the other lanes start over (the final merge must
+    // not see a distance twice).
+    float bound = INFINITY;
+    if (own.y >= KN) {  // group-uniform
+#pragma unroll
+        for (int o = 1; o < NL; o <<= 1) {
+            float other[KN];
+#pragma unroll
+            for (int j = 0; j < KN; ++j) other[j] = __shfl_xor(t.d[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < KN; ++j) t.insert(other[j]);
+        }
+        bound = t.kth();
+        if (sub != 0) t.init();
     }
     // the lane's occupied neighbour cells as a bit mask; their (start, count) is fetched again from the row (a cache hit)
     // when the walk reaches them — a list in LDS cost 14 KB per workgroup, i.e. the occupancy that lets the whole map be
@@ -1166,20 +1182,19 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
                 const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                             gz = axis_gap(c / 9 - 1, fz, h);
                 // this lane alone already knows KN points within its k-th distance: the merged k-th is no larger
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.kth()) continue;
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > fminf(t.kth(), bound)) continue;
                 const int2 e = rl[kk];
                 st = e.x;
                 cnt = e.y;
                 k = 0;
             }
             const int last = st + cnt - 1, k0 = st + k;
-            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
-            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
-            t.insert(point_d2(q0, px, py, pz));
-            t.insert(k1 != k0 ? point_d2(q1, px, py, pz) : INFINITY);
-            t.insert(k2 != k1 ? point_d2(q2, px, py, pz) : INFINITY);
-            t.insert(k3 != k2 ? point_d2(q3, px, py, pz) : INFINITY);
-            k += 4;
+            float4 q[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k0 + i, last)];
+#pragma unroll
+            for (int i = 0; i < W; ++i) t.insert(k0 + i <= last ? point_d2(q[i], px, py, pz) : INFINITY);
+            k += W;
         }
     }
 #pragma unroll
@@ -1193,24 +1208,28 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
     }
     const float T = t.kth();  // group-uniform; +inf when the 27 cells hold fewer than KN points
     wave_lds_sync();          // the cleared counter before the first append
-    // ---- pass 2: the keys with d2 <= T
-    for (int k = own.x + sub; k <= own_last; k += 4 * NL) {
-        const bool v1 = k + NL <= own_last, v2 = k + 2 * NL <= own_last, v3 = k + 3 * NL <= own_last;
-        const float4 q0 = g.pts[k], q1 = g.pts[v1 ? k + NL : k], q2 = g.pts[v2 ? k + 2 * NL : k],
-                     q3 = g.pts[v3 ? k + 3 * NL : k];
-        const float d0 = point_d2(q0, px, py, pz), d1 = point_d2(q1, px, py, pz), d2 = point_d2(q2, px, py, pz),
-                    d3 = point_d2(q3, px, py, pz);
-        const bool a0 = d0 <= T, a1 = v1 && d1 <= T, a2 = v2 && d2 <= T, a3 = v3 && d3 <= T;
-        const int add = (int)a0 + (int)a1 + (int)a2 + (int)a3;
+    // ---- pass 2: the keys with d2 <= T (four per trip: the keys need the points' fourth component, eight spill)
+    constexpr int W2 = 4;
+    for (int k = own.x + sub; k <= own_last; k += W2 * NL) {
+        float4 q[W2];
+#pragma unroll
+        for (int i = 0; i < W2; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
+        float d[W2];
+        int add = 0;
+#pragma unroll
+        for (int i = 0; i < W2; ++i) {
+            d[i] = point_d2(q[i], px, py, pz);
+            if (!(k + i * NL <= own_last && d[i] <= T)) d[i] = -1.f;  // marks "not a member" (distances are >= 0)
+            add += d[i] >= 0.f ? 1 : 0;
+        }
         if (add) {
             int slot = atomicAdd(&sel.n[lq], add);
-            if (a0 && slot < CAP) sel.key[lq][slot] = make_key(d0, __float_as_int(q0.w));
-            slot += (int)a0;
-            if (a1 && slot < CAP) sel.key[lq][slot] = make_key(d1, __float_as_int(q1.w));
-            slot += (int)a1;
-            if (a2 && slot < CAP) sel.key[lq][slot] = make_key(d2, __float_as_int(q2.w));
-            slot += (int)a2;
-            if (a3 && slot < CAP) sel.key[lq][slot] = make_key(d3, __float_as_int(q3.w));
+#pragma unroll
+            for (int i = 0; i < W2; ++i)
+                if (d[i] >= 0.f) {
+                    if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
+                    ++slot;
+                }
         }
     }
     {
@@ -1231,23 +1250,27 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
                 k = 0;
             }
             const int last = st + cnt - 1, k0 = st + k;
-            const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
-            const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
-            const float d0 = point_d2(q0, px, py, pz), d1 = point_d2(q1, px, py, pz), d2 = point_d2(q2, px, py, pz),
-                        d3 = point_d2(q3, px, py, pz);
-            const bool a0 = d0 <= T, a1 = k1 != k0 && d1 <= T, a2 = k2 != k1 && d2 <= T, a3 = k3 != k2 && d3 <= T;
-            const int add = (int)a0 + (int)a1 + (int)a2 + (int)a3;
+            float4 q[W2];
+#pragma unroll
+            for (int i = 0; i < W2; ++i) q[i] = g.pts[min(k0 + i, last)];
+            float d[W2];
+            int add = 0;
+#pragma unroll
+            for (int i = 0; i < W2; ++i) {
+                d[i] = point_d2(q[i], px, py, pz);
+                if (!(k0 + i <= last && d[i] <= T)) d[i] = -1.f;
+                add += d[i] >= 0.f ? 1 : 0;
+            }
             if (add) {
                 int slot = atomicAdd(&sel.n[lq], add);
-                if (a0 && slot < CAP) sel.key[lq][slot] = make_key(d0, __float_as_int(q0.w));
-                slot += (int)a0;
-                if (a1 && slot < CAP) sel.key[lq][slot] = make_key(d1, __float_as_int(q1.w));
-                slot += (int)a1;
-                if (a2 && slot < CAP) sel.key[lq][slot] = make_key(d2, __float_as_int(q2.w));
-                slot += (int)a2;
-                if (a3 && slot < CAP) sel.key[lq][slot] = make_key(d3, __float_as_int(q3.w));
+#pragma unroll
+                for (int i = 0; i < W2; ++i)
+                    if (d[i] >= 0.f) {
+                        if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
+                        ++slot;
+                    }
             }
-            k += 4;
+            k += W2;
         }
     }
     wave_lds_sync();
