@@ -180,7 +180,8 @@ struct icp_ctx {
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
-    icp::DeviceBuffer worklist;        // int[M]
+    icp::DeviceBuffer worklist;        // int[M]: lazy schedule: map points whose normal the search asked for; eager selection path: points ring 1 did not settle
+    icp::DeviceBuffer knn_ctr;         // int[2]: length of that queue, finished workgroups of the kernel that drains it
     bool grid_valid = false;
     uint64_t grid_gen = 0;             // bumped by every grid build: cell-sorted positions are only valid within one
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild

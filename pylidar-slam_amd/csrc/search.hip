@@ -1111,7 +1111,7 @@ __device__ inline void wave_lds_sync() {
 
 template <int KN, int NL, int PTS>
 __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int lq, float* __restrict__ cov,
-                                          SelectBuf<KN, PTS>& sel, TopK<KN>& m) {
+                                          SelectBuf<KN, PTS>& sel, TopK<KN>& m, int* __restrict__ tally = nullptr) {
     constexpr int CAP = SelectBuf<KN, PTS>::CAP;
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
@@ -1130,7 +1130,7 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
     for (int k = 0; k < CPL; ++k) cell[k] = rl[k];
     if (sub == 0) sel.n[lq] = 0;
     const int own_last = own.x + own.y - 1;
-    constexpr int W = 8;  // candidates per trip: a lane left alone on its SIMD waits a memory round trip per trip
+    constexpr int W = 4;  // candidates per lane and trip (measured: 8 costs more in idle list slots than it saves in trips)
     // ---- pass 1: distances only
     TopD<KN> t;
     t.init();
@@ -1141,26 +1141,8 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
 #pragma unroll
         for (int i = 0; i < W; ++i) t.insert(k + i * NL <= own_last ? point_d2(q[i], px, py, pz) : INFINITY);
     }
-    // a dense own cell (>= KN points) bounds T before any neighbour cell is read: in dense regions — where a point has a
-    // thousand candidates in its 27 cells, and whose workgroups set the duration of the launch — nearly all of them are
-    // pruned by this.  Lane 0 carries the merged own-cell list on, the other lanes start over (the final merge must
-    // not see a distance twice).
-    float bound = INFINITY;
-    if (own.y >= KN) {  // group-uniform
-#pragma unroll
-        for (int o = 1; o < NL; o <<= 1) {
-            float other[KN];
-#pragma unroll
-            for (int j = 0; j < KN; ++j) other[j] = __shfl_xor(t.d[j], o, 64);
-#pragma unroll
-            for (int j = 0; j < KN; ++j) t.insert(other[j]);
-        }
-        bound = t.kth();
-        if (sub != 0) t.init();
-    }
     // the lane's occupied neighbour cells as a bit mask; their (start, count) is fetched again from the row (a cache hit)
-    // when the walk reaches them — a list in LDS cost 14 KB per workgroup, i.e. the occupancy that lets the whole map be
-    // resident in ONE round of workgroups (the kernel used to last two workgroup lifetimes for 1.2 rounds of work)
+    // when the walk reaches them — a list in LDS costs 14 KB per workgroup, two waves per SIMD of occupancy
     unsigned live = 0;
     int total = 0;  // candidates behind this lane's row entries (the own cell counts once, with entry 13)
 #pragma unroll
@@ -1182,7 +1164,7 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
                 const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                             gz = axis_gap(c / 9 - 1, fz, h);
                 // this lane alone already knows KN points within its k-th distance: the merged k-th is no larger
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > fminf(t.kth(), bound)) continue;
+                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.kth()) continue;
                 const int2 e = rl[kk];
                 st = e.x;
                 cnt = e.y;
@@ -1207,17 +1189,20 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
         total += __shfl_xor(total, o, 64);
     }
     const float T = t.kth();  // group-uniform; +inf when the 27 cells hold fewer than KN points
+    if (tally && sub == 0) {  // dev: own-cell size and 27-cell candidates of the block's points
+        atomicAdd(&tally[0], own.y);
+        atomicAdd(&tally[1], total);
+    }
     wave_lds_sync();          // the cleared counter before the first append
-    // ---- pass 2: the keys with d2 <= T (four per trip: the keys need the points' fourth component, eight spill)
-    constexpr int W2 = 4;
-    for (int k = own.x + sub; k <= own_last; k += W2 * NL) {
-        float4 q[W2];
+    // ---- pass 2: the keys with d2 <= T
+    for (int k = own.x + sub; k <= own_last; k += W * NL) {
+        float4 q[W];
 #pragma unroll
-        for (int i = 0; i < W2; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
-        float d[W2];
+        for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
+        float d[W];
         int add = 0;
 #pragma unroll
-        for (int i = 0; i < W2; ++i) {
+        for (int i = 0; i < W; ++i) {
             d[i] = point_d2(q[i], px, py, pz);
             if (!(k + i * NL <= own_last && d[i] <= T)) d[i] = -1.f;  // marks "not a member" (distances are >= 0)
             add += d[i] >= 0.f ? 1 : 0;
@@ -1225,7 +1210,7 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
         if (add) {
             int slot = atomicAdd(&sel.n[lq], add);
 #pragma unroll
-            for (int i = 0; i < W2; ++i)
+            for (int i = 0; i < W; ++i)
                 if (d[i] >= 0.f) {
                     if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
                     ++slot;
@@ -1250,13 +1235,13 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
                 k = 0;
             }
             const int last = st + cnt - 1, k0 = st + k;
-            float4 q[W2];
+            float4 q[W];
 #pragma unroll
-            for (int i = 0; i < W2; ++i) q[i] = g.pts[min(k0 + i, last)];
-            float d[W2];
+            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k0 + i, last)];
+            float d[W];
             int add = 0;
 #pragma unroll
-            for (int i = 0; i < W2; ++i) {
+            for (int i = 0; i < W; ++i) {
                 d[i] = point_d2(q[i], px, py, pz);
                 if (!(k0 + i <= last && d[i] <= T)) d[i] = -1.f;
                 add += d[i] >= 0.f ? 1 : 0;
@@ -1264,13 +1249,13 @@ __device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int
             if (add) {
                 int slot = atomicAdd(&sel.n[lq], add);
 #pragma unroll
-                for (int i = 0; i < W2; ++i)
+                for (int i = 0; i < W; ++i)
                     if (d[i] >= 0.f) {
                         if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
                         ++slot;
                     }
             }
-            k += W2;
+            k += W;
         }
     }
     wave_lds_sync();
@@ -1483,60 +1468,72 @@ __global__ __launch_bounds__(NRM_THREADS, nrm_waves(KN, NL, SEL)) void k_normals
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
-// The eager kernel of the selection path (4 lanes per point).  What it is built around: with 5 waves per SIMD 1280 of the
-// 1563 workgroups of a 100 000-point map were resident at once, so the launch lasted TWO workgroup lifetimes for 1.2
-// rounds of work.  Here the per-lane cell lists are bit masks and the wave path reads its starting list from the
-// selection buffer: 12 KB of LDS and (for k <= 10) 72 registers -> 7 waves per SIMD, 1792 workgroups resident — one round.
+// The eager kernels of the selection path (4 lanes per point).  What the in-kernel timers and counters said about
+// k_normals_all (profiles/r02_e_*): every workgroup does the same work (121 +- 20 candidates per point) at the pace the
+// SIMD issues its resident waves' VALU instructions — EXCEPT where points are not settled by ring 1 (1.5 % of a LiDAR
+// map): each of those costs a whole wave about as many instructions as the ring-1 work of 16 points, they come in
+// clumps (isolated points are neighbours in the cell order too), and the launch lasted until the workgroup with seven
+// of them was through — 100 us for 58 us of issue.  So:
+//   k_normals_select: ring 1 only.  Settled points get their normal; the others are appended to a queue in HBM.  No
+//       wave path in the kernel: 12 KB of LDS, 72 registers (k <= 10) -> 7 waves per SIMD, every workgroup of a
+//       100 000-point map resident in ONE round (1280 of 1563 were, so the old kernel lasted two workgroup lifetimes).
+//   k_normals_queue: one wave per queued point, spread over the whole chip (rings 0.., coarse level, exhaustive scan).
+// The last workgroup of the second kernel to finish resets the queue counters for the next map.
 template <int KN>
-struct PendingIds {
-    int s[NRM_THREADS / 4];
-    int tag[NRM_THREADS / 4];
-    int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
-    int n;
-};
-
-template <int KN>
-__global__ __launch_bounds__(NRM_THREADS, KN <= 11 ? 7 : 4) void k_normals_select(GridView g, int max_rings,
-                                                                                 float4* __restrict__ normals,
-                                                                                 int* __restrict__ nflag) {
+__global__ __launch_bounds__(NRM_THREADS, KN <= 11 ? 7 : 4) void k_normals_select(GridView g, float4* __restrict__ normals,
+                                                                                 int* __restrict__ nflag,
+                                                                                 int* __restrict__ queue,
+                                                                                 int* __restrict__ queue_ctr) {
     constexpr int NL = 4, PTS = NRM_THREADS / NL;
-    __shared__ float covs[PTS][7];
+    __shared__ float covs[PTS][7];  // [6]: settled
     __shared__ SelectBuf<KN, PTS> sel;
-    __shared__ PendingIds<KN> pend;
+    __shared__ int tally[2];  // dev
     long long* stamps = (g.stamps && gridDim.x <= 8192) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
-    if (threadIdx.x == 0) {
-        pend.n = 0;
-        if (stamps) stamps[0] = wall_clock64();
+    if (stamps && threadIdx.x == 0) {
+        stamps[0] = wall_clock64();
+        tally[0] = tally[1] = 0;
     }
-    __syncthreads();
+    if (stamps) __syncthreads();
     const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
     const int s = blockIdx.x * PTS + lq;
     if (s < g.m) {
         TopK<KN> m;
-        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m);
-        if (settled <= 0 && sub == 0) {
-            const int k = atomicAdd(&pend.n, 1);
-            pend.s[k] = s;
-            pend.tag[k] = lq | (settled < 0 ? PEND_RESTART : 0);
+        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m, stamps ? tally : nullptr);
+        if (sub == 0) {
+            covs[lq][6] = settled > 0 ? 1.f : 0.f;
+            if (settled <= 0) queue[atomicAdd(&queue_ctr[0], 1)] = s;
         }
     }
     __syncthreads();
-    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
-    {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int k = wave; k < pend.n; k += NRM_THREADS / 64) {
-            const int tag = pend.tag[k], plq = tag & (PEND_RESTART - 1);
-            TopK<KN> m;
-#pragma unroll
-            for (int j = 0; j < KN; ++j) m.key[j] = sel.key[plq][j];  // the sorted, padded list of ring 1
-            finish_cov_wave<KN>(g, pend.s[k], lane, max_rings, m, covs[plq], pend.wl[wave], (tag & PEND_RESTART) != 0);
-        }
-    }
-    __syncthreads();
-    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+    if (stamps && threadIdx.x == 0) stamps[1] = stamps[2] = wall_clock64() | ((long long)min(tally[0] / PTS, 0x7fff) << 48);
     const int s2 = blockIdx.x * PTS + threadIdx.x;
-    if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
-    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+    if (threadIdx.x < PTS && s2 < g.m && covs[threadIdx.x][6] != 0.f) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64() | ((long long)min(tally[1] / PTS, 0x7fff) << 48);
+}
+
+template <int KN>
+__global__ __launch_bounds__(NRM_THREADS) void k_normals_queue(GridView g, int max_rings, float4* __restrict__ normals,
+                                                               int* __restrict__ nflag, const int* __restrict__ queue,
+                                                               int* __restrict__ queue_ctr) {
+    __shared__ int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
+    __shared__ float cov[NRM_THREADS / 64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = queue_ctr[0];
+    const int waves = gridDim.x * (NRM_THREADS / 64);
+    for (int i = blockIdx.x * (NRM_THREADS / 64) + wave; i < n; i += waves) {  // wave-uniform
+        const int s = queue[i];
+        TopK<KN> m;
+        finish_cov_wave<KN>(g, s, lane, max_rings, m, cov[wave], wl[wave], true);
+        if (lane == 0) normal_from_cov(cov[wave], s, normals, nflag);  // the lane that wrote the covariance
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&queue_ctr[1], 1) == (int)gridDim.x - 1) {  // every workgroup has read the count: clear for the next map
+            queue_ctr[0] = 0;
+            queue_ctr[1] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1769,13 +1766,26 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (ctx->knn_select && NL == 4) {  // the neighbourhood by selection (estimate_cov_select), one round of workgroups
-        if (kn == 11)
-            hipLaunchKernelGGL((k_normals_select<11>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else if (kn == 6)
-            hipLaunchKernelGGL((k_normals_select<6>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else
-            hipLaunchKernelGGL((k_normals_select<21>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+    if (ctx->knn_select && NL == 4) {  // the neighbourhood by selection: ring 1 for everyone, then the queue of the rest
+        if (!ctx->knn_ctr.ptr) {
+            if (ctx->knn_ctr.reserve(64) != hipSuccess || hipMemsetAsync(ctx->knn_ctr.ptr, 0, 64, ctx->stream) != hipSuccess)
+                return;  // reported by the caller's hipGetLastError
+        }
+        int* queue = ctx->worklist.as<int>();  // int[M], idle under the eager schedule
+        int* ctr = ctx->knn_ctr.as<int>();
+        int qblocks = blocks / 4;  // a wave per queued point, ~1.5 % of the map: a sixteenth of the waves of the first launch
+        qblocks = qblocks < 16 ? 16 : (qblocks > 1024 ? 1024 : qblocks);
+        const dim3 grid(blocks), qgrid(qblocks), block(NRM_THREADS);
+        if (kn == 11) {
+            hipLaunchKernelGGL((k_normals_select<11>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
+            hipLaunchKernelGGL((k_normals_queue<11>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
+        } else if (kn == 6) {
+            hipLaunchKernelGGL((k_normals_select<6>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
+            hipLaunchKernelGGL((k_normals_queue<6>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
+        } else {
+            hipLaunchKernelGGL((k_normals_select<21>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
+            hipLaunchKernelGGL((k_normals_queue<21>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
+        }
         return;
     }
     if (ctx->knn_select) {
