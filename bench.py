@@ -61,7 +61,7 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_POINT_ITER = 36  # 12 target xyz + 12 matched map xyz + 12 matched normal
 MIN_STEPS_FOR_HEADLINE = 50  # >= 50 timed frames
-PROFILE_EVERY = 5  # frames between two whose iteration kernels are bracketed by HIP events
+PROFILE_EVERY = 9  # frames between two whose iteration kernels are bracketed by HIP events (coprime with the 14-frame period)
 LOOP_PERIOD = 96
 SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
 
@@ -382,9 +382,10 @@ def main():
     for t_ in extra:
         t_.done.wait()
     if not args.no_profile:
-        # HIP-event pairs around the dominant kernel inside the timed region — on every PROFILE_EVERY-th frame: a pair
-        # costs ~2 us of stream time, and 40 of them per frame made the timed steps 10 % slower than the un-instrumented
-        # loop (5 is coprime with the 14-frame period of the trajectory: every phase of it gets sampled)
+        # HIP-event pairs around the dominant kernel inside the timed region — on every PROFILE_EVERY-th frame: an event
+        # breaks the back-to-back dispatch of the kernels around it; a frame with its 20 iteration launches bracketed is
+        # ~0.15 ms slower than an un-instrumented one (measured: 0.653 ms per step with --no-profile, 0.684 with every
+        # 5th frame bracketed).  9 is coprime with the 14-frame period of the trajectory: every phase of it gets sampled
         main_tr.ctx.set_option("profile_every", PROFILE_EVERY)
         main_tr.ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4: + normals
     res, elapsed = timed_region(extra, main_tr, args.steps, dist, dev)

@@ -339,7 +339,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cslot_of,
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
-                            &ctx->vox_out,    &ctx->seed_orig,  &ctx->knn_ctr};
+                            &ctx->vox_out,    &ctx->seed_orig};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -386,7 +386,6 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
-    else if (k == "knn_select") ctx->knn_select = iv != 0;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
@@ -1310,18 +1309,6 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 const long long* t = (const long long*)(raw.data() + DBG_ITER_BYTES);
                 const int nb = (int)((ctx->map_m + 63) / 64);
                 if (nb > 0 && nb <= 8192 && t[0] != 0) {
-                    const long long MASK = (1ll << 48) - 1;
-                    std::vector<long long> clean(4 * (size_t)nb);
-                    FILE* dump = ctx->search_stats == 3 ? fopen("/tmp/icp_normal_blocks.csv", "w") : nullptr;  // dev
-                    if (dump) fprintf(dump, "block,start_us,ring1_us,stragglers_us,eigen_us,unsettled,own_cell,candidates\n");
-                    for (int i = 0; i < 4 * nb; ++i) clean[i] = t[i] & MASK;
-                    for (int i = 0; dump && i < nb; ++i)
-                        fprintf(dump, "%d,%.2f,%.2f,%.2f,%.2f,%d,%d,%d\n", i, (clean[4 * i] - clean[0]) * 0.01,
-                                (clean[4 * i + 1] - clean[4 * i]) * 0.01, (clean[4 * i + 2] - clean[4 * i + 1]) * 0.01,
-                                (clean[4 * i + 3] - clean[4 * i + 2]) * 0.01, (int)(t[4 * i + 1] >> 48),
-                                (int)(t[4 * i + 2] >> 48), (int)(t[4 * i + 3] >> 48));
-                    if (dump) fclose(dump);
-                    t = clean.data();
                     long long first = t[0], last_end = t[3];
                     double a = 0, b = 0, e = 0, amax = 0, bmax = 0;
                     int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};

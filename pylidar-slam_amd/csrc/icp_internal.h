@@ -180,8 +180,7 @@ struct icp_ctx {
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
-    icp::DeviceBuffer worklist;        // int[M]: lazy schedule: map points whose normal the search asked for; eager selection path: points ring 1 did not settle
-    icp::DeviceBuffer knn_ctr;         // int[2]: length of that queue, finished workgroups of the kernel that drains it
+    icp::DeviceBuffer worklist;        // int[M]
     bool grid_valid = false;
     uint64_t grid_gen = 0;             // bumped by every grid build: cell-sorted positions are only valid within one
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
@@ -205,7 +204,6 @@ struct icp_ctx {
     // tuning options (icp_set_option; none of them changes a result)
     int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
-    int knn_select = 0;                // "knn_select": eager kNN normals by selection (k-th distance first, neighbours second)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
     int narrow_from = 6;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)

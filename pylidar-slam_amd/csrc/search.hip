@@ -693,12 +693,9 @@ __device__ inline unsigned long long make_key(float d2, int idx) {
 __device__ inline float key_d2(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
 __device__ inline int key_idx(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
-__device__ inline float point_d2(const float4 q, float px, float py, float pz) {
-    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-}
 __device__ inline unsigned long long point_key(const float4 q, float px, float py, float pz) {
-    return make_key(point_d2(q, px, py, pz), __float_as_int(q.w));
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    return make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w));
 }
 
 template <int KN>
@@ -719,24 +716,6 @@ struct TopK {
             key[k - 1] = lo;
             key[k] = hi;
         }
-    }
-};
-
-// The KN smallest squared DISTANCES only (no indices), ascending: an insert is one v_med3_f32 per slot, branch-free —
-// new d[i] = clamp(c, d[i-1], d[i]), new d[0] = min(d[0], c) — against ~5 instructions per slot and a wave-wide branch for
-// the 64-bit (distance, index) keys above.  Inserting +inf changes nothing.
-template <int KN>
-struct TopD {
-    float d[KN];
-    __device__ inline void init() {
-#pragma unroll
-        for (int k = 0; k < KN; ++k) d[k] = INFINITY;
-    }
-    __device__ inline float kth() const { return d[KN - 1]; }
-    __device__ inline void insert(float c) {
-#pragma unroll
-        for (int k = KN - 1; k > 0; --k) d[k] = __builtin_amdgcn_fmed3f(d[k - 1], c, d[k]);  // reads the OLD d[k-1]
-        d[0] = fminf(d[0], c);
     }
 };
 
@@ -911,9 +890,6 @@ template <int KN, int NL>
 __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m);
 
 static constexpr int NRM_THREADS = 256;
-// waves per SIMD the eager kernel is built for: 5 (96 VGPRs, 5 x 31 KB of LDS per CU) with 4 lanes per point; the
-// selection buffers of the 20-neighbour build leave room for 3 workgroups per CU
-constexpr int nrm_waves(int kn, int nl, bool sel) { return nl == 4 ? (sel && kn > 11 ? 3 : 5) : (sel && kn > 11 ? 1 : 2); }
 
 // kNN counterpart of `coop_rings` for a WHOLE WAVE: rings r_begin..r_end of one level around a map point.  `m` is the
 // merged list so far (identical in all lanes); per ring lane 0 continues from it, the others from empty lists.  The cells
@@ -1080,239 +1056,18 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, float* __
     return exact;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same neighbourhood by SELECTION (option "knn_select"): the k-th smallest distance first, the neighbours second.
-// The counters said k_normals_all is bound by VALU issue: the sorted insert of a 64-bit key is ~55 instructions and runs
-// for the whole wave whenever ONE of its lanes inserts, i.e. for nearly every candidate.  Here
-//   pass 1: every candidate costs its distance + KN v_med3_f32 (TopD); the lanes' lists are merged (the partner's KN
-//           distances inserted, one butterfly step per doubling) -> T = the KN-th smallest distance of the 27 cells;
-//   pass 2: the candidates again (L1 / L2 hits; whole cells pruned against T): the few keys with d2 <= T — KN of them
-//           plus ties on the KN-th distance — are appended to the point's list in LDS, which the group then sorts by
-//           ranking (every lane counts, for its share of the keys, how many keys are smaller).
-// The list is CERTIFIED before it is used: with n keys collected and C candidates in the 27 cells, n >= min(KN, C)
-// proves that the KN smallest keys are among them whatever T was (an underestimated T leaves fewer than KN keys), and
-// n <= CAP that none was dropped.  A point that fails the test (more than CAP - KN ties on the KN-th distance: exact
-// duplicates in the map) returns -1 and is restarted from ring 0 by the wave path below.  Same keys, same order, same
-// covariance as estimate_cov, bit for bit.
-// Returns 1: settled by ring 1, covariance written; 0: not settled, `m` (lane sub == 0) holds the merged list; -1: restart.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int KN, int PTS>
-struct SelectBuf {
-    static constexpr int CAP = KN + 3;
-    unsigned long long key[PTS][CAP];
-    int n[PTS];
-};
-
-__device__ inline void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int KN, int NL, int PTS>
-__device__ inline int estimate_cov_select(const GridView& g, int s, int sub, int lq, float* __restrict__ cov,
-                                          SelectBuf<KN, PTS>& sel, TopK<KN>& m, int* __restrict__ tally = nullptr) {
-    constexpr int CAP = SelectBuf<KN, PTS>::CAP;
-    const float4 P = g.pts[s];
-    const float px = P.x, py = P.y, pz = P.z;
-    const float h = g.h;
-    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
-    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
-    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
-    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
-    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-    const int2* __restrict__ r = g.rows + (size_t)g.row_of_pos[s] * ROW_STRIDE;
-    const int2 own = r[13];
-    constexpr int CPL = ROW_STRIDE / NL;  // row entries per lane (entry 27 is padding)
-    const int2* __restrict__ rl = r + sub * CPL;  // this lane's row entries
-    int2 cell[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) cell[k] = rl[k];
-    if (sub == 0) sel.n[lq] = 0;
-    const int own_last = own.x + own.y - 1;
-    constexpr int W = 4;  // candidates per lane and trip (measured: 8 costs more in idle list slots than it saves in trips)
-    // ---- pass 1: distances only
-    TopD<KN> t;
-    t.init();
-    for (int k = own.x + sub; k <= own_last; k += W * NL) {
-        float4 q[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
-#pragma unroll
-        for (int i = 0; i < W; ++i) t.insert(k + i * NL <= own_last ? point_d2(q[i], px, py, pz) : INFINITY);
-    }
-    // the lane's occupied neighbour cells as a bit mask; their (start, count) is fetched again from the row (a cache hit)
-    // when the walk reaches them — a list in LDS costs 14 KB per workgroup, two waves per SIMD of occupancy
-    unsigned live = 0;
-    int total = 0;  // candidates behind this lane's row entries (the own cell counts once, with entry 13)
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int c = sub * CPL + k;
-        if (c >= 27 || cell[k].y <= 0) continue;
-        total += cell[k].y;
-        if (c != 13) live |= 1u << k;
-    }
-    {
-        unsigned todo = live;
-        int st = 0, cnt = 0, k = 0;
-        for (;;) {
-            if (k >= cnt) {
-                if (!todo) break;
-                const int kk = __ffs((int)todo) - 1;
-                todo &= todo - 1;
-                const int c = sub * CPL + kk;
-                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
-                            gz = axis_gap(c / 9 - 1, fz, h);
-                // this lane alone already knows KN points within its k-th distance: the merged k-th is no larger
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > t.kth()) continue;
-                const int2 e = rl[kk];
-                st = e.x;
-                cnt = e.y;
-                k = 0;
-            }
-            const int last = st + cnt - 1, k0 = st + k;
-            float4 q[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k0 + i, last)];
-#pragma unroll
-            for (int i = 0; i < W; ++i) t.insert(k0 + i <= last ? point_d2(q[i], px, py, pz) : INFINITY);
-            k += W;
-        }
-    }
-#pragma unroll
-    for (int o = 1; o < NL; o <<= 1) {  // butterfly: afterwards every lane of the group holds the same merged list
-        float other[KN];
-#pragma unroll
-        for (int j = 0; j < KN; ++j) other[j] = __shfl_xor(t.d[j], o, 64);
-#pragma unroll
-        for (int j = 0; j < KN; ++j) t.insert(other[j]);
-        total += __shfl_xor(total, o, 64);
-    }
-    const float T = t.kth();  // group-uniform; +inf when the 27 cells hold fewer than KN points
-    if (tally && sub == 0) {  // dev: own-cell size and 27-cell candidates of the block's points
-        atomicAdd(&tally[0], own.y);
-        atomicAdd(&tally[1], total);
-    }
-    wave_lds_sync();          // the cleared counter before the first append
-    // ---- pass 2: the keys with d2 <= T
-    for (int k = own.x + sub; k <= own_last; k += W * NL) {
-        float4 q[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) q[i] = g.pts[min(k + i * NL, own_last)];
-        float d[W];
-        int add = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i) {
-            d[i] = point_d2(q[i], px, py, pz);
-            if (!(k + i * NL <= own_last && d[i] <= T)) d[i] = -1.f;  // marks "not a member" (distances are >= 0)
-            add += d[i] >= 0.f ? 1 : 0;
-        }
-        if (add) {
-            int slot = atomicAdd(&sel.n[lq], add);
-#pragma unroll
-            for (int i = 0; i < W; ++i)
-                if (d[i] >= 0.f) {
-                    if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
-                    ++slot;
-                }
-        }
-    }
-    {
-        unsigned todo = live;
-        int st = 0, cnt = 0, k = 0;
-        for (;;) {
-            if (k >= cnt) {
-                if (!todo) break;
-                const int kk = __ffs((int)todo) - 1;
-                todo &= todo - 1;
-                const int c = sub * CPL + kk;
-                const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
-                            gz = axis_gap(c / 9 - 1, fz, h);
-                if (fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > T) continue;  // every point of the cell is farther than T
-                const int2 e = rl[kk];
-                st = e.x;
-                cnt = e.y;
-                k = 0;
-            }
-            const int last = st + cnt - 1, k0 = st + k;
-            float4 q[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = g.pts[min(k0 + i, last)];
-            float d[W];
-            int add = 0;
-#pragma unroll
-            for (int i = 0; i < W; ++i) {
-                d[i] = point_d2(q[i], px, py, pz);
-                if (!(k0 + i <= last && d[i] <= T)) d[i] = -1.f;
-                add += d[i] >= 0.f ? 1 : 0;
-            }
-            if (add) {
-                int slot = atomicAdd(&sel.n[lq], add);
-#pragma unroll
-                for (int i = 0; i < W; ++i)
-                    if (d[i] >= 0.f) {
-                        if (slot < CAP) sel.key[lq][slot] = make_key(d[i], __float_as_int(q[i].w));
-                        ++slot;
-                    }
-            }
-            k += W;
-        }
-    }
-    wave_lds_sync();
-    const int n = sel.n[lq];  // group-uniform
-    if (n > CAP || n < min(KN, total)) {
-        m.init();
-        return -1;
-    }
-    // ---- rank sort of the n keys by the NL lanes (keys are unique: original indices are)
-    constexpr int OWN = (CAP + NL - 1) / NL;
-    unsigned long long mine[OWN];
-    int rank[OWN];
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) {
-        const int j = sub + NL * u;
-        mine[u] = j < n ? sel.key[lq][j] : KEY_EMPTY;
-        rank[u] = 0;
-    }
-    for (int i = 0; i < n; ++i) {
-        const unsigned long long ki = sel.key[lq][i];
-#pragma unroll
-        for (int u = 0; u < OWN; ++u) rank[u] += ki < mine[u] ? 1 : 0;
-    }
-    wave_lds_sync();  // every lane has read the unsorted list
-#pragma unroll
-    for (int u = 0; u < OWN; ++u)
-        if (sub + NL * u < n) sel.key[lq][rank[u]] = mine[u];
-    wave_lds_sync();
-    if (sub == 0)  // the list stays in LDS for the wave path (a point ring 1 does not settle): pad it to KN keys
-        for (int j = n; j < KN; ++j) sel.key[lq][j] = KEY_EMPTY;
-#pragma unroll
-    for (int j = 0; j < KN; ++j) m.key[j] = j < n ? sel.key[lq][j] : KEY_EMPTY;
-    const float bound1 = h + edge;
-    const bool exact = T <= bound1 * bound1 * 0.999999f;  // T = the distance of m.key[KN - 1] (+inf: fewer than KN)
-    if (exact && sub == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
-    return exact ? 1 : 0;
-}
-
 // The points ring 1 does not settle (isolated points: 1-2 % of a LiDAR map) are finished by a WHOLE WAVE each: a few of
 // them per launch walked the hashed rings and the coarse level with 4 lanes — 25 dependent probes per lane and ring,
 // coarse cells of hundreds of points — and set the duration of the kernel (the same tail as in the iteration kernel).
 // `m` = the merged list after ring 1 (identical in every lane).  Fine rings 2..max_rings, the coarse level, then the
 // exhaustive scan, every one split over the 64 lanes; lane 0 writes the covariance.
-// `restart`: the point comes from estimate_cov_select with nothing settled — rings 0 and 1 are searched here as well.
 template <int KN>
 __device__ inline void finish_cov_wave(const GridView& g, int s, int lane, int max_rings, TopK<KN>& m,
-                                       float* __restrict__ cov, int* __restrict__ wl, bool restart = false) {
+                                       float* __restrict__ cov, int* __restrict__ wl) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     if (g.dbg && lane == 0) atomicAdd(&g.dbg[7], 1);
-    int r_begin = 2, r_end = max_rings;
-    if (restart) {  // wave-uniform
-        m.init();
-        r_begin = 0;
-        r_end = max_rings < 1 ? 1 : max_rings;
-    }
-    bool exact = r_end >= r_begin && wave_knn_rings<KN>(g, px, py, pz, lane, r_begin, r_end, INFINITY, m, wl);
+    bool exact = max_rings >= 2 && wave_knn_rings<KN>(g, px, py, pz, lane, 2, max_rings, INFINITY, m, wl);
     if (g.dbg && lane == 0 && !exact) atomicAdd(&g.dbg[15], 1);
     if (!exact && g.ctable) {
         // the coarse rings start at ring 0 and re-find the fine results: the list starts empty (no duplicates), but what
@@ -1341,13 +1096,11 @@ struct PendingKnn {
     int n;
 };
 
-static constexpr int PEND_RESTART = 1 << 16;  // flag in PendingKnn::lq: search the point from ring 0
-
 template <int KN, int PTS>
-__device__ inline void pend_push(PendingKnn<KN, PTS>& p, int s, int lq, const TopK<KN>& m, bool restart = false) {
+__device__ inline void pend_push(PendingKnn<KN, PTS>& p, int s, int lq, const TopK<KN>& m) {
     const int k = atomicAdd(&p.n, 1);
     p.s[k] = s;
-    p.lq[k] = lq | (restart ? PEND_RESTART : 0);
+    p.lq[k] = lq;
 #pragma unroll
     for (int j = 0; j < KN; ++j) p.key[k][j] = m.key[j];
 }
@@ -1360,9 +1113,7 @@ __device__ inline void pend_finish(const GridView& g, PendingKnn<KN, PTS>& p, in
         TopK<KN> m;
 #pragma unroll
         for (int j = 0; j < KN; ++j) m.key[j] = p.key[k][j];
-        const int tag = p.lq[k];
-        finish_cov_wave<KN>(g, p.s[k], lane, max_rings, m, covs[tag & (PEND_RESTART - 1)], p.wl[wave],
-                            (tag & PEND_RESTART) != 0);
+        finish_cov_wave<KN>(g, p.s[k], lane, max_rings, m, covs[p.lq[k]], p.wl[wave]);
     }
 }
 
@@ -1387,26 +1138,12 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
     }
 }
 
-// one map point by its NL lanes, either way (SEL: by selection); what ring 1 does not settle waits in `pend`
-template <int KN, int NL, int PTS, bool SEL>
-__device__ inline void estimate_point(const GridView& g, int s, int sub, int lq, float (*covs)[7],
-                                      int2* __restrict__ stack, PendingKnn<KN, PTS>& pend,
-                                      SelectBuf<KN, SEL ? PTS : 1>& sel) {
-    TopK<KN> m;
-    if constexpr (SEL) {
-        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m);
-        if (settled <= 0 && sub == 0) pend_push(pend, s, lq, m, settled < 0);
-    } else {
-        if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], stack, NRM_THREADS, m) && sub == 0) pend_push(pend, s, lq, m);
-    }
-}
-
 // Block = NRM_THREADS / NL map points x NL lanes: the groups leave their covariances in LDS, then the first threads
 // (whole waves, every lane busy) run the Jacobi eigen-solves — a group would otherwise spend the ~1.5k-instruction solve
 // with one lane in NL active.
 // lazy schedule: the map points queued by the search of this iteration (a no-op once the registration is done; the
 // count feeds `normals_computed`)
-template <int KN, int NL, bool SEL>
+template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* __restrict__ st,
                                                          const int* __restrict__ worklist, int max_rings,
                                                          float4* __restrict__ normals, int* __restrict__ nflag) {
@@ -1415,15 +1152,18 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
     __shared__ PendingKnn<KN, PTS> pend;
-    __shared__ SelectBuf<KN, SEL ? PTS : 1> sel;
     const int nw = st->n_worklist;
     const int sub = threadIdx.x % NL, lq = threadIdx.x / NL;
     for (int base = blockIdx.x * PTS; base < nw; base += gridDim.x * PTS) {  // block-uniform trip count
         if (threadIdx.x == 0) pend.n = 0;
         __syncthreads();
         const int w = base + lq;
-        if (w < nw)
-            estimate_point<KN, NL, PTS, SEL>(g, worklist[w], sub, lq, covs, &cellstack[0][threadIdx.x], pend, sel);
+        if (w < nw) {
+            TopK<KN> m;
+            const int s = worklist[w];
+            if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+                pend_push(pend, s, lq, m);
+        }
         __syncthreads();
         pend_finish(g, pend, max_rings, covs);
         __syncthreads();
@@ -1441,14 +1181,13 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals(GridView g, RegState* _
 // 1-NN search most points need ring 2 for their 10th neighbour) and a cell-centric variant (one wave per cell, its
 // 27-cell candidates staged once in LDS, brute-force top-k per point: 137 us for the ring-1 part alone + 166 us for the
 // unsettled points, vs 154 us here).
-template <int KN, int NL, bool SEL>
-__global__ __launch_bounds__(NRM_THREADS, nrm_waves(KN, NL, SEL)) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
+template <int KN, int NL>
+__global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(GridView g, int max_rings, float4* __restrict__ normals,
                                                              int* __restrict__ nflag) {
     constexpr int PTS = NRM_THREADS / NL;
     __shared__ int2 cellstack[ROW_STRIDE / NL][NRM_THREADS];
     __shared__ float covs[PTS][7];
     __shared__ PendingKnn<KN, PTS> pend;
-    __shared__ SelectBuf<KN, SEL ? PTS : 1> sel;  // (KN = 11, 4 lanes: 31.0 KB in all — five workgroups per CU still fit)
     long long* stamps = (g.stamps && gridDim.x <= 8192 && NL == 4) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
     if (threadIdx.x == 0) {
         pend.n = 0;
@@ -1457,7 +1196,11 @@ __global__ __launch_bounds__(NRM_THREADS, nrm_waves(KN, NL, SEL)) void k_normals
     __syncthreads();
     const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
     const int s = blockIdx.x * PTS + lq;
-    if (s < g.m) estimate_point<KN, NL, PTS, SEL>(g, s, sub, lq, covs, &cellstack[0][threadIdx.x], pend, sel);
+    if (s < g.m) {
+        TopK<KN> m;
+        if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+            pend_push(pend, s, lq, m);
+    }
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
     pend_finish(g, pend, max_rings, covs);
@@ -1466,74 +1209,6 @@ __global__ __launch_bounds__(NRM_THREADS, nrm_waves(KN, NL, SEL)) void k_normals
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
-}
-
-// The eager kernels of the selection path (4 lanes per point).  What the in-kernel timers and counters said about
-// k_normals_all (profiles/r02_e_*): every workgroup does the same work (121 +- 20 candidates per point) at the pace the
-// SIMD issues its resident waves' VALU instructions — EXCEPT where points are not settled by ring 1 (1.5 % of a LiDAR
-// map): each of those costs a whole wave about as many instructions as the ring-1 work of 16 points, they come in
-// clumps (isolated points are neighbours in the cell order too), and the launch lasted until the workgroup with seven
-// of them was through — 100 us for 58 us of issue.  So:
-//   k_normals_select: ring 1 only.  Settled points get their normal; the others are appended to a queue in HBM.  No
-//       wave path in the kernel: 12 KB of LDS, 72 registers (k <= 10) -> 7 waves per SIMD, every workgroup of a
-//       100 000-point map resident in ONE round (1280 of 1563 were, so the old kernel lasted two workgroup lifetimes).
-//   k_normals_queue: one wave per queued point, spread over the whole chip (rings 0.., coarse level, exhaustive scan).
-// The last workgroup of the second kernel to finish resets the queue counters for the next map.
-template <int KN>
-__global__ __launch_bounds__(NRM_THREADS, KN <= 11 ? 7 : 4) void k_normals_select(GridView g, float4* __restrict__ normals,
-                                                                                 int* __restrict__ nflag,
-                                                                                 int* __restrict__ queue,
-                                                                                 int* __restrict__ queue_ctr) {
-    constexpr int NL = 4, PTS = NRM_THREADS / NL;
-    __shared__ float covs[PTS][7];  // [6]: settled
-    __shared__ SelectBuf<KN, PTS> sel;
-    __shared__ int tally[2];  // dev
-    long long* stamps = (g.stamps && gridDim.x <= 8192) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
-    if (stamps && threadIdx.x == 0) {
-        stamps[0] = wall_clock64();
-        tally[0] = tally[1] = 0;
-    }
-    if (stamps) __syncthreads();
-    const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
-    const int s = blockIdx.x * PTS + lq;
-    if (s < g.m) {
-        TopK<KN> m;
-        const int settled = estimate_cov_select<KN, NL, PTS>(g, s, sub, lq, covs[lq], sel, m, stamps ? tally : nullptr);
-        if (sub == 0) {
-            covs[lq][6] = settled > 0 ? 1.f : 0.f;
-            if (settled <= 0) queue[atomicAdd(&queue_ctr[0], 1)] = s;
-        }
-    }
-    __syncthreads();
-    if (stamps && threadIdx.x == 0) stamps[1] = stamps[2] = wall_clock64() | ((long long)min(tally[0] / PTS, 0x7fff) << 48);
-    const int s2 = blockIdx.x * PTS + threadIdx.x;
-    if (threadIdx.x < PTS && s2 < g.m && covs[threadIdx.x][6] != 0.f) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
-    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64() | ((long long)min(tally[1] / PTS, 0x7fff) << 48);
-}
-
-template <int KN>
-__global__ __launch_bounds__(NRM_THREADS) void k_normals_queue(GridView g, int max_rings, float4* __restrict__ normals,
-                                                               int* __restrict__ nflag, const int* __restrict__ queue,
-                                                               int* __restrict__ queue_ctr) {
-    __shared__ int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
-    __shared__ float cov[NRM_THREADS / 64][8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = queue_ctr[0];
-    const int waves = gridDim.x * (NRM_THREADS / 64);
-    for (int i = blockIdx.x * (NRM_THREADS / 64) + wave; i < n; i += waves) {  // wave-uniform
-        const int s = queue[i];
-        TopK<KN> m;
-        finish_cov_wave<KN>(g, s, lane, max_rings, m, cov[wave], wl[wave], true);
-        if (lane == 0) normal_from_cov(cov[wave], s, normals, nflag);  // the lane that wrote the covariance
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&queue_ctr[1], 1) == (int)gridDim.x - 1) {  // every workgroup has read the count: clear for the next map
-            queue_ctr[0] = 0;
-            queue_ctr[1] = 0;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1550,7 +1225,7 @@ __device__ inline int bucket_owner(float x, float y, float z, int world) {
     return (int)(hash_cell(key) % (unsigned)world);
 }
 
-template <int KN, int NL, bool SEL>
+template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int max_rings, int rank, int world,
                                                                float4* __restrict__ by_index) {
     constexpr int PTS = NRM_THREADS / NL;
@@ -1558,7 +1233,6 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int m
     __shared__ float covs[PTS][7];
     __shared__ int owned[PTS];
     __shared__ PendingKnn<KN, PTS> pend;
-    __shared__ SelectBuf<KN, SEL ? PTS : 1> sel;
     if (threadIdx.x == 0) pend.n = 0;
     __syncthreads();
     const int lq = threadIdx.x / NL, sub = threadIdx.x % NL;
@@ -1567,7 +1241,11 @@ __global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int m
     if (s < g.m) {
         const float4 P = g.pts[s];
         mine = bucket_owner(P.x, P.y, P.z, world) == rank;  // group-uniform
-        if (mine) estimate_point<KN, NL, PTS, SEL>(g, s, sub, lq, covs, &cellstack[0][threadIdx.x], pend, sel);
+        if (mine) {
+            TopK<KN> m;
+            if (!estimate_cov<KN, NL>(g, s, sub, covs[lq], &cellstack[0][threadIdx.x], NRM_THREADS, m) && sub == 0)
+                pend_push(pend, s, lq, m);
+        }
     }
     if (sub == 0) owned[lq] = mine ? 1 : 0;
     __syncthreads();
@@ -1740,16 +1418,15 @@ static void launch_worklist_t(icp_ctx* ctx, int kn, const GridView& g, RegState*
     const int* wl = ctx->worklist.as<int>();
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    const dim3 grid(blocks), block(NRM_THREADS);
-    if (ctx->knn_select) {
-        if (kn == 11) hipLaunchKernelGGL((k_normals<11, NL, true>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
-        else if (kn == 6) hipLaunchKernelGGL((k_normals<6, NL, true>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
-        else hipLaunchKernelGGL((k_normals<21, NL, true>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
-        return;
-    }
-    if (kn == 11) hipLaunchKernelGGL((k_normals<11, NL, false>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
-    else if (kn == 6) hipLaunchKernelGGL((k_normals<6, NL, false>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
-    else hipLaunchKernelGGL((k_normals<21, NL, false>), grid, block, 0, ctx->stream, g, st, wl, rings, nrm, nf);
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
+                           rings, nrm, nf);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
+                           rings, nrm, nf);
+    else
+        hipLaunchKernelGGL((k_normals<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, st, wl,
+                           rings, nrm, nf);
 }
 
 static int worklist_blocks(int64_t cap, int nl) {
@@ -1766,43 +1443,12 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (ctx->knn_select && NL == 4) {  // the neighbourhood by selection: ring 1 for everyone, then the queue of the rest
-        if (!ctx->knn_ctr.ptr) {
-            if (ctx->knn_ctr.reserve(64) != hipSuccess || hipMemsetAsync(ctx->knn_ctr.ptr, 0, 64, ctx->stream) != hipSuccess)
-                return;  // reported by the caller's hipGetLastError
-        }
-        int* queue = ctx->worklist.as<int>();  // int[M], idle under the eager schedule
-        int* ctr = ctx->knn_ctr.as<int>();
-        int qblocks = blocks / 4;  // a wave per queued point, ~1.5 % of the map: a sixteenth of the waves of the first launch
-        qblocks = qblocks < 16 ? 16 : (qblocks > 1024 ? 1024 : qblocks);
-        const dim3 grid(blocks), qgrid(qblocks), block(NRM_THREADS);
-        if (kn == 11) {
-            hipLaunchKernelGGL((k_normals_select<11>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
-            hipLaunchKernelGGL((k_normals_queue<11>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
-        } else if (kn == 6) {
-            hipLaunchKernelGGL((k_normals_select<6>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
-            hipLaunchKernelGGL((k_normals_queue<6>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
-        } else {
-            hipLaunchKernelGGL((k_normals_select<21>), grid, block, 0, ctx->stream, g, nrm, nf, queue, ctr);
-            hipLaunchKernelGGL((k_normals_queue<21>), qgrid, block, 0, ctx->stream, g, rings, nrm, nf, queue, ctr);
-        }
-        return;
-    }
-    if (ctx->knn_select) {
-        if (kn == 11)
-            hipLaunchKernelGGL((k_normals_all<11, NL, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else if (kn == 6)
-            hipLaunchKernelGGL((k_normals_all<6, NL, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        else
-            hipLaunchKernelGGL((k_normals_all<21, NL, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
-        return;
-    }
     if (kn == 11)
-        hipLaunchKernelGGL((k_normals_all<11, NL, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else if (kn == 6)
-        hipLaunchKernelGGL((k_normals_all<6, NL, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_all<6, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else
-        hipLaunchKernelGGL((k_normals_all<21, NL, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
+        hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
 }
 
 int launch_normals_all(icp_ctx* ctx) {
@@ -1835,16 +1481,12 @@ int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev)
     const int rings = knn_fine_rings(ctx);
     float4* out = (float4*)by_index_dev;
     const int tok = prof_begin(ctx, 2);
-    const dim3 grid(blocks), block(NRM_THREADS);
-    if (ctx->knn_select) {
-        if (kn == 11) hipLaunchKernelGGL((k_normals_owned<11, 4, true>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-        else if (kn == 6) hipLaunchKernelGGL((k_normals_owned<6, 4, true>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-        else hipLaunchKernelGGL((k_normals_owned<21, 4, true>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-    } else {
-        if (kn == 11) hipLaunchKernelGGL((k_normals_owned<11, 4, false>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-        else if (kn == 6) hipLaunchKernelGGL((k_normals_owned<6, 4, false>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-        else hipLaunchKernelGGL((k_normals_owned<21, 4, false>), grid, block, 0, ctx->stream, g, rings, rank, world, out);
-    }
+    if (kn == 11)
+        hipLaunchKernelGGL((k_normals_owned<11, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
+    else if (kn == 6)
+        hipLaunchKernelGGL((k_normals_owned<6, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
+    else
+        hipLaunchKernelGGL((k_normals_owned<21, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
