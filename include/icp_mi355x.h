@@ -115,8 +115,6 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   searches expected), instead of 128 with a 4-lane group each; same bits
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
- *   "knn_cells" 0 | 1 (0)           eager kNN normals by the cell-centric kernel: one lane per map point, the candidates
- *                                   of the wave's cells staged once in LDS, the k-th distance first, the keys within it second
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 | 2 (0)
  *   "profile_every" n (1)           icp_profile_enable times the kernels of every n-th registration only (an event pair
  *                                   costs ~2 us of stream time: 40 pairs per frame are 10 % of a 0.8 ms registration)

@@ -204,7 +204,6 @@ struct icp_ctx {
     // tuning options (icp_set_option; none of them changes a result)
     int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
-    int knn_cells = 0;                 // "knn_cells": eager kNN normals by the cell-centric kernel (k_normals_cells)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
     int narrow_from = 6;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)

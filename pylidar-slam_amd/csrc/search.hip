@@ -687,24 +687,15 @@ __global__ void k_cache_to_seed(const int2* __restrict__ nn_cache, const float4*
 // ties with.  Sorted ascending; a compare-swap step is 1 compare + 4 selects.
 static constexpr unsigned long long KEY_EMPTY = (0x7f800000ull << 32) | 0x7fffffffull;  // (+inf, max index)
 
-__device__ inline void wave_lds_sync() {  // LDS written by some lanes of the wave, read by others
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ inline unsigned long long make_key(float d2, int idx) {
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)idx;
 }
 __device__ inline float key_d2(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
 __device__ inline int key_idx(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
-__device__ inline float point_d2(const float4 q, float px, float py, float pz) {
-    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-}
 __device__ inline unsigned long long point_key(const float4 q, float px, float py, float pz) {
-    return make_key(point_d2(q, px, py, pz), __float_as_int(q.w));
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    return make_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q.w));
 }
 
 template <int KN>
@@ -725,24 +716,6 @@ struct TopK {
             key[k - 1] = lo;
             key[k] = hi;
         }
-    }
-};
-
-// The KN smallest squared DISTANCES only (no indices), ascending: an insert is one v_med3_f32 per slot, branch-free —
-// new d[i] = clamp(c, d[i-1], d[i]), new d[0] = min(d[0], c) — against ~5 instructions per slot and a wave-wide branch for
-// the 64-bit (distance, index) keys above.  Inserting +inf changes nothing.
-template <int KN>
-struct TopD {
-    float d[KN];
-    __device__ inline void init() {
-#pragma unroll
-        for (int k = 0; k < KN; ++k) d[k] = INFINITY;
-    }
-    __device__ inline float kth() const { return d[KN - 1]; }
-    __device__ inline void insert(float c) {
-#pragma unroll
-        for (int k = KN - 1; k > 0; --k) d[k] = __builtin_amdgcn_fmed3f(d[k - 1], c, d[k]);  // reads the OLD d[k-1]
-        d[0] = fminf(d[0], c);
     }
 };
 
@@ -1088,20 +1061,13 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, float* __
 // coarse cells of hundreds of points — and set the duration of the kernel (the same tail as in the iteration kernel).
 // `m` = the merged list after ring 1 (identical in every lane).  Fine rings 2..max_rings, the coarse level, then the
 // exhaustive scan, every one split over the 64 lanes; lane 0 writes the covariance.
-// `restart`: nothing is settled about the point yet — rings 0 and 1 are searched here as well, from an empty list.
 template <int KN>
 __device__ inline void finish_cov_wave(const GridView& g, int s, int lane, int max_rings, TopK<KN>& m,
-                                       float* __restrict__ cov, int* __restrict__ wl, bool restart = false) {
+                                       float* __restrict__ cov, int* __restrict__ wl) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     if (g.dbg && lane == 0) atomicAdd(&g.dbg[7], 1);
-    int r_begin = 2, r_end = max_rings;
-    if (restart) {  // wave-uniform
-        m.init();
-        r_begin = 0;
-        r_end = max_rings < 1 ? 1 : max_rings;
-    }
-    bool exact = r_end >= r_begin && wave_knn_rings<KN>(g, px, py, pz, lane, r_begin, r_end, INFINITY, m, wl);
+    bool exact = max_rings >= 2 && wave_knn_rings<KN>(g, px, py, pz, lane, 2, max_rings, INFINITY, m, wl);
     if (g.dbg && lane == 0 && !exact) atomicAdd(&g.dbg[15], 1);
     if (!exact && g.ctable) {
         // the coarse rings start at ring 0 and re-find the fine results: the list starts empty (no duplicates), but what
@@ -1243,213 +1209,6 @@ __global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(Gr
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Cell-centric eager kNN normals (option "knn_cells").
-//
-// What the counters said about k_normals_all: 6700 VALU instructions per wave of 16 map points
-// whose 27 cells hold 121 +- 20 candidates — 17 per candidate would do; the rest is per-point and per-cell overhead paid
-// by every one of the 4 lanes of every point (row entries, box tests, cell switches, tails of 4-wide trips over cells of
-// 4-15 points, the 4-lane merge), and the sorted insert of a 64-bit key (~55 instructions) that runs for the whole
-// wave whenever one lane inserts.  Here:
-//   * a wave takes 64 consecutive cell-sorted map points, ONE LANE EACH: the points of a cell are neighbours in that
-//     order, so the wave's points belong to a handful of cells, and all points of a cell share their 27-cell candidates;
-//   * the candidates of those cells are staged ONCE in LDS, laid end to end (row entries -> prefix sum -> every lane
-//     copies its share; the segment of candidate j found by a binary search over the prefix), as many cells per round
-//     as fit the buffer; the per-cell work is done once per cell and wave instead of once per lane and point;
-//   * pass 1: every lane walks its cell's candidates in LDS keeping the KN smallest DISTANCES (TopD: one v_med3_f32 per
-//     slot and candidate, branch-free) -> T, the k-th smallest distance;
-//   * pass 2: the same walk again, the positions of the candidates with d2 <= T (KN of them plus ties) noted per lane;
-//     CERTIFIED by their count: n >= min(KN, candidates) proves the KN smallest keys are among them whatever T was,
-//     n <= CAP that none was dropped;
-//   * the n keys go through the 64-bit sorted insert (n ~ KN inserts instead of one per improving candidate): the same
-//     list, in the same order, as estimate_cov builds -> same covariance, same normal, bit for bit.
-// Points ring 1 does not settle (or whose certificate fails: more than CAP - KN ties on the k-th distance, a cell whose
-// candidates alone overflow the buffer) wait in a short list and are finished by the whole wave (finish_cov_wave).
-// One wave per workgroup: no barriers, 20 KB of LDS.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int KN>
-struct CellKnnShared {
-    static constexpr int CB = 896;    // candidate points staged per round
-    static constexpr int MAXC = 8;    // cells per round
-    static constexpr int CAP = KN + 3;
-    static constexpr int PEND = 8;
-    float4 cand[CB];
-    int2 seg[MAXC * ROW_STRIDE];        // row entries (start, count) of the round's cells; entry 27 of a row is (0, 0)
-    int segoff[MAXC * ROW_STRIDE + 4];  // exclusive prefix of the counts = offsets into `cand`
-    int cellslot[MAXC];
-    unsigned short member[64][CAP];     // per lane: positions in `cand` of the candidates within T
-    unsigned long long pkey[PEND][KN];  // pending points: merged list after ring 1
-    int ps[PEND];                       // their map positions (bit 30: restart from ring 0)
-    float pcov[8];
-    int wl[128];                        // scratch of wave_knn_rings
-};
-
-template <int KN>
-__device__ __noinline__ void cell_knn_drain(const GridView& g, CellKnnShared<KN>& sh, int npend, int lane, int max_rings,
-                                      float4* __restrict__ normals, int* __restrict__ nflag) {
-    for (int k = 0; k < npend; ++k) {  // wave-uniform
-        const int tag = sh.ps[k], s = tag & 0x3fffffff;
-        TopK<KN> m;
-#pragma unroll
-        for (int j = 0; j < KN; ++j) m.key[j] = sh.pkey[k][j];
-        finish_cov_wave<KN>(g, s, lane, max_rings, m, sh.pcov, sh.wl, (tag & (1 << 30)) != 0);
-        if (lane == 0) normal_from_cov(sh.pcov, s, normals, nflag);  // the lane that wrote the covariance
-    }
-}
-
-template <int KN>
-__global__ __launch_bounds__(64) void k_normals_cells(GridView g, int max_rings, float4* __restrict__ normals,
-                                                      int* __restrict__ nflag) {
-    using SH = CellKnnShared<KN>;
-    __shared__ SH sh;
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x * 64 + lane;
-    const bool valid = s < g.m;
-    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
-    int slot = -1;
-    if (valid) {
-        P = g.pts[s];
-        slot = g.row_of_pos[s];
-    }
-    const float px = P.x, py = P.y, pz = P.z;
-    // the wave's cells: consecutive points of a cell are consecutive lanes
-    const int prev = __shfl_up(slot, 1, 64);
-    const bool leader = valid && (lane == 0 || slot != prev);
-    const unsigned long long leaders = __ballot(leader);
-    const int ncells = __popcll(leaders);
-    const int my_cell = valid ? __popcll(leaders & ((2ull << lane) - 1ull)) - 1 : -1;  // rank of this lane's cell
-    int npend = 0;  // wave-uniform
-    for (int c0 = 0; c0 < ncells;) {  // rounds; everything below is wave-uniform except where a lane's own cell matters
-        const int nc = min(ncells - c0, SH::MAXC);
-        if (leader && my_cell >= c0 && my_cell < c0 + nc) sh.cellslot[my_cell - c0] = slot;
-        wave_lds_sync();
-        const int nseg = nc * ROW_STRIDE;
-        for (int e = lane; e < nseg; e += 64) {
-            const int i = e / ROW_STRIDE, k = e - i * ROW_STRIDE;
-            int2 v = make_int2(0, 0);
-            if (k < 27) v = g.rows[(size_t)sh.cellslot[i] * ROW_STRIDE + k];
-            if (v.y < 0) v.y = 0;
-            sh.seg[e] = v;
-        }
-        wave_lds_sync();
-        // exclusive prefix of the counts: 4 consecutive entries per lane (nseg <= 224), then a wave scan
-        {
-            int c[4], sum = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 4 * lane + q;
-                c[q] = e < nseg ? sh.seg[e].y : 0;
-                sum += c[q];
-            }
-            int incl = sum;
-#pragma unroll
-            for (int o = 1; o <= 32; o <<= 1) {
-                const int up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-            int run = incl - sum;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 4 * lane + q;
-                if (e <= nseg) sh.segoff[e] = run;  // segoff[nseg] = total (nseg is a multiple of 4: lane nseg / 4, q = 0)
-                run += c[q];
-            }
-        }
-        wave_lds_sync();
-        // as many of the round's cells as fit the buffer
-        int fit = 0;
-        while (fit < nc && sh.segoff[(fit + 1) * ROW_STRIDE] <= SH::CB) ++fit;
-        const bool in_round = my_cell >= c0 && my_cell < c0 + fit;
-        bool restart = false;  // this lane's point goes to the wave path from ring 0
-        if (fit == 0) {        // the first cell's candidates alone overflow the buffer: its points take the wave path
-            restart = my_cell == c0;
-            fit = 0;
-        }
-        const int total = fit > 0 ? sh.segoff[fit * ROW_STRIDE] : 0;
-        const int nfit = fit * ROW_STRIDE;
-        for (int j = lane; j < total; j += 64) {
-            int e = 0;
-#pragma unroll
-            for (int st = 128; st > 0; st >>= 1)
-                if (e + st < nfit && sh.segoff[e + st] <= j) e += st;
-            sh.cand[j] = g.pts[sh.seg[e].x + (j - sh.segoff[e])];
-        }
-        wave_lds_sync();
-        int jb = 0, je = 0;
-        if (in_round) {
-            jb = sh.segoff[(my_cell - c0) * ROW_STRIDE];
-            je = sh.segoff[(my_cell - c0 + 1) * ROW_STRIDE];
-        }
-        // ---- pass 1: the k-th smallest distance
-        TopD<KN> t;
-        t.init();
-        for (int j = jb; j < je; j += 4) {
-            const float4 q0 = sh.cand[j], q1 = sh.cand[min(j + 1, je - 1)], q2 = sh.cand[min(j + 2, je - 1)],
-                         q3 = sh.cand[min(j + 3, je - 1)];
-            t.insert(point_d2(q0, px, py, pz));
-            t.insert(j + 1 < je ? point_d2(q1, px, py, pz) : INFINITY);
-            t.insert(j + 2 < je ? point_d2(q2, px, py, pz) : INFINITY);
-            t.insert(j + 3 < je ? point_d2(q3, px, py, pz) : INFINITY);
-        }
-        const float T = t.kth();  // +inf when the 27 cells hold fewer than KN points
-        // ---- pass 2: the candidates within T
-        int n = 0;
-        for (int j = jb; j < je; j += 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (j + i < je && point_d2(sh.cand[j + i], px, py, pz) <= T) {
-                    if (n < SH::CAP) sh.member[lane][n] = (unsigned short)(j + i);
-                    ++n;
-                }
-            }
-        }
-        if (in_round && (n > SH::CAP || n < min(KN, je - jb))) restart = true;
-        // ---- the n keys through the sorted insert: the list estimate_cov builds, in its order
-        TopK<KN> m;
-        m.init();
-        const int nk = (in_round && !restart) ? n : 0;
-        for (int k = 0; k < nk; ++k) m.insert(point_key(sh.cand[sh.member[lane][k]], px, py, pz));
-        bool settled = false;
-        if (in_round && !restart) {
-            const float h = g.h;
-            const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
-            const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
-            const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
-            const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
-            const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-            const float bound1 = h + edge;
-            settled = m.kth() <= bound1 * bound1 * 0.999999f;
-        }
-        if (settled) {
-            float cov[6];
-            neighbourhood_cov<KN>(g, px, py, pz, m, cov);
-            normal_from_cov(cov, s, normals, nflag);
-        }
-        // ---- the others wait for the wave path
-        unsigned long long waiting = __ballot((in_round && !settled) || restart);
-        while (waiting) {  // wave-uniform
-            const int src = __ffsll((long long)waiting) - 1;
-            waiting &= waiting - 1;
-            if (lane == src) {
-                sh.ps[npend] = s | (restart ? (1 << 30) : 0);
-#pragma unroll
-                for (int j = 0; j < KN; ++j) sh.pkey[npend][j] = m.key[j];
-            }
-            ++npend;
-            if (npend == SH::PEND) {
-                wave_lds_sync();
-                cell_knn_drain<KN>(g, sh, npend, lane, max_rings, normals, nflag);
-                npend = 0;
-                wave_lds_sync();
-            }
-        }
-        wave_lds_sync();  // the next round overwrites the buffers
-        c0 += fit > 0 ? fit : 1;
-    }
-    wave_lds_sync();
-    cell_knn_drain<KN>(g, sh, npend, lane, max_rings, normals, nflag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1684,13 +1443,6 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (ctx->knn_cells) {  // cell-centric: one lane per map point, a wave per workgroup
-        const dim3 grid((unsigned)((ctx->map_m + 63) / 64)), block(64);
-        if (kn == 11) hipLaunchKernelGGL((k_normals_cells<11>), grid, block, 0, ctx->stream, g, rings, nrm, nf);
-        else if (kn == 6) hipLaunchKernelGGL((k_normals_cells<6>), grid, block, 0, ctx->stream, g, rings, nrm, nf);
-        else hipLaunchKernelGGL((k_normals_cells<21>), grid, block, 0, ctx->stream, g, rings, nrm, nf);
-        return;
-    }
     if (kn == 11)
         hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else if (kn == 6)

@@ -317,8 +317,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "wave_search_always": {"wave_misses": 128},
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
-                "lanes2": {"knn_lanes": 2}, "knn_cells": {"knn_cells": 1}, "knn_lanes4": {"knn_cells": 0},
-                "unfused": {"fuse_iteration": 0}}
+                "lanes2": {"knn_lanes": 2}, "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
         ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure",
@@ -411,20 +410,17 @@ def test_knn_normals_on_stress_clouds(torch_cuda, O, neighbors):
             assert dots[clear].min() > 1 - 1e-4, (name, dots[clear].min())
         if cloud.shape[0] < 100:
             continue
-        for cells in (0, 1):  # the eager kernel: 4 lanes per point / cell-centric (one lane per point, candidates in LDS)
-            ctx = _ctx(num_neighbors_normals=neighbors, max_num_alignments=1, threshold_delta_pose=0.0)
-            ctx.set_option("knn_cells", cells)
-            ctx.map_set(cloud)
-            if not cells:
-                _, lazy, ix = ctx.nearest_neighbor_search(cloud[::3], with_index=True)
-                np.testing.assert_array_equal(lazy, whole[ix, :3], err_msg=f"{name} lazy")
-            try:
-                ctx.register(cloud)  # eager normals of every map point, whatever becomes of the degenerate alignment
-            except RuntimeError:
-                pass
-            _, eager, ix = ctx.nearest_neighbor_search(cloud, with_index=True)
-            np.testing.assert_array_equal(eager, whole[ix, :3], err_msg=f"{name} eager, knn_cells={cells}")
-            ctx.close()
+        ctx = _ctx(num_neighbors_normals=neighbors, max_num_alignments=1, threshold_delta_pose=0.0)
+        ctx.map_set(cloud)
+        _, lazy, ix = ctx.nearest_neighbor_search(cloud[::3], with_index=True)
+        np.testing.assert_array_equal(lazy, whole[ix, :3], err_msg=f"{name} lazy")
+        try:
+            ctx.register(cloud)  # eager normals of every map point, whatever becomes of the degenerate alignment
+        except RuntimeError:
+            pass
+        _, eager, ix = ctx.nearest_neighbor_search(cloud, with_index=True)
+        np.testing.assert_array_equal(eager, whole[ix, :3], err_msg=f"{name} eager")
+        ctx.close()
 
 
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
