@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "icp_internal.h"
+#include "map_move_device.h"
 
 using namespace icp;
 
@@ -72,73 +73,6 @@ static void prof_collect(icp_ctx* ctx) {
 __global__ void k_state_init(RegState* st, Pose16 init, int keep_pose) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     state_init(st, init.m, keep_pose);
-}
-
-// general 4x4 inverse in f64 (np.linalg.inv(relative_pose), local_map.py:346); the same code on host and device
-__host__ __device__ inline bool invert4(const float* m, float* out) {
-    double a[4][8];
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            a[r][c] = m[4 * r + c];
-            a[r][4 + c] = r == c ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (a[piv][c] == 0.0) return false;
-        if (piv != c)
-            for (int k = 0; k < 8; ++k) {
-                const double t = a[c][k];
-                a[c][k] = a[piv][k];
-                a[piv][k] = t;
-            }
-        const double inv = 1.0 / a[c][c];
-        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-#if defined(__HIP_DEVICE_COMPILE__)
-                for (int k = 0; k < 8; ++k) a[r][k] = __dsub_rn(a[r][k], __dmul_rn(f, a[c][k]));  // no fma: host bits
-#else
-                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
-#endif
-            }
-    }
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) out[4 * r + c] = (float)a[r][4 + c];
-    return true;
-}
-
-// moved = R^-1 x + t^-1 over the kept part of the map (local_map.py:346-348)
-__device__ inline void move_point(const float* T, const float* __restrict__ in, long long i, float* __restrict__ out) {
-    const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-    // np.einsum("ij,nj->ni", R, map) + t
-    out[3 * i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
-    out[3 * i + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
-    out[3 * i + 2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
-}
-
-// The relative pose comes by value from the host or, st != nullptr, from the device-resident result of the last
-// registration (no host round trip).  Every block inverts the 4x4 once: one arithmetic for both sources, so the two
-// give the same map bit for bit.
-__global__ void k_map_move(const float* __restrict__ in, long long m, Pose16 rel, const RegState* __restrict__ st,
-                           float* __restrict__ out) {
-    __shared__ float T[16];
-    if (threadIdx.x == 0) {
-        float pose[16], inv[16];
-        for (int k = 0; k < 16; ++k) pose[k] = st ? st->pose[k] : rel.m[k];
-        // a registration that stopped on an error moves nothing: the reference raises before it would touch the map
-        // (slam/common/optimization.py:334-336 inside icp_odometry.py:286), the host learns of it in icp_register_end
-        const bool failed = st && st->status != ICP_OK;
-        if (failed || !invert4(pose, inv))  // a pose built from Euler angles is never singular; the host path checks
-            for (int k = 0; k < 16; ++k) inv[k] = (k % 5 == 0) ? 1.f : 0.f;
-        for (int k = 0; k < 16; ++k) T[k] = inv[k];
-    }
-    __syncthreads();
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    move_point(T, in, i, out);
 }
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
@@ -339,7 +273,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cslot_of,
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
-                            &ctx->vox_out,    &ctx->seed_orig};
+                            &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -620,6 +554,7 @@ int icp_map_init(icp_ctx* ctx) {
     ctx->map_m = 0;
     ctx->cloud_sizes.clear();
     ctx->grid_valid = false;
+    ctx->move_job = MapMoveJob();
     return ICP_OK;
 }
 
@@ -646,6 +581,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
                            int64_t n, bool has_cloud, int64_t* inserted_out) {
     int rc = ensure_state(ctx);
     if (rc) return rc;
+    ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
     int64_t inserted = 0;
     int64_t evicted = 0;
     if (ctx->map_m == 0 && ctx->cloud_sizes.empty() && !ctx->grid_valid) {
@@ -676,13 +612,14 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         DeviceBuffer& dst = ctx->map_xyz[next];
         ICP_HIP(ctx, dst.reserve((size_t)(keep + (has_cloud ? n : 0) + 1) * 12));
         const float* src = ctx->map_xyz[ctx->map_cur].as<float>() + 3 * evict;
-        if (keep > 0) {
-            Pose16 p;
-            memset(p.m, 0, sizeof(p.m));
-            if (rel_pose) memcpy(p.m, rel_pose, sizeof(p.m));
-            hipLaunchKernelGGL(k_map_move, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, ctx->stream, src,
-                               (long long)keep, p, rel_pose ? (const RegState*)nullptr : (const RegState*)reg_state(ctx),
-                               dst.as<float>());
+        if (keep > 0) {  // the re-expression rides in the first launch of the grid build below
+            MapMoveJob& job = ctx->move_job;
+            job.in = src;
+            job.out = dst.as<float>();
+            job.m = keep;
+            memset(job.rel.m, 0, sizeof(job.rel.m));
+            if (rel_pose) memcpy(job.rel.m, rel_pose, sizeof(job.rel.m));
+            job.st = rel_pose ? (const RegState*)nullptr : (const RegState*)reg_state(ctx);
         }
         if (has_cloud) {
             int* count_dev = ctx->counter.as<int>();

@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include "icp_internal.h"
+#include "map_move_device.h"
 
 namespace icp {
 
@@ -160,9 +161,15 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // + (seed_n > 0) the neighbours the last registration left in the NN cache -> original map indices, shifted by the
 // `evicted` oldest points this update drops: the seeds of the next frame's first iteration.  Must run while the old
 // cell-sorted positions still mean something, i.e. before the scatter of this build: it shares the first launch.
+// + (move.m > 0) the re-expression of the kept map points in the new frame (local_map.py:346-348): independent of the
+// other two, one launch less per frame.
 __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int2* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
-                             int* __restrict__ seed) {
+                             int* __restrict__ seed, MapMoveJob move) {
+    __shared__ float T[16];
+    const long long first = (long long)blockIdx.x * blockDim.x;
+    const bool moves = first < move.m;  // block-uniform
+    if (moves && threadIdx.x == 0) map_move_prepare(move, T);
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < size) {
         GridEntry e;
@@ -177,15 +184,18 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
         if (pos >= 0 && pos < old_m) o = __float_as_int(old_pts[pos].w) - evicted;
         seed[i] = o;
     }
+    if (moves) {
+        __syncthreads();
+        if ((long long)i < move.m) move_point(T, move.in, (long long)i, move.out);
+    }
 }
 
 // rows[cell][c] = (start, count) of the neighbour cell c of every occupied cell (0,0 if that neighbour is empty)
-__global__ void k_build_rows(const GridEntry* __restrict__ table, unsigned int mask,
-                             const int* __restrict__ slot_of_cell, const int* __restrict__ ncells_dev,
-                             int2* __restrict__ rows) {
+__device__ inline void build_rows_part(const GridEntry* __restrict__ table, unsigned int mask,
+                                       const int* __restrict__ slot_of_cell, const int* __restrict__ ncells_dev,
+                                       int2* __restrict__ rows, int block, int blocks) {
     const long long total = (long long)(*ncells_dev) * 27;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long long)gridDim.x * blockDim.x) {
+    for (long long t = (long long)block * blockDim.x + threadIdx.x; t < total; t += (long long)blocks * blockDim.x) {
         const int j = (int)(t / 27), c = (int)(t % 27);
         const GridEntry own = table[slot_of_cell[j]];
         int2 out = make_int2(0, 0);
@@ -322,46 +332,56 @@ __device__ inline unsigned long long block_exclusive_scan_u64(unsigned long long
     return wave_off + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_grid_tile_sums(const GridEntry* __restrict__ table, long long n,
-                                                                 unsigned int tsize,
-                                                                 unsigned long long* __restrict__ sums) {
-    __shared__ unsigned long long lds[16];
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    unsigned long long s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) s += grid_scan_item(table, base + k, n, tsize);
-    unsigned long long tot;
-    block_exclusive_scan_u64(s, &tot, lds);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+// ---------------------------------------------------------------------------------------------------------------------
+// The scan of the table in ONE launch (decoupled look-back): a tile of SCAN_TILE slots per workgroup; the workgroup sums
+// its tile, publishes the sum, and its first wave walks back over the predecessors' descriptors — 64 at a time — until
+// it meets one that already knows its inclusive prefix; then it publishes its own and applies the offsets to the counts
+// it still holds in registers.  (Three launches before: tile sums, scan of the sums by one workgroup, apply — the table
+// read twice and two kernel boundaries, 17.8 us per rebuild of a 100 000-point map.)
+// A descriptor is two 64-bit words, each (tag << 32 | 32-bit sum): A carries the point count, B the count of occupied
+// fine cells; tag = generation of this build << 2 | state (1: sum of the tile, 2: inclusive prefix).  Each word is written
+// and read by ONE relaxed agent-scope atomic, so no fence orders them: a reader takes a descriptor only when both tags
+// agree.  Stale descriptors of earlier builds carry another generation.  A workgroup only ever waits for LOWER-numbered
+// workgroups, which were dispatched before it.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr unsigned SCAN_STATE_SUM = 1, SCAN_STATE_PREFIX = 2;
+
+__device__ inline void scan_publish(unsigned long long* __restrict__ desc_a, unsigned long long* __restrict__ desc_b,
+                                    int tile, unsigned long long value, unsigned gen, unsigned state) {
+    const unsigned long long tag = (unsigned long long)((gen << 2) | state) << 32;
+    __hip_atomic_store(&desc_a[tile], tag | (value & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&desc_b[tile], tag | (value >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// single block: exclusive scan of the tile sums in place; the number of occupied fine cells -> *ncells_out
-__global__ __launch_bounds__(1024) void k_grid_scan_sums(unsigned long long* __restrict__ sums, int nb,
-                                                         int* __restrict__ ncells_out) {
-    __shared__ unsigned long long lds[16];
-    __shared__ unsigned long long carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        const unsigned long long v = (i < nb) ? sums[i] : 0ull;
-        unsigned long long tot;
-        const unsigned long long excl = block_exclusive_scan_u64(v, &tot, lds);
-        const unsigned long long carry = carry_s;
-        if (i < nb) sums[i] = carry + excl;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
+// waits for the descriptor of `tile` of this generation; false after ~2^20 polls (never seen; the caller then sums the
+// table itself instead of hanging the GPU)
+__device__ inline bool scan_wait(const unsigned long long* __restrict__ desc_a,
+                                 const unsigned long long* __restrict__ desc_b, int tile, unsigned gen,
+                                 unsigned long long& value, unsigned& state) {
+    for (int polls = 0; polls < (1 << 20); ++polls) {
+        const unsigned long long a = __hip_atomic_load(&desc_a[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(&desc_b[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned ta = (unsigned)(a >> 32), tb = (unsigned)(b >> 32);
+        if (ta == tb && (ta >> 2) == gen && (ta & 3u) != 0u) {
+            state = ta & 3u;
+            value = ((b & 0xffffffffull) << 32) | (a & 0xffffffffull);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
-    if (threadIdx.x == 0) *ncells_out = (int)(carry_s >> 32);
+    return false;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restrict__ table, long long n,
-                                                             unsigned int tsize, int m,
-                                                             const unsigned long long* __restrict__ sums,
-                                                             int* __restrict__ slot_of_cell) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restrict__ table, long long n,
+                                                            unsigned int tsize, int m,
+                                                            unsigned long long* __restrict__ desc_a,
+                                                            unsigned long long* __restrict__ desc_b, unsigned gen,
+                                                            int* __restrict__ slot_of_cell, int* __restrict__ ncells_out) {
     __shared__ unsigned long long lds[16];
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    __shared__ unsigned long long prefix_s;
+    __shared__ int gave_up;
+    const int tile = blockIdx.x;
+    const long long base = (long long)tile * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
     unsigned long long v[SCAN_ITEMS];
     unsigned long long s = 0;
 #pragma unroll
@@ -369,8 +389,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restri
         v[k] = grid_scan_item(table, base + k, n, tsize);
         s += v[k];
     }
+    if (threadIdx.x == 0) gave_up = 0;
     unsigned long long tot;
-    unsigned long long off = block_exclusive_scan_u64(s, &tot, lds) + sums[blockIdx.x];
+    const unsigned long long excl = block_exclusive_scan_u64(s, &tot, lds);  // (two barriers inside)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long prefix = 0;
+        if (tile == 0) {
+            if (lane == 0) scan_publish(desc_a, desc_b, 0, tot, gen, SCAN_STATE_PREFIX);
+        } else {
+            if (lane == 0) scan_publish(desc_a, desc_b, tile, tot, gen, SCAN_STATE_SUM);
+            bool failed = false;
+            for (int hi = tile - 1;; hi -= 64) {  // wave-uniform
+                const int idx = hi - lane;
+                unsigned long long val = 0;
+                unsigned state = SCAN_STATE_PREFIX;  // lanes in front of tile 0: a prefix of nothing ends the walk
+                bool ok = true;
+                if (idx >= 0) ok = scan_wait(desc_a, desc_b, idx, gen, val, state);
+                if (__ballot(!ok)) {
+                    failed = true;
+                    break;
+                }
+                const unsigned long long ends = __ballot(state == SCAN_STATE_PREFIX);
+                const int stop = ends ? __ffsll((long long)ends) - 1 : 64;  // nearest predecessor that knows its prefix
+                unsigned long long part = lane <= stop ? val : 0ull;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o, 64);
+                prefix += part;
+                if (stop < 64) break;
+            }
+            if (failed) {  // never seen: a predecessor did not publish in ~a second — the prefix from the table itself
+                if (lane == 0) gave_up = 1;
+            } else if (lane == 0) {
+                scan_publish(desc_a, desc_b, tile, prefix + tot, gen, SCAN_STATE_PREFIX);
+            }
+        }
+        if (lane == 0) prefix_s = prefix;
+    }
+    __syncthreads();
+    if (gave_up) {  // block-uniform
+        unsigned long long mine = 0;
+        for (long long i = threadIdx.x; i < (long long)tile * SCAN_TILE; i += SCAN_THREADS)
+            mine += grid_scan_item(table, i, n, tsize);
+        unsigned long long all;
+        block_exclusive_scan_u64(mine, &all, lds);
+        if (threadIdx.x == 0) {
+            prefix_s = all;
+            scan_publish(desc_a, desc_b, tile, all + tot, gen, SCAN_STATE_PREFIX);
+        }
+        __syncthreads();
+    }
+    unsigned long long off = excl + prefix_s;
+    if (threadIdx.x == 0 && tile == (int)gridDim.x - 1) *ncells_out = (int)((prefix_s + tot) >> 32);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const long long i = base + k;
@@ -387,13 +457,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_apply(GridEntry* __restri
     }
 }
 
-__global__ void k_grid_scatter2(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
+__device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
                                 const int* __restrict__ slot_of, const int* __restrict__ rank_of,
                                 const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
                                 float4* __restrict__ sorted,
                                 float4* __restrict__ csorted, float4* __restrict__ normals, int* __restrict__ nflag,
                                 int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const int slot = slot_of[i];
     const int pos = table[slot].start + rank_of[i];
@@ -408,6 +477,25 @@ __global__ void k_grid_scatter2(const float* __restrict__ xyz, int m, const Grid
     nflag[i] = 0;
 }
 
+
+// The neighbour rows and the scatter both need the scanned table and nothing of each other: one launch, the first
+// `row_blocks` workgroups build rows (grid-stride over the occupied cells x 27), the others scatter the points.
+__global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
+                                    unsigned int mask, const int* __restrict__ slot_of_cell,
+                                    const int* __restrict__ ncells_dev, int2* __restrict__ rows, int row_blocks,
+                                    const int* __restrict__ slot_of, const int* __restrict__ rank_of,
+                                    const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
+                                    float4* __restrict__ sorted, float4* __restrict__ csorted,
+                                    float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
+                                    int* __restrict__ pos_of_orig) {
+    if ((int)blockIdx.x < row_blocks) {  // block-uniform
+        build_rows_part(table, mask, slot_of_cell, ncells_dev, rows, blockIdx.x, row_blocks);
+        return;
+    }
+    grid_scatter_part((blockIdx.x - row_blocks) * blockDim.x + threadIdx.x, xyz, m, table, slot_of, rank_of, cslot_of,
+                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig);
+}
+
 static unsigned int next_pow2(unsigned int v) {
     unsigned int p = 1024;
     while (p < v) p <<= 1;
@@ -418,6 +506,7 @@ int build_grid(icp_ctx* ctx) {
     const int64_t m = ctx->map_m;
     ctx->grid_valid = false;
     if (m <= 0) {
+        ctx->move_job = MapMoveJob();
         ctx->seed_job_n = 0;  // nothing to seed against
         ctx->seed_n = 0;
         return ICP_OK;
@@ -473,35 +562,44 @@ int build_grid(icp_ctx* ctx) {
     const unsigned mb = (unsigned)((m + 255) / 256);
     const long long n2 = 2ll * tsize;  // both levels
     const int nb = (int)((n2 + SCAN_TILE - 1) / SCAN_TILE);
-    ICP_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * sizeof(unsigned long long)));
-    unsigned long long* sums = ctx->scan_tmp.as<unsigned long long>();
+    // descriptors of the one-launch scan: [nb] point-count words, then [nb] cell-count words; a fresh allocation is
+    // zeroed (tag 0 belongs to no build), later builds tell their descriptors from stale ones by the generation
+    {
+        const size_t need = (size_t)2 * nb * sizeof(unsigned long long);
+        if (ctx->scan_desc.bytes < need) {
+            ICP_HIP(ctx, ctx->scan_desc.reserve(need));
+            ICP_HIP(ctx, hipMemsetAsync(ctx->scan_desc.ptr, 0, ctx->scan_desc.bytes, ctx->stream));
+        }
+    }
+    unsigned long long* desc = ctx->scan_desc.as<unsigned long long>();
+    const unsigned scan_gen = (unsigned)((ctx->scan_builds++ % 0x3ffffffeull) + 1ull);  // 1 .. 2^30 - 2, a new one per launch
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
     {
         const int seed_n = ctx->seed_job_n;
         ctx->seed_job_n = 0;
-        const long long span = n2 > seed_n ? n2 : (long long)seed_n;
+        long long span = n2 > seed_n ? n2 : (long long)seed_n;
+        const MapMoveJob move = ctx->move_job;  // the kept points re-expressed in the new frame (map update)
+        ctx->move_job = MapMoveJob();
+        if (move.m > span) span = move.m;
         hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
                            (unsigned int)n2, ctx->nn_cache.as<int2>(), ctx->sorted_pts.as<float4>(), seed_n,
-                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>());
+                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move);
     }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                        ctx->crank_of.as<int>());
-    hipLaunchKernelGGL(k_grid_tile_sums, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, sums);
-    hipLaunchKernelGGL(k_grid_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nb, ncells_dev);
-    hipLaunchKernelGGL(k_grid_apply, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, sums,
-                       ctx->slot_of_cell.as<int>());
+    hipLaunchKernelGGL(k_grid_scan, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, desc,
+                       desc + nb, scan_gen, ctx->slot_of_cell.as<int>(), ncells_dev);
     {
         long long want = ((long long)m * 27 + 255) / 256;
         const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
-        hipLaunchKernelGGL(k_build_rows, dim3(rb), dim3(256), 0, ctx->stream, table, tsize - 1,
-                           ctx->slot_of_cell.as<int>(), ncells_dev, ctx->rows.as<int2>());
+        hipLaunchKernelGGL(k_grid_rows_scatter, dim3(rb + mb), dim3(256), 0, ctx->stream, xyz, (int)m, table, tsize - 1,
+                           ctx->slot_of_cell.as<int>(), ncells_dev, ctx->rows.as<int2>(), (int)rb,
+                           ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
+                           ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(), ctx->csorted.as<float4>(),
+                           ctx->normals.as<float4>(), ctx->nflag.as<int>(), ctx->row_of_pos.as<int>(),
+                           ctx->pos_of_orig.as<int>());
     }
-    hipLaunchKernelGGL(k_grid_scatter2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, table,
-                       ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                       ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(),
-                       ctx->csorted.as<float4>(), ctx->normals.as<float4>(), ctx->nflag.as<int>(),
-                       ctx->row_of_pos.as<int>(), ctx->pos_of_orig.as<int>());
     ctx->ctable_ptr = table + tsize;
     ctx->ctable_size = tsize;
     ICP_HIP(ctx, hipGetLastError());

@@ -125,6 +125,21 @@ struct ExchangeView {
     long long timeout_ticks;                  // 100 MHz wall-clock ticks to wait for the peers
 };
 
+struct Pose16 {
+    float m[16];
+};
+
+// Re-expression of the map (local_map.py:346-348) that the next grid build carries out in its first launch
+// (map_move_device.h): moved = inv(pose) applied to `m` points.  The relative pose comes by value from the host or,
+// st != nullptr, from the device-resident result of the last registration (no host round trip).
+struct MapMoveJob {
+    const float* in = nullptr;
+    float* out = nullptr;
+    long long m = 0;               // 0: nothing to move
+    Pose16 rel{};
+    const RegState* st = nullptr;  // device-resident pose instead of `rel`
+};
+
 struct AlignParams {
     int scheme;
     float sigma;
@@ -180,7 +195,10 @@ struct icp_ctx {
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
+    icp::DeviceBuffer scan_desc;       // descriptors of the one-launch table scan of the grid build (k_grid_scan)
+    uint64_t scan_builds = 0;          // launches of that scan so far (its descriptors are tagged with it)
     icp::DeviceBuffer worklist;        // int[M]
+    icp::MapMoveJob move_job;          // pending re-expression of the kept points (consumed by build_grid)
     bool grid_valid = false;
     uint64_t grid_gen = 0;             // bumped by every grid build: cell-sorted positions are only valid within one
     bool normals_ready = false;        // every map normal already estimated (eager mode) since the last rebuild
@@ -343,9 +361,6 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 // targets -> float4 rows (x, y, z, bits(row)) in ctx->tgt4
 // targets -> float4 rows; with `init` the registration state is initialised by the same launch (init->m = the initial
 // guess; keep_pose: the pose the state already holds — the previous result — is the guess)
-struct Pose16 {
-    float m[16];
-};
 int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init = nullptr, bool keep_pose = false);
 int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                             long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
