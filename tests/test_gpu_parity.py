@@ -423,6 +423,31 @@ def test_knn_normals_on_stress_clouds(torch_cuda, O, neighbors):
         ctx.close()
 
 
+def test_grid_build_with_more_scan_tiles_than_resident_workgroups(torch_cuda, O):
+    """The table scan of the grid build is one launch with decoupled look-back: a tile waits for the descriptors of its
+    predecessors.  3 M points give 8192 tiles — four times what the chip keeps resident — so most tiles are dispatched
+    while others spin; the grid must come out right (exact neighbours against a kd-tree, every point its own nearest
+    neighbour) and a second build on the same context (stale descriptors of the first) as well."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(3)
+    model = (rng.random((3_000_000, 3)) * np.array([400.0, 400.0, 20.0])).astype(np.float32)
+    ctx = _ctx()
+    for build in range(2):
+        ctx.map_set(model)
+        q = (rng.random((2000, 3)) * np.array([400.0, 400.0, 20.0])).astype(np.float32)
+        _, _, ix = ctx.nearest_neighbor_search(q, with_normals=False, with_index=True)
+        _, best = cKDTree(model.astype(np.float64)).query(q.astype(np.float64), workers=-1)
+        same = ix == best
+        dq = ((q - model[ix]).astype(np.float64) ** 2).sum(-1)
+        db = ((q - model[best]).astype(np.float64) ** 2).sum(-1)
+        assert same.mean() > 0.99 and np.allclose(dq[~same], db[~same], rtol=2e-6), (build, same.mean())
+        sub = model[::997]
+        _, _, own = ctx.nearest_neighbor_search(sub, with_normals=False, with_index=True)
+        assert np.array_equal(model[own], sub), build  # itself, or an exact duplicate with a smaller index
+        model = model[::-1].copy()  # another order -> other table contents for the second build
+    ctx.close()
+
+
 def test_split_iteration_seam_equals_fused_register(torch_cuda, golden_components):
     """The multi-GPU seam (accumulate -> [all-reduce] -> solve) with world size 1 reproduces icp_register bit for bit,
     and two half-slices summed by hand give the same normal equations as the whole scan."""
