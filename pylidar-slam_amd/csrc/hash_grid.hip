@@ -225,7 +225,7 @@ __device__ inline void build_rows_part(const GridEntry* __restrict__ table, unsi
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused build of BOTH levels: the fine and the coarse table live back to back in one array ([0,T) fine, [T,2T) coarse),
-// so clearing, inserting, the count scan and the scatter are one launch each (7 launches per rebuild instead of 21).
+// so clearing, inserting, the count scan and the scatter (with the neighbour rows) are one launch each: 4 per rebuild.
 // One 64-bit scan carries two sums at once: low word = points before the slot (cell start; the fine level holds exactly
 // m points, so coarse starts are that prefix minus m), high word = occupied FINE cells before the slot (row id).
 // ---------------------------------------------------------------------------------------------------------------------
