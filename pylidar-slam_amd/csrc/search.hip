@@ -18,7 +18,7 @@ namespace icp {
 // ---------------------------------------------------------------------------------------------------------------------
 // K1: transform + exact 1-NN, neighbour rows, 4 lanes per query.
 //
-// What the hardware counters said about a one-lane-per-query ring search (round 1, tools/pmc_probe.sh): L1 hit rate
+// What the hardware counters said about a one-lane-per-query ring search (round 1): L1 hit rate
 // > 90 %, HBM traffic = the compulsory bytes, yet 160 dependent load instructions and ~3000 VALU instructions per wave:
 // the 27-cell loop runs once per cell for the union of the lanes, each pass = hash + dependent probe + dependent
 // candidate rounds.  So:

@@ -1,4 +1,4 @@
-// Device-side building blocks of the exact voxel-hash nearest-neighbour search (shared by search.hip and tools/).
+// Device-side building blocks of the exact voxel-hash nearest-neighbour search (search.hip).
 #pragma once
 #include "icp_internal.h"
 
