@@ -34,7 +34,9 @@ collective) -> weak scaling; `--mode sharded` instead splits every scan's points
 packed 6x6 normal equations (32 doubles) once per ICP iteration (strong scaling of one sequence).
 
 `--sequences-per-gpu S` (throughput mode, default 1): S independent sequences per GPU on S contexts / HIP streams / host
-threads; one sequence is a chain of dependent, latency-bound kernels and leaves most of the GPU idle.
+threads; one sequence is a chain of dependent, latency-bound kernels and leaves most of the GPU idle.  The default
+single-GPU run reports such a leg next to the headline (`"throughput"`: 4 sequences, same steps, outside the headline
+timing; `--throughput-leg 0` skips it).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-iteration fused search + rows kernel),
 timed with HIP events on the library's stream inside the timed region (`traffic` = the PMC figure of the committed
@@ -102,6 +104,10 @@ def parse():
                     help="throughput mode: S independent sequences per GPU, each with its own context and HIP stream, "
                          "driven by S host threads (one sequence cannot fill the GPU: its kernels are latency-bound and "
                          "serially dependent).  `value` then counts all sequences; ms_per_step stays the per-frame latency")
+    ap.add_argument("--throughput-leg", type=int, default=4, metavar="S",
+                    help="after the headline (single process, --sequences-per-gpu 1 only): S independent sequences on S "
+                         "streams of this GPU for the same number of steps, reported as `throughput` in the JSON line "
+                         "(0: skip; also skipped with --no-cpu-baseline, the switch of the developer A/B runs)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (icp_set_option), repeatable — for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,6 +284,40 @@ class SequenceThread(threading.Thread):
         self.go.set()
 
 
+def throughput_leg(args, S, device_index):
+    """S independent sequences on S contexts / streams / host threads of this GPU, outside the headline timing: what the
+    chip delivers when it is not waiting on one sequence's chain of dependent kernels."""
+    threads = [SequenceThread(args, 100 + j, device_index) for j in range(S)]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.ready.wait()
+        t_.start_phase(args.warmup)
+    for t_ in threads:
+        t_.done.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t_ in threads:
+        t_.start_phase(args.steps)
+    for t_ in threads:
+        t_.done.wait()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    err = max(t_.max_err for t_ in threads)
+    for t_ in threads:
+        t_.phase = None
+        t_.go.set()
+    for t_ in threads:
+        t_.join(timeout=30)
+    value = S * args.steps / elapsed
+    frame_bytes = args.iters * BYTES_PER_POINT_ITER * 131072 + 28 * 131072 + (48 + 28 + 132) * 100_000  # SURVEY §8(d)
+    return {"sequences_per_gpu": S, "value": value, "unit": "scans/s", "steps_per_sequence": args.steps,
+            "ms_per_step_per_sequence": elapsed * 1e3 / args.steps,
+            "whole_path_algorithmic_GBps": frame_bytes * value / 1e9,
+            "whole_path_frac_of_hbm_peak": frame_bytes * value / HBM_PEAK,
+            "max_pose_error_vs_ground_truth_m": err}
+
+
 def cpu_baseline(tracker, args, frames=3):
     """The oracle ("port") on the same workload on the host cores of this box: one warm-up frame, then the median of
     `frames` frames (projection + 20-iteration registration + map re-expression and kd-tree rebuild, like a GPU step);
@@ -407,6 +447,10 @@ def main():
                 "max_pose_error_vs_ground_truth_m": lt.max_err}
         lt.close()
 
+    through = None
+    if rank == 0 and world == 1 and S == 1 and args.throughput_leg > 1 and not sharded and not args.no_cpu_baseline:
+        through = throughput_leg(args, args.throughput_leg, local_rank)
+
     if rank == 0:
         scans_total = args.steps * (1 if sharded else world) * S
         value = scans_total / elapsed
@@ -438,6 +482,8 @@ def main():
                            f"{MIN_STEPS_FOR_HEADLINE}; read ms_per_step_spread with the value")
         if loop is not None:
             out["loop"] = loop
+        if through is not None:
+            out["throughput"] = through
         if prof and prof["search_launches"] > 0:
             avg_s = prof["search_ms"] * 1e-3 / prof["search_launches"]
             n_local = main_tr.n_local if sharded else main_tr.n_pts
