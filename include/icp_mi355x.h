@@ -116,6 +116,8 @@ int icp_synchronize(icp_ctx* ctx);
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 | 2 (0)
+ *   "scan_poll_limit" n (2^20)      grid build: polls of a predecessor tile's descriptor before a tile of the one-launch table
+ *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
  *   "profile_every" n (1)           icp_profile_enable times the kernels of every n-th registration only (an event pair
  *                                   costs ~2 us of stream time: 40 pairs per frame are 10 % of a 0.8 ms registration)
  * The library reads no environment variables. */

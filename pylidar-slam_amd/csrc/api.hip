@@ -320,6 +320,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
+    else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {

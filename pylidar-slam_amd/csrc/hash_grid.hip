@@ -353,12 +353,12 @@ __device__ inline void scan_publish(unsigned long long* __restrict__ desc_a, uns
     __hip_atomic_store(&desc_b[tile], tag | (value >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// waits for the descriptor of `tile` of this generation; false after ~2^20 polls (never seen; the caller then sums the
-// table itself instead of hanging the GPU)
+// waits for the descriptor of `tile` of this generation; false after `poll_limit` polls (2^20 in production: never seen;
+// the caller then sums the table itself instead of hanging the GPU — the option "scan_poll_limit" lets a test go there)
 __device__ inline bool scan_wait(const unsigned long long* __restrict__ desc_a,
-                                 const unsigned long long* __restrict__ desc_b, int tile, unsigned gen,
+                                 const unsigned long long* __restrict__ desc_b, int tile, unsigned gen, int poll_limit,
                                  unsigned long long& value, unsigned& state) {
-    for (int polls = 0; polls < (1 << 20); ++polls) {
+    for (int polls = 0; polls < poll_limit; ++polls) {
         const unsigned long long a = __hip_atomic_load(&desc_a[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long b = __hip_atomic_load(&desc_b[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned ta = (unsigned)(a >> 32), tb = (unsigned)(b >> 32);
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
                                                             unsigned int tsize, int m,
                                                             unsigned long long* __restrict__ desc_a,
                                                             unsigned long long* __restrict__ desc_b, unsigned gen,
-                                                            int* __restrict__ slot_of_cell, int* __restrict__ ncells_out) {
+                                                            int poll_limit, int* __restrict__ slot_of_cell,
+                                                            int* __restrict__ ncells_out) {
     __shared__ unsigned long long lds[16];
     __shared__ unsigned long long prefix_s;
     __shared__ int gave_up;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
                 unsigned long long val = 0;
                 unsigned state = SCAN_STATE_PREFIX;  // lanes in front of tile 0: a prefix of nothing ends the walk
                 bool ok = true;
-                if (idx >= 0) ok = scan_wait(desc_a, desc_b, idx, gen, val, state);
+                if (idx >= 0) ok = scan_wait(desc_a, desc_b, idx, gen, poll_limit, val, state);
                 if (__ballot(!ok)) {
                     failed = true;
                     break;
@@ -589,7 +590,7 @@ int build_grid(icp_ctx* ctx) {
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                        ctx->crank_of.as<int>());
     hipLaunchKernelGGL(k_grid_scan, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, desc,
-                       desc + nb, scan_gen, ctx->slot_of_cell.as<int>(), ncells_dev);
+                       desc + nb, scan_gen, ctx->scan_poll_limit, ctx->slot_of_cell.as<int>(), ncells_dev);
     {
         long long want = ((long long)m * 27 + 255) / 256;
         const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);

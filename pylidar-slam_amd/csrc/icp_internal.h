@@ -197,6 +197,7 @@ struct icp_ctx {
     icp::DeviceBuffer scan_tmp;
     icp::DeviceBuffer scan_desc;       // descriptors of the one-launch table scan of the grid build (k_grid_scan)
     uint64_t scan_builds = 0;          // launches of that scan so far (its descriptors are tagged with it)
+    int scan_poll_limit = 1 << 20;     // "scan_poll_limit" (dev): polls of a predecessor's descriptor before a tile sums the table itself
     icp::DeviceBuffer worklist;        // int[M]
     icp::MapMoveJob move_job;          // pending re-expression of the kept points (consumed by build_grid)
     bool grid_valid = false;

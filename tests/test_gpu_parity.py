@@ -304,7 +304,8 @@ def test_fresh_context_after_a_large_one_reads_no_stale_memory(torch_cuda, O, go
 def test_schedule_options_are_bit_identical(torch_cuda):
     """The tuning options of `icp_set_option` are pure schedule changes: the per-iteration NN cache (skip the search
     when the cached neighbour is provably still the nearest), the in-block compaction of its misses, the 64-register
-    build, the cross-frame seeds and the cell size give the same poses, losses and maps bit for bit;
+    build, the cross-frame seeds, the cell size and the fallback of the grid build's one-launch scan (every tile summing
+    the table itself instead of waiting for its predecessors) give the same poses, losses and maps bit for bit;
     the unfused path shares everything but the reduction order (1e-6 relative)."""
     from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
     cfg = SceneConfig(height=32, width=1024)
@@ -317,7 +318,8 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "wave_search_always": {"wave_misses": 128},
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
-                "lanes2": {"knn_lanes": 2}, "unfused": {"fuse_iteration": 0}}
+                "lanes2": {"knn_lanes": 2}, "scan_gives_up": {"scan_poll_limit": 0},
+                "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
         ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure",
