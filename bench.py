@@ -42,8 +42,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-i
 timed with HIP events on the library's stream inside the timed region (`traffic` = the PMC figure of the committed
 rocprofv3 counter run, tagged with its source file and the commit it was measured at: counters cannot be collected
 from inside this process); `cpu_baseline` times the numpy/cKDTree oracle (oracle/icp_oracle.py, a restatement of the
-reference's CPU path — the reference itself does not exist on the GPU box) on the same workload: median of 3 frames
-after one warm-up frame, the kd-tree build timed separately.
+reference's CPU path — the reference itself does not exist on the GPU box) on the same workload: median of 6 frames
+after two warm-up frames, the kd-tree build timed separately.
 """
 import argparse
 import json
@@ -322,10 +322,10 @@ def throughput_leg(args, S, device_index, main_tr):
             "max_pose_error_vs_ground_truth_m": err}
 
 
-def cpu_baseline(tracker, args, frames=3):
-    """The oracle ("port") on the same workload on the host cores of this box: one warm-up frame, then the median of
-    `frames` frames (projection + 20-iteration registration + map re-expression and kd-tree rebuild, like a GPU step);
-    the first kd-tree build is reported on its own."""
+def cpu_baseline(tracker, args, frames=6, warmup=2):
+    """The oracle ("port") on the same workload on the host cores of this box: `warmup` warm-up frames, then the median
+    of `frames` frames (projection + 20-iteration registration + map re-expression and kd-tree rebuild, like a GPU
+    step) — about 18 s of CPU work; the first kd-tree build is reported on its own."""
     import icp_oracle as O
     lm = O.KdTreeLocalMapOracle()
     t0 = time.perf_counter()
@@ -336,7 +336,7 @@ def cpu_baseline(tracker, args, frames=3):
     orc.local_map = lm
     times, last = [], np.eye(4, dtype=np.float32)
     order = tracker.order
-    for i in range(frames + 1):
+    for i in range(frames + warmup):
         scan = tracker.host_scans[order[i % len(order)]]
         t0 = time.perf_counter()
         O.build_projection_map(scan, 64, 2048, 3.0, -24.0)
@@ -344,13 +344,13 @@ def cpu_baseline(tracker, args, frames=3):
         lm.update(pose)
         times.append(time.perf_counter() - t0)
         last = pose
-    timed = sorted(times[1:])
+    timed = sorted(times[warmup:])
     med = timed[len(timed) // 2]
     return {"value": 1.0 / med, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"median of {frames} frames after 1 warm-up frame of the same workload (131072-pt scan vs 100k "
+            "sample": f"median of {frames} frames after {warmup} warm-up frames of the same workload (131072-pt scan vs 100k "
                       f"map, {args.iters} iters; projection + registration + map re-expression/kd-tree rebuild) with "
                       f"oracle/icp_oracle.py: numpy f32 + scipy cKDTree(workers=-1) standing in for pykdtree",
-            "frame_s": {"min": timed[0], "median": med, "max": timed[-1], "warmup": times[0]},
+            "frame_s": {"min": timed[0], "median": med, "max": timed[-1], "warmup": times[:warmup]},
             "tree_build_s": build_s, "ms_per_icp_iter": med * 1e3 / args.iters,
             "torch_threads": torch.get_num_threads()}
 
