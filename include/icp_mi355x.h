@@ -179,9 +179,10 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* s
  * update), evict the oldest cloud beyond local_map_size, rebuild the search structure and clear the normal cache.
  * *inserted_out (optional) = number of rows appended.  rel_pose = NULL: the pose of the last registration on this
  * context, read on the device (no host round trip; valid after icp_register / icp_register_launch).  If that
- * registration stopped on an error (ICP_ERR_INVALID_JACOBIAN, ICP_ERR_EXCHANGE) the map is NOT moved and the new cloud
- * is inserted as it stands (the reference raises before it would touch the map; the error itself reaches the caller
- * through icp_register_end). */
+ * registration stopped on an error (ICP_ERR_INVALID_JACOBIAN, ICP_ERR_EXCHANGE) the map is NOT moved (the reference
+ * raises before it would touch the map; the error itself reaches the caller through icp_register_end).  While the
+ * result of a launched registration is still pending, only the pose-only form (new_xyz = NULL) is accepted with
+ * rel_pose = NULL: an insertion / eviction must not follow a registration whose status the host has not seen. */
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out);
 /* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */
@@ -282,7 +283,9 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
  *                        exchange mode; every rank must then issue the same sequence of registrations;
  *   icp_exchange_destroy leaves exchange mode and releases the mappings.
  * A peer that does not deliver within the budget (option "exchange_timeout_ms", default 5000) ends the registration
- * with ICP_ERR_EXCHANGE instead of hanging the GPU.  world <= 16. */
+ * with ICP_ERR_EXCHANGE instead of hanging the GPU — and the context LEAVES exchange mode: the ranks' sequence counters
+ * and inbox tags may have diverged, so registrations fall back to the rank-local solve until every rank has called
+ * icp_exchange_create + icp_exchange_connect again (fresh inboxes, counters at zero).  world <= 16. */
 #define ICP_EXCHANGE_HANDLE_BYTES 64
 int icp_exchange_create(icp_ctx* ctx, int32_t rank, int32_t world, void* handle_out);
 int icp_exchange_connect(icp_ctx* ctx, const void* handles);

@@ -648,6 +648,12 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
     if (!rel_pose && !ctx->have_device_pose)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL needs a previous registration on this context");
     const bool has_cloud = new_xyz != nullptr;
+    // a registration that stops on an error must leave the window untouched (the reference raises before it touches the
+    // map, icp_odometry.py:286): while its status is still unknown to the host, only the pose-only update — which the
+    // device skips on an error — may be enqueued behind it
+    if (!rel_pose && has_cloud && ctx->result_pending())
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL with a new cloud: collect the pending registration "
+                                                   "(icp_register_end) first");
     const void* in = nullptr;
     int rc;
     if (has_cloud) {
@@ -889,6 +895,7 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
     if ((rc = prepare_targets_and_state(ctx, n, init_pose))) return rc;
+    ctx->have_device_pose = false;  // icp_map_update(rel_pose = NULL) follows a registration against the kd-tree style map only
     ctx->in_registration = true;
     const int iters = ctx->cfg.max_num_alignments;
     const int poll = ctx->cfg.threshold_delta_pose > 0.f ? ctx->cfg.poll_every : 0;
@@ -1294,8 +1301,13 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     if (ctx->prof.enabled) prof_collect(ctx);
     if (st.status == ICP_ERR_INVALID_JACOBIAN)
         return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
-    if (st.status == ICP_ERR_EXCHANGE)
-        return fail(ctx, ICP_ERR_EXCHANGE, "multi-GPU exchange: a peer did not deliver its normal equations in time");
+    if (st.status == ICP_ERR_EXCHANGE) {
+        // the ranks' sequence counters and inbox tags may have diverged (a rank that timed out did not advance, one that
+        // received everything did): the exchange is unusable until it is created and connected again
+        ctx->exchange_on = false;
+        return fail(ctx, ICP_ERR_EXCHANGE, "multi-GPU exchange: a peer did not deliver its normal equations in time; "
+                                           "the context left exchange mode (icp_exchange_create / _connect again)");
+    }
     return st.status;
 }
 

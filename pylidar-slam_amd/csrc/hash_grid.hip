@@ -165,8 +165,9 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // other two, one launch less per frame.
 __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int2* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
-                             int* __restrict__ seed, MapMoveJob move) {
+                             int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket) {
     __shared__ float T[16];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scan_ticket = 0;  // the tile numbers of this build's k_grid_scan
     const long long first = (long long)blockIdx.x * blockDim.x;
     const bool moves = first < move.m;  // block-uniform
     if (moves && threadIdx.x == 0) map_move_prepare(move, T);
@@ -341,8 +342,9 @@ __device__ inline unsigned long long block_exclusive_scan_u64(unsigned long long
 // A descriptor is two 64-bit words, each (tag << 32 | 32-bit sum): A carries the point count, B the count of occupied
 // fine cells; tag = generation of this build << 2 | state (1: sum of the tile, 2: inclusive prefix).  Each word is written
 // and read by ONE relaxed agent-scope atomic, so no fence orders them: a reader takes a descriptor only when both tags
-// agree.  Stale descriptors of earlier builds carry another generation.  A workgroup only ever waits for LOWER-numbered
-// workgroups, which were dispatched before it.
+// agree.  Stale descriptors of earlier builds carry another generation (the descriptors are zeroed when the generation
+// counter wraps).  A workgroup takes its tile number from a ticket counter (reset by k_grid_clear), so it only ever waits
+// for tiles whose workgroups are already running, whatever order the hardware dispatches blockIdx in.
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr unsigned SCAN_STATE_SUM = 1, SCAN_STATE_PREFIX = 2;
 
@@ -377,11 +379,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
                                                             unsigned long long* __restrict__ desc_a,
                                                             unsigned long long* __restrict__ desc_b, unsigned gen,
                                                             int poll_limit, int* __restrict__ slot_of_cell,
-                                                            int* __restrict__ ncells_out) {
+                                                            int* __restrict__ ncells_out, int* __restrict__ ticket) {
     __shared__ unsigned long long lds[16];
     __shared__ unsigned long long prefix_s;
     __shared__ int gave_up;
-    const int tile = blockIdx.x;
+    __shared__ int tile_s;
+    if (threadIdx.x == 0) {
+        tile_s = atomicAdd(ticket, 1);
+        gave_up = 0;
+    }
+    __syncthreads();
+    const int tile = tile_s;
     const long long base = (long long)tile * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
     unsigned long long v[SCAN_ITEMS];
     unsigned long long s = 0;
@@ -390,7 +398,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
         v[k] = grid_scan_item(table, base + k, n, tsize);
         s += v[k];
     }
-    if (threadIdx.x == 0) gave_up = 0;
     unsigned long long tot;
     const unsigned long long excl = block_exclusive_scan_u64(s, &tot, lds);  // (two barriers inside)
     if (threadIdx.x < 64) {
@@ -565,15 +572,18 @@ int build_grid(icp_ctx* ctx) {
     const int nb = (int)((n2 + SCAN_TILE - 1) / SCAN_TILE);
     // descriptors of the one-launch scan: [nb] point-count words, then [nb] cell-count words; a fresh allocation is
     // zeroed (tag 0 belongs to no build), later builds tell their descriptors from stale ones by the generation
+    // (the first 64 bytes of the buffer hold the ticket counter the tiles draw their numbers from)
+    const unsigned scan_gen = (unsigned)((ctx->scan_builds++ % 0x3ffffffeull) + 1ull);  // 1 .. 2^30 - 2, a new one per launch
     {
-        const size_t need = (size_t)2 * nb * sizeof(unsigned long long);
-        if (ctx->scan_desc.bytes < need) {
+        const size_t need = 64 + (size_t)2 * nb * sizeof(unsigned long long);
+        const bool wrapped = scan_gen == 1u && ctx->scan_builds > 1ull;  // generations start over: no stale tag may match
+        if (ctx->scan_desc.bytes < need || wrapped) {
             ICP_HIP(ctx, ctx->scan_desc.reserve(need));
             ICP_HIP(ctx, hipMemsetAsync(ctx->scan_desc.ptr, 0, ctx->scan_desc.bytes, ctx->stream));
         }
     }
-    unsigned long long* desc = ctx->scan_desc.as<unsigned long long>();
-    const unsigned scan_gen = (unsigned)((ctx->scan_builds++ % 0x3ffffffeull) + 1ull);  // 1 .. 2^30 - 2, a new one per launch
+    int* scan_ticket = ctx->scan_desc.as<int>();
+    unsigned long long* desc = ctx->scan_desc.as<unsigned long long>() + 8;
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
     {
         const int seed_n = ctx->seed_job_n;
@@ -584,13 +594,13 @@ int build_grid(icp_ctx* ctx) {
         if (move.m > span) span = move.m;
         hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
                            (unsigned int)n2, ctx->nn_cache.as<int2>(), ctx->sorted_pts.as<float4>(), seed_n,
-                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move);
+                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket);
     }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                        ctx->crank_of.as<int>());
     hipLaunchKernelGGL(k_grid_scan, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, desc,
-                       desc + nb, scan_gen, ctx->scan_poll_limit, ctx->slot_of_cell.as<int>(), ncells_dev);
+                       desc + nb, scan_gen, ctx->scan_poll_limit, ctx->slot_of_cell.as<int>(), ncells_dev, scan_ticket);
     {
         long long want = ((long long)m * 27 + 255) / 256;
         const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);

@@ -392,6 +392,7 @@ int pmap_iterate(icp_ctx* ctx, int* blocks_out) {
     const int k_maps = (int)ctx->pm_slots.size();
     ICP_HIP(ctx, ctx->zbuf.reserve((size_t)npix * sizeof(unsigned long long)));
     unsigned long long* z = ctx->zbuf.as<unsigned long long>();
+    ctx->zbuf_clean = nullptr;  // the target keys stay behind: the next icp_project on this context must clear first
     const int blocks = (npix + PM_THREADS - 1) / PM_THREADS;
     ICP_HIP(ctx, ctx->partials.reserve((size_t)blocks * NEQ * sizeof(double)));
     hipLaunchKernelGGL(k_zclear, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, z, (long long)npix);

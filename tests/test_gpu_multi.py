@@ -204,6 +204,13 @@ def _rank_main_exchange(rank, world, port, out):
             ctx.register(mine)
         except ExchangeTimeoutError:
             timed_out = True
+        # the ranks' exchange counters may have diverged: the context left exchange mode and solves rank-locally until
+        # the exchange is created and connected again (no stale inbox payload is ever summed)
+        alone = ctx.register(mine)
+        solo = IcpContext(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0,
+                          scheme="geman_mcclure", sigma=0.3)
+        solo.map_set(torch.from_numpy(model).cuda())
+        timed_out = timed_out and np.array_equal(alone.pose, solo.register(mine).pose)
         np.savez(out, pose=res.pose, losses=res.losses, dx=res.dx, pose2=res2.pose,
                  all=np.stack([p.numpy() for p in poses]), targets=res.num_targets, timed_out=timed_out)
     dist.barrier()

@@ -271,3 +271,58 @@ def test_two_frames_in_flight_equal_the_synchronous_loop(torch_cuda):
     fresh.map_set(model)
     with pytest.raises(AssertionError):
         fresh.register_launch(dscans[4], "last")  # no previous registration to start from
+
+
+# ---- round-3 regressions (ADVICE.md of round 2) ----------------------------------------------------------------------
+def test_projection_after_a_projective_registration_starts_from_a_clean_z_buffer(torch_cuda):
+    """The projective iteration leaves its target keys in the context's z-buffer; the next `icp_project` on that context
+    must clear them first (the "left clean by the resolve kernel" shortcut only holds behind another projection).
+    project -> pmap_register (threshold 0: the loop ends on its last iteration) -> project of a SMALLER cloud, compared
+    with a fresh context bit for bit — on a stale buffer old (range, ~index) keys win pixels and index past the cloud."""
+    from pylidar_slam_amd.engine import IcpContext
+    h, w = 32, 512
+    scans, _ = _scans(h, w, 3)
+    kw = dict(height=h, width=w, max_num_alignments=5, threshold_delta_pose=0.0, local_map_size=3)
+    ctx, fresh = IcpContext(**kw), IcpContext(**kw)
+    d0 = torch_cuda.from_numpy(scans[0]).cuda()
+    vm0 = ctx.project(d0)
+    ctx.pmap_init()
+    ctx.pmap_update(np.eye(4, dtype=np.float32), vm0)
+    ctx.pmap_register(torch_cuda.from_numpy(scans[1]).cuda(), None)
+    small = scans[2][::3].copy()  # fewer points than the frame whose keys stayed behind, and farther ranges win nothing
+    small *= 1.5
+    got, gi = ctx.project(small, with_index=True)
+    want, wi = fresh.project(small, with_index=True)
+    assert np.array_equal(got, want) and np.array_equal(gi, wi)
+    # the same through the plugin: projective local map fed with [N, 3] clouds projects on the registration's context
+    from pylidar_slam_amd.odometry import MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector
+    cfg = MI355XICPConfig(max_num_alignments=5, threshold_delta_pose=0.0, data_key="numpy_pc",
+                          local_map=dict(type="projective_local_map", local_map_size=3))
+    odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(h, w), device=torch_cuda.device("cuda:0"))
+    odo.init()
+    for s in scans:
+        odo.process_next_frame({"numpy_pc": s})
+        assert np.array_equal(odo._tgt_vmap.cpu().numpy(), fresh.project(s))
+
+
+def test_insertion_by_the_device_pose_waits_for_the_pending_result(torch_cuda):
+    """`icp_map_update(rel_pose = NULL, new cloud)` behind a registration whose status the host has not seen would evict /
+    insert even if that registration failed (the reference raises before it touches the map): refused while the result is
+    pending, accepted once it has been collected; the pose-only form stays available."""
+    from pylidar_slam_amd.engine import IcpContext
+    scans, _ = _scans(16, 256, 3)
+    ctx = IcpContext(height=16, width=256, max_num_alignments=4, threshold_delta_pose=0.0, local_map_size=2)
+    ctx.map_init()
+    ctx.map_update(np.eye(4, dtype=np.float32), scans[0])
+    ctx.register_launch(scans[1], None)
+    with pytest.raises(AssertionError):
+        ctx.map_update(None, scans[1])
+    assert ctx.map_num_clouds() == 1 and ctx.map_size() == scans[0].shape[0]
+    res = ctx.register_end()
+    ctx.map_update(None, scans[1])  # collected: the device pose is the pose the host holds
+    assert ctx.map_num_clouds() == 2
+    ref = IcpContext(height=16, width=256, max_num_alignments=4, threshold_delta_pose=0.0, local_map_size=2)
+    ref.map_init()
+    ref.map_update(np.eye(4, dtype=np.float32), scans[0])
+    ref.map_update(res.pose, scans[1])
+    np.testing.assert_array_equal(ctx.map_points(), ref.map_points())
