@@ -1,0 +1,127 @@
+"""Golden trajectory of the reference's PUBLISHED configuration on synthetic frames (stand-in for BASELINE.json
+configs[2], "KITTI seq 00 replay, full odometry loop, ATE vs reference": KITTI is not mounted anywhere this code runs).
+TEST INFRASTRUCTURE.  Run in the build container only:
+
+    python oracle/make_golden_loop.py            # writes tests/golden/loop_reference.npz (takes a few minutes)
+
+What runs: the reference's OWN `SLAM` loop (slam/slam.py:81-170, imported unmodified from /root/reference through
+oracle/shims) — `ConstantVelocityInitialization` -> `Preprocessing` [distortion (pass-through: no timestamps) ->
+grid_sample 0.4 m -> to_tensor sample_points -> input_data] -> `ICPFrameToModel` — with the options of the one command
+line the reference publishes timings for (docs/results/KITTI/kitti_benchmark.md:10,19, "CV+KdF2M", 174.8 ms per frame):
+
+    slam/odometry/local_map=kdtree  slam/odometry/initialization=CV  slam/odometry/alignment=point_to_plane_GN
+    slam.odometry.local_map.local_map_size=30  slam.odometry.max_num_alignments=20
+    slam.odometry.alignment.gauss_newton_config.scheme=neighborhood  ...sigma=0.2
+    slam/odometry/preprocessing=grid_sample  ...voxel_size=0.4  slam.odometry.data_key=input_data  device=cpu
+
+(threshold_delta_pose, threshold_trans / threshold_rot, num_neighbors_normals stay at the defaults of
+ICPFrameToModelConfig / KdTreeLocalMapConfig: 1e-4, 0.1 m / 0.3 deg, 10.)  36 seeded 64x2048 frames of the synthetic
+drive (pylidar_slam_amd.synthetic, 0.4 m and 0.01 rad per frame): the local map takes a new key frame on every frame
+and, from frame 30 on, evicts the oldest one (local_map.py:350-360).
+
+Stored: per-frame relative poses, iteration counts and final losses, the inserted-cloud sizes, the trajectory metrics of
+the reference's own slam/eval/eval_odometry.py (ATE / ARE on the relative poses; the KITTI segment error with segment
+lengths scaled to a 14 m drive: 2, 4, 6, 8 m) against the generator's ground truth, sha1 of every input scan, and the
+reference's wall-clock per frame in this container (context for the bench leg, not a baseline).
+"""
+import hashlib
+import logging
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle", "shims"), "/root/reference", os.path.join(ROOT, "pylidar-slam_amd")]
+logging.disable(logging.WARNING)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(1)  # the reference's z-buffer races under intra-op parallelism (oracle/make_golden.py)
+
+from omegaconf import OmegaConf  # noqa: E402
+import slam.eval.eval_odometry as E  # noqa: E402
+import slam.preprocessing as pp  # noqa: E402
+from slam.common.pointcloud import voxelise  # noqa: E402
+from slam.common.pose import Pose  # noqa: E402
+from slam.common.projection import SphericalProjector  # noqa: E402
+from slam.slam import SLAM, SLAMConfig  # noqa: E402
+
+from pylidar_slam_amd.synthetic import SceneConfig, make_sequence  # noqa: E402
+
+H, W, FRAMES = 64, 2048, 36
+SEGMENTS = [2.0, 4.0, 6.0, 8.0]
+OUT = os.path.join(ROOT, "tests", "golden", "loop_reference.npz")
+
+PUBLISHED = {
+    "initialization": {"type": "cv"},
+    "preprocessing": {"filters": {
+        "1": {"filter_name": "distortion", "force": False, "activate": True, "pointcloud_key": "numpy_pc",
+              "timestamps_key": "numpy_pc_timestamps", "output_key": "distorted"},
+        "2": {"filter_name": "grid_sample", "voxel_size": 0.4, "pointcloud_key": "distorted"},
+        "3": {"filter_name": "to_tensor", "keys": {"sample_points": "input_data"}}}},
+    "odometry": {"algorithm": "icp_F2M", "data_key": "input_data", "max_num_alignments": 20,
+                 "local_map": {"type": "kdtree_local_map", "local_map_size": 30},
+                 "alignment": {"mode": "point_to_plane_gauss_newton",
+                               "gauss_newton_config": {"scheme": "neighborhood", "sigma": 0.2, "max_iters": 1}}},
+    "loop_closure": None, "backend": None,
+}
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    # GridSample of the reference: numba types the f32 / f64 division as f64 (slam/common/pointcloud.py:73-75); under
+    # the pure-Python numba stub the harness feeds float64 copies (exact), as oracle/make_golden.py does
+    pp.voxelise = lambda pc, a, b, c: voxelise(pc.astype(np.float64), a, b, c)
+    scans, gt_abs = make_sequence(SceneConfig(height=H, width=W), FRAMES)
+    cfg = OmegaConf.create({"slam": PUBLISHED})
+    slam = SLAM(SLAMConfig(**cfg.slam), projector=SphericalProjector(H, W, 3, 3.0, -24.0), pose=Pose("euler"),
+                device=torch.device("cpu"), viz_num_pointclouds=1)
+    slam.init()
+    odo = slam.odometry
+    assert type(odo).__name__ == "ICPFrameToModel"
+
+    # iteration counts / losses per frame: wrap the registration (no change of behaviour)
+    trace = {"iters": [0], "loss": [0.0]}
+    inner = odo.register_new_frame
+
+    def traced(*a, **k):
+        params, pose, losses = inner(*a, **k)
+        trace["iters"].append(len(losses))
+        trace["loss"].append(float(losses[-1]))
+        return params, pose, losses
+
+    odo.register_new_frame = traced
+    seconds, samples, map_sizes = [], [], []
+    for f, scan in enumerate(scans):
+        d = {"numpy_pc": scan, "absolute_pose_gt": gt_abs[f]}
+        t0 = time.perf_counter()
+        slam.process_next_frame(d)
+        seconds.append(time.perf_counter() - t0)
+        samples.append(int(d["sample_points"].shape[0]))
+        map_sizes.append(int(odo.local_map._local_map.shape[0]) if odo.local_map._local_map is not None else 0)
+        print(f"frame {f:2d}: {seconds[-1]:6.2f} s, {samples[-1]} samples, map {map_sizes[-1]} points in "
+              f"{len(odo.local_map._local_map_num_elements)} clouds, iterations {trace['iters'][-1]}", flush=True)
+    rel = np.asarray(slam.get_relative_poses(), dtype=np.float64)
+    gt_rel = E.compute_relative_poses(gt_abs)
+    gt_rel[0] = np.eye(4)  # the trajectory expressed from its first frame, like the estimate
+    gt0 = E.compute_absolute_poses(gt_rel)
+    est_abs = E.compute_absolute_poses(rel)
+    ate, ate_std = E.compute_ate(rel, gt_rel)
+    are, are_std = E.compute_are(rel, gt_rel)
+    tr, rot, errors = E.compute_kitti_metrics(est_abs, gt0, SEGMENTS)
+    out = dict(hw=np.array([H, W]), scan_sha=np.array([sha(s) for s in scans]), gt_abs=gt_abs, rel=rel.astype(np.float32),
+               iters=np.array(trace["iters"]), loss=np.array(trace["loss"]), samples=np.array(samples),
+               map_sizes=np.array(map_sizes), ate=np.array([ate, ate_std]), are=np.array([are, are_std]),
+               kitti=np.array([tr, rot]), segments=np.array(SEGMENTS), num_segments=np.int64(len(errors)),
+               reference_seconds_per_frame=np.array(seconds), reference_threads=np.int64(torch.get_num_threads()))
+    np.savez_compressed(OUT, **out)
+    print(f"ATE {ate:.3e} +- {ate_std:.1e} m, ARE {are:.3e}, tr_err {tr:.3e} m/m, r_err {rot:.3e} rad/m over "
+          f"{len(errors)} segments; reference median {np.median(seconds[1:]) * 1e3:.0f} ms per frame (1 torch thread)")
+
+
+if __name__ == "__main__":
+    main()

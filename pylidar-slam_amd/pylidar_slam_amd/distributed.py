@@ -51,10 +51,11 @@ def sharded_register(engine, local_points, init_pose=None, iterations: Optional[
 
     `engine` is an `IcpContext` (or anything with the same five calls): register_begin / iteration_accumulate /
     normal_equations_tensor / iteration_solve / register_end.  `local_points` is this rank's slice of the scan.
-    With world size 1 (or torch.distributed not initialised) the loop degenerates to the single-GPU registration.
+    Without a process group the loop degenerates to the single-GPU registration (a group of one rank still all-reduces).
     """
     import torch.distributed as dist
-    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # (a process group of ONE rank still issues its collective: that is how the 1-GPU test box exercises RCCL)
+    use_dist = dist.is_available() and dist.is_initialized()
     if hasattr(engine, "use_torch_stream"):
         engine.use_torch_stream()  # accumulate / all-reduce / solve must share one stream: torch's current one
     neq = engine.normal_equations_tensor()
@@ -74,9 +75,9 @@ def sharded_map_normals(engine, group=None):
     over the ranks by original map index (16 B per map point: 16 MB for a 1M-point map, i.e. 2 MB per rank and ring
     step — bandwidth-bound on the ~153 GB/s xGMI links, ~0.1 ms), and every rank installs the full set into its own
     normal cache.  Every index has exactly one owner, so the sum is exact and all ranks end with identical normals.
-    With world size 1 (or torch.distributed not initialised) this is the eager single-GPU estimation."""
+    Without a process group (or with one rank) this is the eager single-GPU estimation."""
     import torch.distributed as dist
-    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    use_dist = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if use_dist else 0
     world = dist.get_world_size(group) if use_dist else 1
     shard = engine.map_normals_owned(rank, world)

@@ -718,6 +718,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self._tgt_vmap = None
         self._tgt_pc = None
         self._delta_since_map_update = np.eye(4, dtype=np.float32)
+        self._host_rows = None
+        self._pin_in = self._pin_in_free = self._pin_out = self._copy_stream = None
         self._register_threshold_trans = config.threshold_trans
         self._register_threshold_rot = config.threshold_rot
 
@@ -745,10 +747,13 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         data = data_dict[key]
         self._tgt_vmap = None
         self._tgt_pc = None
+        self._host_rows = None
         if isinstance(data, np.ndarray):
             assert_debug(data.ndim == 2 and data.shape[1] == 3, f"expected [N, 3], got {data.shape}")
             self._sample_pointcloud = True  # sticky (:330)
-            pc = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(self.device)
+            self._host_rows = data if data.dtype == np.float32 and data.flags.c_contiguous else \
+                np.ascontiguousarray(data, dtype=np.float32)
+            pc = self._upload(self._host_rows)
             vmap = self.ctx.project(pc)
         elif isinstance(data, torch.Tensor):
             if data.ndim in (3, 4):
@@ -787,6 +792,11 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         return res.params, res.pose, res.losses
 
     def do_process_next_frame(self, data_dict: dict):  # :157-246
+        """One frame.  Against the kd-tree style map the registration is only ENQUEUED (`icp_register_launch`): while the
+        GPU iterates, the host prepares the frame's `odometry_pc` (the host rows of a numpy frame, or an asynchronous
+        device -> pinned copy of a tensor frame started before the registration was enqueued), then blocks on the
+        registration alone (`icp_register_end`); the map update is enqueued from the pose without waiting for it, so it
+        overlaps the caller's preparation of the next frame."""
         self.ctx.use_torch_stream()
         self._read_input(data_dict)
         if self._iter == 0:
@@ -798,25 +808,85 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             return
         initial_estimate = self._initial_pose(data_dict)
         targets, skip_null = self.sample_points()
-        params, pose, _ = self.register_new_frame(targets, initial_estimate, skip_null=skip_null)
+        if self._projective:
+            params, pose, _ = self.register_new_frame(targets, initial_estimate, skip_null=skip_null)
+            tgt_np_pc = data_dict["distorted"] if "distorted" in data_dict else self._finish_rows(self._start_rows())
+        else:
+            rows_job = None if "distorted" in data_dict else self._start_rows()  # (a device frame: copy on a side stream)
+            self.ctx.register_launch(targets, initial_estimate, skip_null=skip_null)
+            tgt_np_pc = data_dict["distorted"] if rows_job is None else self._finish_rows(rows_job)  # GPU busy meanwhile
+            res = self.ctx.register_end()  # raises before the map is touched (:286)
+            self.last_result = res
+            params, pose = res.params, res.pose
         self.__update_map(pose)
         self.relative_poses.append(pose[None].copy())
         self.absolute_poses.append(self.absolute_poses[-1].dot(build_pose_matrix(params.astype(np.float64),
                                                                                  np.float64)))  # :200-202
-        if "distorted" in data_dict:
-            tgt_np_pc = data_dict["distorted"]
-        else:
-            tgt_np_pc = self._valid_rows(self._tgt_pc)
         data_dict[self.pointcloud_key()] = tgt_np_pc  # :243
         data_dict[self.relative_pose_key()] = pose.reshape(4, 4).copy()  # :244
         self._iter += 1
 
-    def _valid_rows(self, pc: torch.Tensor) -> np.ndarray:
-        a = pc.cpu().numpy().reshape(-1, 3)
-        keep = ~np.isnan(a).any(axis=1)
-        if self._pc_is_pixels:
-            keep &= np.abs(a).max(axis=1) > 0
-        return a if keep.all() else a[keep]
+    # ---- host <-> device traffic of a frame, kept off the critical path ----------------------------------------------
+    def _upload(self, rows: np.ndarray) -> torch.Tensor:
+        """[N,3] float32 host rows -> device tensor through a pinned staging buffer (a pageable source makes the
+        runtime stage and block; pinned, the copy is one asynchronous DMA behind the previous frame's map update)."""
+        n = int(rows.shape[0])
+        if self.device.type != "cuda":  # (tensor placement only — the host logic is exercised without a GPU in tests/)
+            return torch.from_numpy(rows).to(self.device)
+        if self._pin_in is None or self._pin_in.shape[0] < n:
+            self._pin_in = torch.empty((max(n, 1), 3), dtype=torch.float32, pin_memory=True)
+            self._pin_in_free = None
+        if self._pin_in_free is not None:
+            self._pin_in_free.synchronize()  # the previous upload has left the staging buffer (long done in practice)
+        stage = self._pin_in[:n]
+        stage.numpy()[...] = rows
+        dev = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        dev.copy_(stage, non_blocking=True)
+        self._pin_in_free = torch.cuda.Event()
+        self._pin_in_free.record(torch.cuda.current_stream(self.device))
+        return dev
+
+    def _start_rows(self):
+        """Begins producing `odometry_pc` = the frame's points as a host array (`self._tgt_pc.cpu().numpy()`, :213).
+        A numpy frame already is on the host; a tensor frame is copied device -> pinned memory on a side stream that
+        waits for what has been enqueued so far (the frame exists) and NOT for the registration enqueued next."""
+        if self._host_rows is not None:
+            return ("host", self._host_rows)
+        pc = self._tgt_pc
+        if not pc.is_cuda:
+            return ("host_pixels" if self._pc_is_pixels else "host", pc.numpy().reshape(-1, 3))
+        n = int(pc.shape[0])
+        if self._pin_out is None or self._pin_out.shape[0] < n:
+            self._pin_out = torch.empty((max(n, 1), 3), dtype=torch.float32, pin_memory=True)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        side = self._copy_stream
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            self._pin_out[:n].copy_(pc, non_blocking=True)
+            done.record(side)
+        return ("device", done, n)
+
+    def _finish_rows(self, job) -> np.ndarray:
+        if job[0] == "host":
+            a = job[1]
+            if not np.isnan(a).any():
+                return a.copy()  # a fresh array per frame, like the reference's (:213)
+            return a[~np.isnan(a).any(axis=1)]
+        if job[0] == "host_pixels":
+            a = job[1]
+        else:
+            _, done, n = job
+            done.synchronize()
+            a = self._pin_out[:n].numpy()
+        keep = None
+        if np.isnan(a).any():
+            keep = ~np.isnan(a).any(axis=1)
+        if self._pc_is_pixels:  # vertex-map input: `_tgt_pc` = the non-null pixels (:342-344)
+            nz = np.abs(a).max(axis=1) > 0
+            keep = nz if keep is None else keep & nz
+        return a.copy() if keep is None or keep.all() else a[keep]
 
     def __update_map(self, new_rpose: np.ndarray):  # :360-380
         new_delta = (self._delta_since_map_update @ new_rpose).astype(np.float32)

@@ -95,3 +95,13 @@ class OracleContext:
         params, pose = self.reg.register_new_frame(pts, init)
         tr = self.reg.traces[-1]
         return RegisterResult(pose, params, len(tr.dx), False, pts.shape[0], 0, np.array(tr.loss), np.array(tr.dx))
+
+    # the asynchronous hand-off of the plugin's frame loop: here the "launch" just remembers its arguments
+    def register_launch(self, points, init_pose=None, skip_null=False):
+        assert getattr(self, "_pending", None) is None, "collect the pending result first"
+        self._pending = (points, init_pose, skip_null)
+
+    def register_end(self):
+        points, init_pose, skip_null = self._pending
+        self._pending = None
+        return self.register(points, init_pose, skip_null)

@@ -1,0 +1,77 @@
+"""`-m gpu`: the reference's published configuration as a full odometry loop on the MI355X (SURVEY §8 row f3 / BASELINE
+configs[2] stand-in), against `tests/golden/loop_reference.npz` — the trajectory of the reference's own `SLAM` loop on
+the same 36 seeded 64x2048 frames (oracle/make_golden_loop.py).  Every frame within 1e-4 m / 1e-4 rad of the reference's,
+the same ATE / ARE / segment errors through `pylidar_slam_amd.eval`, the sliding window (insertions, evictions) of the
+same sizes — with the reference's host preprocessing order (numpy grid sample -> tensor) and with the device-resident
+filters of config/slam/preprocessing/grid_sample_mi355x.yaml."""
+import numpy as np
+import pytest
+
+from test_loop_reference import golden_loop, loop_scans, published_config, trajectory_metrics  # noqa: F401 (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists for the product path)")
+    return torch
+
+
+def _filters(kind, dev):
+    from pylidar_slam_amd import odometry as our
+    if kind == "host":  # config/slam/preprocessing/grid_sample.yaml of the reference, with our GridSample
+        return [our.Distortion(our.DistortionConfig(output_key="distorted")),
+                our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted")),
+                our.ToTensor(our.ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}), device=dev)]
+    return [our.ToDevice(our.ToDeviceConfig(device=str(dev)), device=dev),
+            our.Distortion(our.DistortionConfig(pointcloud_key="pc_device", timestamps_key="timestamps_device",
+                                                output_key="distorted")),
+            our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted")),
+            our.ToTensor(our.ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}, dtype="float32"),
+                         device=dev)]
+
+
+@pytest.mark.parametrize("preprocessing", ["host", "device"])
+def test_published_configuration_loop_matches_the_reference_run(torch_cuda, golden_loop, loop_scans, preprocessing):
+    import icp_oracle as O
+    from pylidar_slam_amd import odometry as our
+    torch = torch_cuda
+    g = golden_loop
+    scans, gt_abs = loop_scans
+    dev = torch.device("cuda:0")
+    odo = our.MI355XICPFrameToModel(published_config(), projector=our.SphericalProjector(64, 2048), device=dev)
+    filters = _filters(preprocessing, dev)
+    init = our.ConstantVelocityInitialization()
+    odo.init()
+    init.init()
+    worst, iters_off = (0.0, 0.0), 0
+    for f, scan in enumerate(scans):
+        d = {"numpy_pc": scan}
+        init.next_frame(d)  # slam/slam.py:126-127
+        for flt in filters:
+            flt.filter(d)   # :129-130
+        assert int(d["sample_points"].shape[0]) == int(g["samples"][f])  # grid sampling is index-exact
+        odo.process_next_frame(d)
+        if f == 0:
+            assert "odometry_pose" not in d
+            continue
+        init.save_real_motion(d["odometry_pose"], d)  # :139-140
+        dt, dr = O.pose_error(d["odometry_pose"], g["rel"][f])
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        assert dt < 1e-4 and dr < 1e-4, (preprocessing, f, dt, dr)
+        iters_off += int(odo.last_result.iterations != int(g["iters"][f]))
+        assert abs(odo.ctx.map_size() - int(g["map_sizes"][f])) <= 2, (f, odo.ctx.map_size(), int(g["map_sizes"][f]))
+        assert d["odometry_pc"].shape == (int(g["samples"][f]), 3)
+    assert odo.ctx.map_num_clouds() == 30  # six evictions happened
+    rel = odo.get_relative_poses()
+    ate, are, tr, rot, n = trajectory_metrics(rel, gt_abs, g["segments"])
+    assert n == int(g["num_segments"])
+    print(f"loop ({preprocessing} preprocessing): worst frame {worst[0]:.1e} m / {worst[1]:.1e} rad vs the reference; ATE "
+          f"{ate:.4e} (reference {g['ate'][0]:.4e}) m, tr_err {tr:.4e} ({g['kitti'][0]:.4e}) m/m, r_err {rot:.4e} "
+          f"({g['kitti'][1]:.4e}) rad/m; frames with another iteration count: {iters_off}")
+    assert abs(ate - g["ate"][0]) < 2e-5 and abs(are - g["are"][0]) < 2e-5
+    assert abs(tr - g["kitti"][0]) < 2e-5 and abs(rot - g["kitti"][1]) < 2e-5
+    assert iters_off <= 2  # a stop decided by |dx| within float32 noise of the 1e-4 threshold may move by one iteration

@@ -120,27 +120,32 @@ def test_c4_size_map_sharded_registration_vs_oracle(torch_cuda, O):
 
 
 # ---- world size 2 on one GPU (gloo) ----------------------------------------------------------------------------------
-def _rank_main(rank, world, port, out):
+def _rank_main(rank, world, port, out, backend="gloo"):
     for p in (os.path.join(ROOT, "pylidar-slam_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = rank if backend == "nccl" else 0  # nccl (= RCCL): one GPU per rank; gloo: the ranks share GPU 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from pylidar_slam_amd.distributed import shard_bounds, sharded_map_normals, sharded_register
     from pylidar_slam_amd.engine import IcpContext
     model, scan = _small_problem()
     ctx = IcpContext(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure",
-                     sigma=0.3)
+                     sigma=0.3, device=device)
     ctx.map_set(torch.from_numpy(model).cuda())
     shard = sharded_map_normals(ctx)  # owner-computed normals, all-reduced by original index
     b, e = shard_bounds(scan.shape[0], world, rank)
     res = sharded_register(ctx, torch.from_numpy(scan[b:e]).cuda(), None, 10)
-    poses = [torch.zeros(16) for _ in range(world)]
-    dist.all_gather(poses, torch.from_numpy(res.pose.reshape(-1).copy()))
+    where = "cuda" if backend == "nccl" else "cpu"  # (RCCL moves device tensors only)
+    poses = [torch.zeros(16, device=where) for _ in range(world)]
+    dist.all_gather(poses, torch.from_numpy(res.pose.reshape(-1).copy()).to(where))
     if rank == 0:
-        np.savez(out, pose=res.pose, losses=res.losses, dx=res.dx, all=np.stack([p.numpy() for p in poses]),
+        np.savez(out, pose=res.pose, losses=res.losses, dx=res.dx, all=np.stack([p.cpu().numpy() for p in poses]),
                  owned_everywhere=float(shard[:, 3].min()), targets=res.num_targets)
     dist.barrier()
     dist.destroy_process_group()
@@ -170,6 +175,52 @@ def test_hip_engine_world_size_2_on_one_gpu(torch_cuda, tmp_path):
     np.testing.assert_allclose(got["pose"], ref.pose, atol=1e-6)
     np.testing.assert_allclose(got["losses"], ref.losses, rtol=1e-9)
     np.testing.assert_allclose(got["dx"], ref.dx, atol=1e-7)
+
+
+def _check_against_single_process(got, bitwise):
+    model, scan = _small_problem()
+    single = _ctx(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                  sigma=0.3)
+    single.map_set(model)
+    ref = single.register(scan)
+    assert float(got["owned_everywhere"]) == 1.0 and int(got["targets"]) > 0
+    assert len(got["losses"]) == ref.iterations == 10
+    if bitwise:
+        assert np.array_equal(got["pose"], ref.pose) and np.array_equal(got["losses"], ref.losses)
+    else:
+        np.testing.assert_allclose(got["pose"], ref.pose, atol=1e-6)
+        np.testing.assert_allclose(got["losses"], ref.losses, rtol=1e-9)
+        np.testing.assert_allclose(got["dx"], ref.dx, atol=1e-7)
+
+
+def test_rccl_is_loaded_and_called_world_size_1(torch_cuda, tmp_path):
+    """The `nccl` backend (RCCL on ROCm) on the one GPU of the test box: a process group of one rank, through which
+    `sharded_map_normals` (one all-reduce of [M,4] floats) and `sharded_register` (an all-reduce of the 32 doubles per
+    ICP iteration, between icp_iteration_accumulate and icp_iteration_solve on torch's stream) really issue their
+    collectives.  A one-rank sum changes no bit: the result equals the plain single-process registration exactly."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    mp.start_processes(_rank_main, args=(1, port, out, "nccl"), nprocs=1, join=True, start_method="spawn")
+    _check_against_single_process(np.load(out), bitwise=True)
+
+
+def test_rccl_scan_sharded_registration_on_two_gpus(torch_cuda, tmp_path):
+    """Two ranks on two GPUs over RCCL / xGMI — runs wherever the box has at least two devices (the single-GPU test box
+    skips it): same bits on both ranks, the single-process result up to the association of the float64 sums."""
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    mp.start_processes(_rank_main, args=(2, port, out, "nccl"), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    assert np.array_equal(got["all"][0], got["all"][1])
+    _check_against_single_process(got, bitwise=False)
 
 
 # ---- in-library exchange (peer-written inboxes instead of a collective) ---------------------------------------------
