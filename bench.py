@@ -132,6 +132,8 @@ def parse():
                          "200k-point scan against a 1M-point map with map-sharded normals — timed on its own (one GPU: "
                          "the single-device figure; N GPUs: scan- and map-sharded) and printed as the line's value with "
                          "`config.workload` saying so")
+    ap.add_argument("--leg", choices=["plugin", "odometry_loop"], default=None,
+                    help="developer switch (profiling): run ONLY that leg and print its object")
     ap.add_argument("--plugin-steps", type=int, default=60,
                     help="timed frames of the plugin leg (the workload through MI355XICPFrameToModel.process_next_frame "
                          "from host numpy arrays; 0: skip)")
@@ -735,6 +737,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.leg == "odometry_loop":
+        print(json.dumps({"odometry_loop": odometry_loop_leg(args, local_rank)}))
+        return
+    if args.leg == "plugin":
+        tr = Tracker(args, 0, args.trajectory, args.warmup + args.steps, local_rank)
+        print(json.dumps({"plugin": plugin_leg(args, tr, local_rank, args.plugin_steps, max(3, args.warmup))}))
+        return
     if args.workload == "c4":
         c4 = c4_leg(args, dist, rank, world, local_rank, dev, steps=max(2, min(args.steps, 20)), warmup=min(args.warmup, 3))
         if rank == 0:

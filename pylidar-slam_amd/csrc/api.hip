@@ -638,7 +638,13 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
     }
     if (inserted_out) *inserted_out = inserted;
     if ((rc = stash_frame_seeds(ctx, evicted, true))) return rc;  // kept points keep their order: index - evicted
-    return build_grid(ctx);
+    if ((rc = build_grid(ctx))) return rc;
+    // the next registration will want every normal at once (same rule as register_begin, with the size of the scan just
+    // registered standing in for the next one): estimate them NOW, behind the rebuild, so that the GPU works through the
+    // caller's preparation of the next frame (host staging, upload) instead of starting on them when that frame arrives
+    if (ctx->cost == ICP_COST_POINT_TO_PLANE && ctx->have_device_pose && ctx->tgt_n > 0 && ctx->map_m <= 2 * ctx->tgt_n)
+        rc = launch_normals_all(ctx);
+    return rc;
 }
 
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,

