@@ -70,9 +70,10 @@ static void prof_collect(icp_ctx* ctx) {
 }
 
 // ---- small kernels owned by the API layer ---------------------------------------------------------------------------
-__global__ void k_state_init(RegState* st, Pose16 init, int keep_pose) {
+__global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned long long* box, unsigned gen) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     state_init(st, init.m, keep_pose);
+    if (box) box_publish_serial(box, gen, st->pose, 0, 0);  // generation `gen` of the pose mailbox: the initial guess
 }
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
@@ -178,6 +179,11 @@ static int ensure_state(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->neq_own.reserve(NEQ * sizeof(double)));
     if (!ctx->neq) ctx->neq = ctx->neq_own.as<double>();
     ICP_HIP(ctx, ctx->counter.reserve(64));
+    if (!ctx->posebox.ptr) {  // pose mailbox (2 parities) + ticket counter of the lead launches
+        ICP_HIP(ctx, ctx->posebox.reserve(BOX_BYTES));
+        ICP_HIP(ctx, hipMemsetAsync(ctx->posebox.ptr, 0, ctx->posebox.bytes, ctx->stream));
+        ctx->box_gen = 0;
+    }
     return ICP_OK;
 }
 
@@ -196,14 +202,16 @@ static Pose16 pose_or_identity(const float* init_pose) {
 static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_pose, bool keep_pose = false) {
     const Pose16 p = pose_or_identity(init_pose);
     if (n > 0) return prepare_targets(ctx, ctx->tgt_ptr, n, &p, keep_pose);
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0,
+                       pose_box(ctx), next_box_generation(ctx));
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
 static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = false) {
     const Pose16 p = pose_or_identity(init_pose);
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0,
+                       pose_box(ctx), next_box_generation(ctx));
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -322,6 +330,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
     else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
+    else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
         ctx->search_stats = (int)iv;  // 1: path counters + phase stamps, 2: stamps only (no atomics)
@@ -1305,6 +1314,8 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
             ICP_HIP(ctx, hipMemcpy(dx_per_iter_out, ctx->dx_hist, (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
     }
     if (ctx->prof.enabled) prof_collect(ctx);
+    if (st.handoff_timeouts > 0)
+        return fail(ctx, ICP_ERR_HIP, "internal: the pose hand-off inside a fused iteration launch timed out");
     if (st.status == ICP_ERR_INVALID_JACOBIAN)
         return fail(ctx, ICP_ERR_INVALID_JACOBIAN, "Invalid Jacobian in Gauss Newton minimization");
     if (st.status == ICP_ERR_EXCHANGE) {
@@ -1322,8 +1333,27 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
     const int iters = ctx->cfg.max_num_alignments;
     // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
     const int poll = (poll_allowed && ctx->cfg.threshold_delta_pose > 0.f) ? ctx->cfg.poll_every : 0;
+    // lead launches: the solve of iteration k rides in the head of launch k + 1 (LeadArgs, icp_internal.h); one summing /
+    // solving launch remains, behind the last iteration.  Not with the host polling in between (it reads the RegState,
+    // which would lag one iteration) and not with the in-library exchange (its solve waits for the peers)
+    const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0;
+    int prev_rows = 0, prev_quad = 1;  // rows a lead launch still has to solve
     for (int it = 0; it < iters; ++it) {
-        if (fused_path(ctx)) {
+        if (lead) {
+            // every launch takes its pose from the mailbox; the NARROW ones (late iterations: one workgroup more fits beside
+            // the others) also solve the iteration before them, the others follow a summing / solving launch as before
+            int rows = 0, quad = 1;
+            rc = launch_iterate_fused(ctx, &rows, &quad, true, prev_rows, prev_quad);
+            prev_rows = rows;
+            prev_quad = quad;
+            if (!rc && (it + 1 == iters || !next_fused_launch_is_narrow(ctx))) {
+                // the rows of this launch: the parity it has just written
+                rc = launch_sum_solve(ctx, rows, quad, (const double*)(ctx->partials.as<char>() +
+                                                                       (size_t)(ctx->partials_parity ^ 1) * ctx->partials_half),
+                                      true);
+                prev_rows = 0;
+            }
+        } else if (fused_path(ctx)) {
             int rows = 0, quad = 1;
             rc = launch_iterate_fused(ctx, &rows, &quad);
             if (!rc) rc = launch_sum_solve(ctx, rows, quad);

@@ -255,57 +255,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_procrustes_cov(const float* __r
     block_store_partial(acc, partials + (size_t)blockIdx.x * NEQ);
 }
 
-// fixed-order sum of the partial rows -> out[NEQ] (1024 threads: 32 row groups x 32 columns; the order of the additions
-// depends only on the geometry, never on timing).  Canonical order: four consecutive BASE rows form a super-row
-// (r0 + r1) + (r2 + r3) (rows past the end count as 0.0); the super-rows are added in the strided 8-accumulator pattern
-// below.  `quad` = 1: `partials` holds base rows (grouped here); 0: the producer already wrote super-rows (the
-// 512-queries-per-block shape of the fused iteration kernel: a quarter of the bytes for this single workgroup to load).
-__device__ inline double load_super_row(const double* __restrict__ partials, int nrows, int quad, int sr, int col) {
-    if (!quad) return partials[(size_t)sr * NEQ + col];
-    const int b = 4 * sr;
-    const double r0 = partials[(size_t)b * NEQ + col];
-    const double r1 = b + 1 < nrows ? partials[(size_t)(b + 1) * NEQ + col] : 0.0;
-    const double r2 = b + 2 < nrows ? partials[(size_t)(b + 2) * NEQ + col] : 0.0;
-    const double r3 = b + 3 < nrows ? partials[(size_t)(b + 3) * NEQ + col] : 0.0;
-    return (r0 + r1) + (r2 + r3);
-}
-
-__device__ inline void sum_partials_block(const double* __restrict__ partials, int nrows, int quad,
-                                          double* out /* LDS or global */) {
-    __shared__ double lds[32][NEQ];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int ns = quad ? (nrows + 3) / 4 : nrows;  // super-rows
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-    int b = grp;
-    for (; b + 224 < ns; b += 256) {  // eight independent super-rows (8 or 32 loads) in flight
-        const double v0 = load_super_row(partials, nrows, quad, b, col);
-        const double v1 = load_super_row(partials, nrows, quad, b + 32, col);
-        const double v2 = load_super_row(partials, nrows, quad, b + 64, col);
-        const double v3 = load_super_row(partials, nrows, quad, b + 96, col);
-        const double v4 = load_super_row(partials, nrows, quad, b + 128, col);
-        const double v5 = load_super_row(partials, nrows, quad, b + 160, col);
-        const double v6 = load_super_row(partials, nrows, quad, b + 192, col);
-        const double v7 = load_super_row(partials, nrows, quad, b + 224, col);
-        s0 += v0;
-        s1 += v1;
-        s2 += v2;
-        s3 += v3;
-        s4 += v4;
-        s5 += v5;
-        s6 += v6;
-        s7 += v7;
-    }
-    for (; b < ns; b += 32) s0 += load_super_row(partials, nrows, quad, b, col);
-    lds[grp][col] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-    __syncthreads();
-    if (threadIdx.x < NEQ) {
-        double t = 0.0;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) t += lds[g][threadIdx.x];
-        out[threadIdx.x] = t;
-    }
-}
-
+// (the fixed-order sum of the partial rows — `sum_partials_block` — lives in solve_device.h: the lead workgroup of the
+// fused iteration launch runs it too)
 __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partials, int nblocks, int quad,
                                                        const RegState* __restrict__ st, int check_done,
                                                        double* __restrict__ neq) {
@@ -331,7 +282,8 @@ __global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const d
 __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks, int quad,
                                                     RegState* __restrict__ st, AlignParams ap,
                                                     double* __restrict__ neq, double* __restrict__ loss_hist,
-                                                    float* __restrict__ dx_hist, int hist_cap) {
+                                                    float* __restrict__ dx_hist, int hist_cap,
+                                                    unsigned long long* __restrict__ box, unsigned gen) {
     // the state words are requested first and consumed last: their latency hides behind the partial-row loads
     const int done = st->done;
     int it = 0;
@@ -346,9 +298,16 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
     __shared__ double total[NEQ];
     sum_partials_block(partials, nblocks, quad, total);
     __syncthreads();
-    if (done) return;
+    if (done) {
+        // (box: the next fused launch takes its pose — and the news that the loop is over — from the mailbox)
+        if (box && threadIdx.x < BOX_USED) {
+            const int k = threadIdx.x;
+            box_store(box, gen, k, k < 12 ? __float_as_uint(st->pose[k]) : (k == 12 ? 1u : (unsigned)st->iter));
+        }
+        return;
+    }
     if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
-    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in);
+    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in, box, gen);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -486,17 +445,19 @@ int launch_reduce(icp_ctx* ctx) {
 }
 
 // final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
-int launch_sum_solve(icp_ctx* ctx, int blocks, int quad) {
+int launch_sum_solve(icp_ctx* ctx, int blocks, int quad, const double* partials, bool publish) {
+    if (!partials) partials = ctx->partials.as<double>();
     if (ctx->exchange_on) {
         ExchangeView x = ctx->xview;
         x.timeout_ticks = (long long)(ctx->exchange_timeout_ms * 1.0e5);  // 100 MHz
-        hipLaunchKernelGGL(k_sum_exchange_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(),
+        hipLaunchKernelGGL(k_sum_exchange_solve, dim3(1), dim3(1024), 0, ctx->stream, partials,
                            blocks, quad, reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist,
                            ctx->dx_hist, ctx->hist_cap, x);
     } else {
-        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, quad,
+        hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, partials, blocks, quad,
                            reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
-                           ctx->hist_cap);
+                           ctx->hist_cap, publish ? pose_box(ctx) : (unsigned long long*)nullptr,
+                           publish ? next_box_generation(ctx) : 0u);
     }
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;

@@ -88,11 +88,64 @@ struct RegState {
     int n_worklist;  // map points queued for normal estimation in the current iteration
     long long normals_computed;
     int grid_cells;  // occupied fine cells of the last grid build (feeds the cell-size auto-tuning; rides home with the result)
+    int handoff_timeouts;  // workgroups that gave up waiting for the pose of the lead workgroup (never seen; -> ICP_ERR_HIP)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pose mailbox of the fused iteration launches ("lead solve").  The 6x6 solve of iteration k does not get a launch of
+// its own: workgroup 0 of launch k + 1 (the first one the hardware dispatches) sums the partial rows launch k left, solves,
+// updates the RegState and publishes the new pose here, while the other workgroups — which already have their targets,
+// cache entries, cached neighbours and normals in flight — poll for it.  A generation of the pose is 14 granules of 8
+// bytes, (tag << 32) | payload, each written and read by ONE sc1 (agent-scope, relaxed) access, so no fence orders
+// anything: a reader takes a granule when its tag is the generation it waits for.  Two parities: generation g lives in
+// parity g & 1, generation g - 1 (the pose the NN-cache bounds refer to) stays readable in the other one.
+//   granule 0..11: rows 0-2 of the 4x4 pose; 12: done (the loop is finished: the launch has nothing to do); 13: iteration
+// ---------------------------------------------------------------------------------------------------------------------
+// Every generation is written into BOX_REPLICAS copies, each on a cache line of its own; workgroup b polls copy
+// b % BOX_REPLICAS: a thousand workgroups polling ONE line queue up behind one memory channel.
+static constexpr int BOX_WORDS = 16;
+static constexpr int BOX_USED = 14;
+static constexpr int BOX_REPLICAS = 16;
+static constexpr size_t BOX_BYTES = (size_t)2 * BOX_REPLICAS * BOX_WORDS * sizeof(unsigned long long);
+
+__device__ inline const unsigned long long* box_granule(const unsigned long long* box, unsigned gen, int replica, int k) {
+    return box + ((size_t)(gen & 1u) * BOX_REPLICAS + (size_t)replica) * BOX_WORDS + k;
+}
+
+__device__ inline void box_store(unsigned long long* __restrict__ box, unsigned gen, int k, unsigned bits) {
+    const unsigned long long v = ((unsigned long long)gen << 32) | bits;
+#pragma unroll
+    for (int r = 0; r < BOX_REPLICAS; ++r)
+        __hip_atomic_store(const_cast<unsigned long long*>(box_granule(box, gen, r, k)), v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// published by ONE thread (the state-initialising thread of a registration)
+__device__ inline void box_publish_serial(unsigned long long* __restrict__ box, unsigned gen, const float* pose, int done,
+                                          int iter) {
+    for (int k = 0; k < 12; ++k) box_store(box, gen, k, __float_as_uint(pose[k]));
+    box_store(box, gen, 12, (unsigned)done);
+    box_store(box, gen, 13, (unsigned)iter);
+}
+
+// what a fused iteration launch needs to know about the hand-off (box == nullptr: classic launch, pose from the RegState)
+struct LeadArgs {
+    unsigned long long* box = nullptr;
+    unsigned gen = 0;                // generation of the pose this launch consumes
+    int solve = 0;                   // 1: a lead workgroup (grid + 1) solves the previous iteration first and publishes `gen`
+    const double* prev_partials = nullptr;
+    int prev_rows = 0, prev_quad = 0;
+    double* neq = nullptr;
+    double* loss_hist = nullptr;
+    float* dx_hist = nullptr;
+    int hist_cap = 0;
+    long long timeout_ticks = 0;     // 100 MHz wall clock
 };
 
 // keep_pose: the initial guess is the pose the state already holds — the result of the previous registration, i.e. the
 // constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip
 __device__ inline void state_init(RegState* st, const float* init, int keep_pose) {
+    st->handoff_timeouts = 0;
     for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = keep_pose ? st->pose[k] : init[k];
     for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
     st->iter = 0;
@@ -237,7 +290,12 @@ struct icp_ctx {
     uint64_t cache_gen = 0;
     icp::DeviceBuffer seed_orig;       // int[N]: original map index of the neighbour each scan slot had in the last frame
     int64_t seed_n = 0;                // valid entries of seed_orig (0: none)
-    icp::DeviceBuffer partials;        // double[blocks][NEQ]
+    icp::DeviceBuffer partials;        // double[2][blocks][NEQ]: two parities (a lead launch sums the rows of the previous launch while its own workgroups write theirs)
+    size_t partials_half = 0;          // bytes of one parity
+    int partials_parity = 0;           // parity the NEXT fused launch writes
+    icp::DeviceBuffer posebox;         // pose mailbox of the lead launches (BOX_BYTES)
+    unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
+    int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
     // per-iteration histories live behind the RegState in the same allocation (one D2H copy brings back everything):
@@ -325,10 +383,16 @@ int run_seed_job(icp_ctx* ctx);
 AlignParams make_align_params(const icp_ctx* ctx);
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
-int launch_sum_solve(icp_ctx* ctx, int rows, int quad = 1);  // (with an exchange connected: + the all-reduce over the ranks)
+int launch_sum_solve(icp_ctx* ctx, int rows, int quad = 1, const double* partials = nullptr, bool publish = false);  // (with an exchange connected: + the all-reduce over the ranks; partials: ctx->partials unless given)
 int launch_sum_partials(icp_ctx* ctx, int rows, int quad = 1);
 // fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
-int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out);  // rows written; quad: base rows (1) or super-rows (0)
+// rows written; quad: base rows (1) or super-rows (0).  lead: the launch takes its pose from the mailbox; with prev_rows > 0
+// its lead workgroup first solves the equations the previous fused launch left (prev_rows / prev_quad rows of the other
+// parity of ctx->partials)
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead = false, int prev_rows = 0, int prev_quad = 1);
+unsigned long long* pose_box(icp_ctx* ctx);   // device pointer of the mailbox (allocated by ensure_state)
+unsigned next_box_generation(icp_ctx* ctx);    // a new generation number for a pose about to be published
+bool next_fused_launch_is_narrow(const icp_ctx* ctx);  // the shape launch_iterate_fused will pick for the next iteration
 int launch_reduce_solve(icp_ctx* ctx);  // single-GPU path: reduction, final sum and solve without the exchange seam
 int launch_align_given(icp_ctx* ctx, const float* ref, const float* tgt, const float* nrm, int64_t n,
                        float* residuals_dev);

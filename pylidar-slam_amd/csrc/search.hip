@@ -12,6 +12,7 @@
 #include "gn_device.h"
 #include "icp_internal.h"
 #include "search_device.h"
+#include "solve_device.h"
 
 namespace icp {
 
@@ -444,7 +445,8 @@ static constexpr int IT_QUERIES = IT_THREADS / 4;
 // -> super-row (r0 + r1) + (r2 + r3); super-rows in the strided 8-accumulator pattern.  A block of 128 queries (Q = 128)
 // writes its base row, a block of 512 queries its super-row: a quarter of the rows for the summing kernel, same bits.
 template <int Q>
-__device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials) {
+__device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
+                                         int block) {
     constexpr int SUB = Q / IT_QUERIES;  // base rows per block
     if ((int)threadIdx.x < SUB * 4 * NEQ) {
         const int e = threadIdx.x & (NEQ - 1), qtr = (threadIdx.x / NEQ) & 3, sb = threadIdx.x / (4 * NEQ);
@@ -467,7 +469,7 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
             r[sb] = (part[4 * sb][e] + part[4 * sb + 1][e]) + (part[4 * sb + 2][e] + part[4 * sb + 3][e]);
         double v = r[0];
         if (SUB == 4) v = (r[0] + r[1]) + (r[2] + r[3]);
-        partials[(size_t)blockIdx.x * NEQ + e] = v;
+        partials[(size_t)block * NEQ + e] = v;
     }
 }
 
@@ -510,78 +512,186 @@ struct IterInputs {
 //       quarters of the waves of the other shape would only be launched to wait at the barriers — and a quarter of the
 //       partial rows for the single workgroup that sums them).
 // Same bits either way (block_reduce_rows).
+// The LEAD workgroup of a lead launch (LeadArgs, icp_internal.h; one workgroup more than the queries need): fixed-order
+// sum of the partial rows the PREVIOUS launch left, 6x6 solve, pose update, RegState — what k_sum_solve does in a launch
+// of its own — and the new pose into the mailbox, for the workgroups of this launch that poll for it.  A separate
+// workgroup on a path of its own (it returns before the iteration proper): folded into workgroup 0's regular work the
+// f64 Cholesky set the register allocation of everybody's main path (69 spilled VGPRs instead of 37 in the 64-register
+// shape, every launch 20 % slower), and as a non-inlined call it was itself three times slower (both measured).
+// `scratch` = LDS the iteration does not use yet.
+template <int THREADS>
+__device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ st, AlignParams ap, double* scratch) {
+    double(*lds)[NEQ] = reinterpret_cast<double(*)[NEQ]>(scratch);
+    double* total = scratch + 32 * NEQ;
+    const int done = st->done;  // block-uniform
+    int it = 0;
+    float pose_in[16], params_in[6];
+    if (threadIdx.x < 64) {  // the solving wave (uniform addresses: one transaction)
+        it = st->iter;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
+    }
+    if (done) {  // the loop ended earlier: this launch has nothing to do, and its workgroups must hear it
+        if (threadIdx.x < BOX_USED) {
+            const int k = threadIdx.x;
+            box_store(lead.box, lead.gen, k,
+                      k < 12 ? __float_as_uint(st->pose[k]) : (k == 12 ? 1u : (unsigned)st->iter));
+        }
+        return;
+    }
+    sum_partials_vt<THREADS>(lead.prev_partials, lead.prev_rows, lead.prev_quad, total, lds);
+    __syncthreads();
+    if (threadIdx.x < NEQ) lead.neq[threadIdx.x] = total[threadIdx.x];
+    if (threadIdx.x < 64)
+        solve_and_update(st, total, ap, lead.loss_hist, lead.dx_hist, lead.hist_cap, it, pose_in, params_in, lead.box,
+                         lead.gen);
+}
+
 template <int MINW, int THREADS, int Q>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
-                                                                   RegState* __restrict__ st, AlignParams ap) {
+                                                                   RegState* __restrict__ st, AlignParams ap,
+                                                                   LeadArgs lead) {
     __shared__ float rowbuf[Q][9];
     __shared__ double part[Q / 32][NEQ];
     __shared__ int2 cellstack[7][THREADS];
     __shared__ float4 miss_p[Q];   // transformed target + bits(query slot)
     __shared__ int4 miss_seed[Q];  // bits(seed d2), seed index, seed position
     __shared__ int nmiss;
-    if (st->done) return;  // block-uniform
-    // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
-    // counters
-    long long* stamps = nullptr;
-    if (g.stamps && gridDim.x <= 1024 && st->iter < 24)
-        stamps = g.stamps + 4 * ((size_t)st->iter * 1024 + blockIdx.x);
-    if (threadIdx.x == 0) {
-        nmiss = 0;
-        if (stamps) stamps[0] = wall_clock64();
+    __shared__ float pose_s[12], prev_s[12];  // rows 0-2 of the pose of this iteration and of the previous one
+    __shared__ int ctl_s[4];                  // logical block | done | iteration | hand-off failures
+    static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ) * sizeof(double), "the lead's scratch lives in the cell stacks");
+    // In a lead launch (LeadArgs) workgroup 0 is the lead: it solves the previous iteration and publishes the pose the
+    // others poll for.  The hardware dispatches workgroups in ascending order, so whoever polls, polls for a workgroup
+    // placed before it (a role ticket drawn from a counter would make that independent of the dispatch order — and costs
+    // a thousand same-address device-scope atomics per launch, ~10 us: measured); should the order ever differ, the
+    // wall-clock bound of the poll turns the wait into ICP_ERR_HIP instead of a hang.
+    const int vb = (int)blockIdx.x - (lead.box ? lead.solve : 0);  // logical workgroup: which queries, which partial row
+    if (lead.box) {
+        if (vb < 0) {  // block-uniform
+            lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]));
+            return;
+        }
+    } else if (st->done) {
+        return;  // classic launch behind the end of the loop (block-uniform)
     }
-    __syncthreads();
-    const int q0 = blockIdx.x * Q;
-    // ---- phase A: one lane per query
-    if ((int)threadIdx.x < Q) {
-        const int lq = threadIdx.x, qi = q0 + lq;
-        float row[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) row[k] = 0.f;
-        bool valid = qi < in.n;
-        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long t_entry = g.stamps ? wall_clock64() : 0;
+    const int q0 = vb * Q;
+    // ---- phase A, first half: everything that does not depend on the pose is requested now — target, cache entry and,
+    // behind it, the cached neighbour and its normal (or the frame seed and its map point): in a lead launch these loads
+    // are in flight while the lead workgroup solves
+    const int lq = threadIdx.x, qi = q0 + lq;
+    bool valid = false;
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq;
+    int2 c = make_int2(-1, 0);
+    int seed_o = -1, seed_sp = -1;
+    if (lq < Q) {
+        valid = qi < in.n;
         if (valid) {
             t4 = in.tgt[qi];
             valid = target_valid(t4.x, t4.y, t4.z, in.mode);
             if (!valid && !in.use_cache) in.nn_cache[qi] = make_int2(-1, 0);  // masked row: no neighbour, no seed
         }
         if (valid) {
-            float px, py, pz;
-            transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
-            bool hit = false;
-            float seed_d2 = INFINITY;
-            int seed_idx = 0x7fffffff, seed_pos = -1;
             if (in.use_cache) {
-                const int2 c = in.nn_cache[qi];
+                c = in.nn_cache[qi];
                 if (c.x >= 0) {
-                    const float4 q = g.pts[c.x];
-                    const float4 nn = in.normals[c.x];  // speculative: needed on a hit only
-                    float ox, oy, oz;
-                    transform_point(st->pose_prev, t4.x, t4.y, t4.z, ox, oy, oz);
-                    const float mx = px - ox, my = py - oy, mz = pz - oz;
-                    const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                    const float L = __int_as_float(c.y) - delta;
-                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    hit = sqrtf(d2) * 1.000001f < L;
-                    if (hit) {
-                        in.nn_cache[qi] = make_int2(c.x, __float_as_int(L));
-                        point_to_plane_row(px, py, pz, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-                    } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
-                        seed_d2 = d2;
-                        seed_idx = __float_as_int(q.w);
-                        seed_pos = c.x;
-                    }
+                    cq = g.pts[c.x];
+                    cn = in.normals[c.x];  // speculative: needed on a hit only
                 }
             } else if (in.frame_seed) {
                 const int o = in.frame_seed[qi];
                 if (o >= 0 && o < g.m) {
-                    const int sp = g.pos_of_orig[o];
-                    const float4 q = g.pts[sp];
-                    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-                    seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    seed_idx = o;
-                    seed_pos = sp;
+                    seed_o = o;
+                    seed_sp = g.pos_of_orig[o];
+                    cq = g.pts[seed_sp];
                 }
+            }
+        }
+    }
+    // ---- the pose: from the mailbox (lead launch) or from the RegState (classic launch)
+    if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
+    __syncthreads();
+    if (lead.box) {
+        if (threadIdx.x < BOX_USED) {
+            const unsigned long long* p = box_granule(lead.box, lead.gen, vb % BOX_REPLICAS, threadIdx.x);
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == lead.gen) break;
+                if (wall_clock64() - t0 > lead.timeout_ticks) {
+                    atomicAdd(&ctl_s[3], 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned bits = (unsigned)(v & 0xffffffffull);
+            if (threadIdx.x < 12) pose_s[threadIdx.x] = __uint_as_float(bits);
+            else ctl_s[threadIdx.x - 11] = (int)bits;  // 12 -> done, 13 -> iteration
+        } else if (threadIdx.x >= 64 && threadIdx.x < 76 && in.use_cache) {
+            // the pose of the previous launch (generation gen - 1, the other parity): what the cache bounds refer to
+            const int k = threadIdx.x - 64;
+            const unsigned long long v = __hip_atomic_load(box_granule(lead.box, lead.gen - 1u, vb % BOX_REPLICAS, k),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) != lead.gen - 1u) atomicAdd(&ctl_s[3], 1);
+            prev_s[k] = __uint_as_float((unsigned)(v & 0xffffffffull));
+        }
+    } else if (threadIdx.x < 12) {
+        pose_s[threadIdx.x] = st->pose[threadIdx.x];
+        prev_s[threadIdx.x] = st->pose_prev[threadIdx.x];
+        if (threadIdx.x == 0) ctl_s[2] = st->iter;
+    }
+    if (threadIdx.x == 0) nmiss = 0;
+    __syncthreads();
+    if (ctl_s[3]) {  // never seen: the hand-off did not arrive within its wall-clock budget -> a loud error, not a hang
+        if (threadIdx.x == 0) atomicAdd(&st->handoff_timeouts, 1);
+        return;
+    }
+    if (ctl_s[1]) return;  // the loop is finished (block-uniform)
+    const int iter_now = ctl_s[2];
+    // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
+    // counters
+    long long* stamps = nullptr;
+    if (g.stamps && gridDim.x <= 1025 && vb < 1024 && iter_now < 24)
+        stamps = g.stamps + 4 * ((size_t)iter_now * 1024 + vb);
+    if (stamps && threadIdx.x == 0) stamps[0] = t_entry;
+    // ---- phase A, second half: one lane per query
+    if (lq < Q) {
+        float row[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) row[k] = 0.f;
+        if (valid) {
+            float px, py, pz;
+            transform_point(pose_s, t4.x, t4.y, t4.z, px, py, pz);
+            bool hit = false;
+            float seed_d2 = INFINITY;
+            int seed_idx = 0x7fffffff, seed_pos = -1;
+            if (in.use_cache) {
+                if (c.x >= 0) {
+                    float ox, oy, oz;
+                    transform_point(prev_s, t4.x, t4.y, t4.z, ox, oy, oz);
+                    const float mx = px - ox, my = py - oy, mz = pz - oz;
+                    const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                    const float L = __int_as_float(c.y) - delta;
+                    const float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
+                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    hit = sqrtf(d2) * 1.000001f < L;
+                    if (hit) {
+                        in.nn_cache[qi] = make_int2(c.x, __float_as_int(L));
+                        point_to_plane_row(px, py, pz, cq.x, cq.y, cq.z, cn.x, cn.y, cn.z, ap.scheme, ap.sigma, row);
+                    } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
+                        seed_d2 = d2;
+                        seed_idx = __float_as_int(cq.w);
+                        seed_pos = c.x;
+                    }
+                }
+            } else if (seed_sp >= 0) {
+                const float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
+                seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                seed_idx = seed_o;
+                seed_pos = seed_sp;
             }
             if (!hit) {
                 const int k = atomicAdd(&nmiss, 1);
@@ -597,7 +707,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         stamps[1] = wall_clock64() | ((long long)nmiss << 48);  // the block's miss count rides in the top bits
         if (g.dbg) {
             atomicAdd(&g.dbg[6], nmiss);
-            atomicAdd(&g.dbg[8 + min(st->iter, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
+            atomicAdd(&g.dbg[8 + min(iter_now, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
         }
     }
     // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
@@ -663,7 +773,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
-    block_reduce_rows<Q>(rowbuf, part, in.partials);
+    block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
@@ -1502,15 +1612,34 @@ int launch_normals_install(icp_ctx* ctx, const float* by_index_dev) {
     return ICP_OK;
 }
 
-int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out) {
+unsigned long long* pose_box(icp_ctx* ctx) { return ctx->posebox.as<unsigned long long>(); }
+
+unsigned next_box_generation(icp_ctx* ctx) {
+    ctx->box_gen += 1u;
+    if (ctx->box_gen == 0u) ctx->box_gen = 1u;  // tag 0 = never written
+    return ctx->box_gen;
+}
+
+// from iteration `narrow_from` on (few NN-cache misses expected) 512 queries per block, one lane each: a wrong guess costs
+// time only
+bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
+    const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
+    return use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
+}
+
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad) {
     const int n = (int)ctx->tgt_n;
     const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
-    // from iteration `narrow_from` on (few NN-cache misses expected) 512 queries per block, one lane each: a wrong guess
-    // costs time only
-    const bool narrow = use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
+    const bool narrow = next_fused_launch_is_narrow(ctx);
     const int per_block = narrow ? IT_THREADS : IT_QUERIES;
     const int blocks = n > 0 ? (n + per_block - 1) / per_block : 1;
-    ICP_HIP(ctx, ctx->partials.reserve((size_t)(n > 0 ? (n + IT_QUERIES - 1) / IT_QUERIES : 1) * NEQ * sizeof(double)));
+    {
+        const size_t half = (size_t)(n > 0 ? (n + IT_QUERIES - 1) / IT_QUERIES : 1) * NEQ * sizeof(double);
+        if (half > ctx->partials_half) {  // (only ever at the first launch of a registration: nothing is pending in it)
+            ICP_HIP(ctx, ctx->partials.reserve(2 * half));
+            ctx->partials_half = ctx->partials.bytes / 2 / (NEQ * sizeof(double)) * (NEQ * sizeof(double));
+        }
+    }
     ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
     const int tok = prof_begin(ctx, 0);
     IterInputs in;
@@ -1520,21 +1649,39 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out) {
     // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
     in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
                         ? ctx->seed_orig.as<int>() : nullptr;
-    in.partials = ctx->partials.as<double>();
+    // the classic launch writes parity 0 (what launch_sum_solve reads by default); lead launches alternate
+    const int parity = lead_mode ? ctx->partials_parity : 0;
+    in.partials = (double*)(ctx->partials.as<char>() + (size_t)parity * ctx->partials_half);
+    LeadArgs lead;
+    if (lead_mode) {
+        lead.box = pose_box(ctx);
+        lead.solve = prev_rows > 0 ? 1 : 0;
+        lead.gen = lead.solve ? next_box_generation(ctx) : ctx->box_gen;  // the lead publishes it / already published
+        lead.prev_partials = (const double*)(ctx->partials.as<char>() + (size_t)(parity ^ 1) * ctx->partials_half);
+        lead.prev_rows = prev_rows;
+        lead.prev_quad = prev_quad;
+        lead.neq = ctx->neq;
+        lead.loss_hist = ctx->loss_hist;
+        lead.dx_hist = ctx->dx_hist;
+        lead.hist_cap = ctx->hist_cap;
+        lead.timeout_ticks = 5000000ll;  // 50 ms of the 100 MHz wall clock
+        ctx->partials_parity = parity ^ 1;
+    }
+    const int grid = blocks + (lead_mode ? lead.solve : 0);
     in.n = n;
     in.mode = ctx->tgt_mode;
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
     in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
     if (narrow)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
+        hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else if (ctx->iterate_dense)
-        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
+        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else
-        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), dim3(blocks), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx));
+        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;

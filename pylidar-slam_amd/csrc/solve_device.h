@@ -223,9 +223,19 @@ __device__ inline void solve_core(const double* __restrict__ neq, AlignParams ap
 // the step applied to a RegState in place (lane 0 of the wave writes)
 __device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
                                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
-                                        int it, const float* pose_in, const float* params_in) {
+                                        int it, const float* pose_in, const float* params_in,
+                                        unsigned long long* __restrict__ box = nullptr, unsigned gen = 0) {
     SolveOut o;
     solve_core(neq, ap, it, pose_in, params_in, o);
+    if (box) {  // the pose mailbox first (workgroups of this very launch may be polling for it), one granule per lane
+        const int lane = threadIdx.x & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (lane == k) v = o.pose[k];
+        const unsigned bits = lane < 12 ? __float_as_uint(v) : (lane == 12 ? (unsigned)o.done : (unsigned)(it + 1));
+        if (lane < BOX_USED) box_store(box, gen, lane, bits);
+    }
     if ((threadIdx.x & 63) != 0) return;
     st->n_worklist = 0;
     st->n_targets = (int)neq[29];
@@ -242,6 +252,73 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
         for (int k2 = 0; k2 < 16; ++k2) st->pose[k2] = o.pose[k2];
     }
     if (o.done) st->done = 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fixed-order sum of the partial rows -> out[NEQ].  The order of the additions depends only on the geometry, never on
+// timing, and is defined for 1024 VIRTUAL threads (32 row groups x 32 columns): a workgroup of THREADS threads plays
+// 1024 / THREADS of them each, so the 1024-thread summing kernel and the 512-thread lead workgroup of the fused iteration
+// launch form the same bits.  Canonical order: four consecutive BASE rows form a super-row (r0 + r1) + (r2 + r3) (rows past
+// the end count as 0.0); the super-rows are added in the strided 8-accumulator pattern below.  `quad` = 1: `partials`
+// holds base rows (grouped here); 0: the producer already wrote super-rows (the 512-queries-per-block shape of the fused
+// iteration kernel: a quarter of the bytes for this single workgroup to load).  `lds` = 32 x NEQ doubles of scratch.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline double load_super_row(const double* __restrict__ partials, int nrows, int quad, int sr, int col) {
+    if (!quad) return partials[(size_t)sr * NEQ + col];
+    const int b = 4 * sr;
+    const double r0 = partials[(size_t)b * NEQ + col];
+    const double r1 = b + 1 < nrows ? partials[(size_t)(b + 1) * NEQ + col] : 0.0;
+    const double r2 = b + 2 < nrows ? partials[(size_t)(b + 2) * NEQ + col] : 0.0;
+    const double r3 = b + 3 < nrows ? partials[(size_t)(b + 3) * NEQ + col] : 0.0;
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int THREADS>
+__device__ inline void sum_partials_vt(const double* __restrict__ partials, int nrows, int quad, double* out,
+                                       double (*lds)[NEQ]) {
+    static_assert(1024 % THREADS == 0, "virtual threads");
+    const int ns = quad ? (nrows + 3) / 4 : nrows;  // super-rows
+#pragma unroll 1
+    for (int v = threadIdx.x; v < 1024; v += THREADS) {
+        const int col = v & 31, grp = v >> 5;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+        int b = grp;
+        for (; b + 224 < ns; b += 256) {  // eight independent super-rows (8 or 32 loads) in flight
+            const double v0 = load_super_row(partials, nrows, quad, b, col);
+            const double v1 = load_super_row(partials, nrows, quad, b + 32, col);
+            const double v2 = load_super_row(partials, nrows, quad, b + 64, col);
+            const double v3 = load_super_row(partials, nrows, quad, b + 96, col);
+            const double v4 = load_super_row(partials, nrows, quad, b + 128, col);
+            const double v5 = load_super_row(partials, nrows, quad, b + 160, col);
+            const double v6 = load_super_row(partials, nrows, quad, b + 192, col);
+            const double v7 = load_super_row(partials, nrows, quad, b + 224, col);
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+            s4 += v4;
+            s5 += v5;
+            s6 += v6;
+            s7 += v7;
+        }
+        for (; b < ns; b += 32) s0 += load_super_row(partials, nrows, quad, b, col);
+        lds[grp][col] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    }
+    __syncthreads();
+    if (threadIdx.x < NEQ) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += lds[g][threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// the 1024-thread form with its own scratch
+__device__ inline void sum_partials_block(const double* __restrict__ partials, int nrows, int quad,
+                                          double* out /* LDS or global */) {
+    __shared__ double lds[32][NEQ];
+    sum_partials_vt<1024>(partials, nrows, quad, out, lds);
 }
 
 }  // namespace icp
