@@ -625,6 +625,8 @@ def c4_leg(args, dist, rank, world, local_rank, dev, steps=6, warmup=2):
         if err is not None:
             out[name] = {"error": err}
             continue
+        if normals == "auto":
+            tr.ctx.set_option("eager_normals_limit", 0)  # the lazy schedule (normals on demand, unfused iterations)
         exchange = "none"
         if world > 1:
             tr.ctx.set_option("exchange_timeout_ms", 3000)

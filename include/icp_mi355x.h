@@ -118,6 +118,13 @@ int icp_synchronize(icp_ctx* ctx);
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 | 2 (0)
  *   "scan_poll_limit" n (2^20)      grid build: polls of a predecessor tile's descriptor before a tile of the one-launch table
  *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
+ *   "lead_solve" 0 | 1 (1)          launched / unpolled registrations: the 6x6 solve of iteration k runs in an extra workgroup
+ *                                   at the head of the (late, 512-queries-per-block) launch k + 1, which publishes the pose to
+ *                                   the workgroups of that launch through a mailbox, instead of a launch of its own; same bits
+ *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last
+ *                                   registration ran, plus one; icp_register_end enqueues more while the loop is still running
+ *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
+ *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
  *   "profile_every" n (1)           icp_profile_enable times the kernels of every n-th registration only (an event pair
  *                                   costs ~2 us of stream time: 40 pairs per frame are 10 % of a 0.8 ms registration)
  * The library reads no environment variables. */
@@ -247,6 +254,15 @@ int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* 
  * `iterations` entries ([.] double, [.,6] float). */
 int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16],
                  icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out);
+
+/* Device-side helper of ICPFrameToModel.sample_points for vertex-map targets (slam/odometry/icp_odometry.py:301-308:
+ * `target_points[target_points.norm(dim=-1) > 0.0]`) without a host round trip for the count: the rows of xyz [n,3]
+ * that pass `target_mode` (rows with a NaN never do; null rows do not under ICP_TARGETS_SKIP_NULL) are written, in
+ * order, to the head of out [cap,3]; the rest of `out` is zero-filled, so registering `out` with ICP_TARGETS_SKIP_NULL
+ * registers exactly the passing rows — with cap instead of n rows to walk (a 64x2048 vertex map built from a 6000-point
+ * grid sample has at most 6000 non-null pixels).  Both pointers are device memory.  cap must be >= the number of passing
+ * rows (the caller knows such a bound by construction); passing rows beyond cap are dropped.  Asynchronous. */
+int icp_compact_targets(icp_ctx* ctx, const float* xyz, int64_t n, int target_mode, float* out, int64_t cap);
 
 /* ---- multi-GPU seam: one ICP iteration split around the exchange of the packed normal equations -------------------
  * begin -> { accumulate -> [all-reduce the 32 doubles at icp_normal_equations_ptr over RCCL] -> solve } x iters -> end.

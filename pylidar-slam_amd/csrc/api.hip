@@ -217,6 +217,19 @@ static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = fal
 }
 
 static void exchange_release(icp_ctx* ctx);
+static int continue_launch(icp_ctx* ctx, int count);
+
+// Normals of the whole map at once (one dense launch, then the fused iteration kernel) or lazily for the map points the
+// scan touches (local_map.py:397-422; three more launches per iteration, each a latency-bound chain when the scan is
+// small)?  Same values either way.  Eager costs ~1 us per 1000 map points; measured, it wins whenever the map is at most
+// twice the scan, and for any scan while the map stays below ~10^6 points (a 6 000-point grid sample against 180 000
+// map points: 0.19 ms eager vs 0.45 ms for four lazy iterations; 200 000 points against 10^6: 2.8 vs 4.7 ms per frame of
+// twenty iterations).
+static bool wants_eager_normals(const icp_ctx* ctx, int64_t n) {
+    if (ctx->cost != ICP_COST_POINT_TO_PLANE) return false;
+    return ctx->map_m <= 2 * n || ctx->map_m <= (int64_t)ctx->eager_normals_limit;
+}
+static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first = 0, int count = -1);
 
 // ---- lifecycle ------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -331,6 +344,8 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
+    else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
+    else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {
         ctx->search_stats = (int)iv;  // 1: path counters + phase stamps, 2: stamps only (no atomics)
@@ -651,8 +666,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
     // the next registration will want every normal at once (same rule as register_begin, with the size of the scan just
     // registered standing in for the next one): estimate them NOW, behind the rebuild, so that the GPU works through the
     // caller's preparation of the next frame (host staging, upload) instead of starting on them when that frame arrives
-    if (ctx->cost == ICP_COST_POINT_TO_PLANE && ctx->have_device_pose && ctx->tgt_n > 0 && ctx->map_m <= 2 * ctx->tgt_n)
-        rc = launch_normals_all(ctx);
+    if (ctx->have_device_pose && ctx->tgt_n > 0 && wants_eager_normals(ctx, ctx->tgt_n)) rc = launch_normals_all(ctx);
     return rc;
 }
 
@@ -669,6 +683,10 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
     if (!rel_pose && has_cloud && ctx->result_pending())
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL with a new cloud: collect the pending registration "
                                                    "(icp_register_end) first");
+    if (!rel_pose) {  // the pose it reads is the END of that registration: iterations a chunked launch holds back go first
+        const int rc0 = continue_launch(ctx, -1);
+        if (rc0) return rc0;
+    }
     const void* in = nullptr;
     int rc;
     if (has_cloud) {
@@ -680,6 +698,19 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
                                ctx->flags.as<int>());
     }
     return map_update_impl(ctx, rel_pose, (const float*)in, ctx->flags.as<int>(), n, has_cloud, inserted_out);
+}
+
+int icp_compact_targets(icp_ctx* ctx, const float* xyz, int64_t n, int target_mode, float* out, int64_t cap) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || n < 0 || cap < 0 || (n > 0 && !xyz) || (cap > 0 && !out)) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    if (cap > 0) ICP_HIP(ctx, hipMemsetAsync(out, 0, (size_t)cap * 12, ctx->stream));
+    if (n == 0 || cap == 0) return ICP_OK;
+    ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
+    hipLaunchKernelGGL(k_flag_not_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz, (long long)n,
+                       target_mode == ICP_TARGETS_SKIP_NULL ? 1 : 0, ctx->flags.as<int>());
+    return compact_rows(ctx, xyz, ctx->flags.as<int>(), n, 3, out, ctx->counter.as<int>(), cap);
 }
 
 int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,
@@ -1116,9 +1147,7 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations++ % ctx->prof.every) == 0;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
-    if (ctx->cost == ICP_COST_POINT_TO_PLANE && !ctx->normals_ready && ctx->map_m <= 2 * n &&
-        (rc = launch_normals_all(ctx)))
-        return rc;
+    if (!ctx->normals_ready && wants_eager_normals(ctx, n) && (rc = launch_normals_all(ctx))) return rc;
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     return ICP_OK;
@@ -1163,9 +1192,10 @@ static size_t state_bytes(const icp_ctx* ctx) {
     return STATE_BLOCK + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
 }
 
-static int enqueue_result_copy(icp_ctx* ctx) {
-    if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
-    icp_ctx::ResultSlot& r = ctx->rslot[(ctx->r_head + ctx->r_count) & 1];
+// refresh = true: the newest pending slot is copied again (a further chunk of its registration has been enqueued)
+static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
+    if (!refresh && ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
+    icp_ctx::ResultSlot& r = ctx->rslot[(ctx->r_head + ctx->r_count - (refresh ? 1 : 0)) & 1];
     const size_t sb = state_bytes(ctx), need = sb;
     if (need > r.bytes) {
         if (r.host) (void)hipHostFree(r.host);
@@ -1177,16 +1207,30 @@ static int enqueue_result_copy(icp_ctx* ctx) {
     if (!r.event) ICP_HIP(ctx, hipEventCreateWithFlags(&r.event, hipEventDisableTiming));
     char* h = (char*)r.host;
     ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));  // state + histories
+    ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
+    if (refresh) return ICP_OK;
     // the grid statistics about to be read back belong to the current build; a later build starts a new pending set
     r.stats = ctx->stats_pending;
     r.stats_m = ctx->stats_m_pending;
     r.stats_h = ctx->stats_h_pending;
     ctx->stats_pending = false;
-    ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
     r.eager_normals = ctx->normals_eager_count;
     ctx->normals_eager_count = 0;
     ctx->r_count += 1;
     return ICP_OK;
+}
+
+// enqueues the iterations a chunked launch has held back (all of them, or the next `count`) and copies the result again
+static int continue_launch(icp_ctx* ctx, int count) {
+    if (ctx->launch_remaining <= 0) return ICP_OK;
+    if (count < 0 || count > ctx->launch_remaining) count = ctx->launch_remaining;
+    ctx->in_registration = true;
+    int rc = enqueue_iterations(ctx, false, ctx->launch_enqueued, count);
+    ctx->in_registration = false;
+    ctx->launch_enqueued += count;
+    ctx->launch_remaining -= count;
+    if (!rc) rc = enqueue_result_copy(ctx, true);
+    return rc;
 }
 
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
@@ -1200,11 +1244,20 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     const char* pinned = nullptr;
     if (async) {  // copies were enqueued right behind the last iteration: wait for those only (the OLDEST result)
         icp_ctx::ResultSlot& r = ctx->rslot[ctx->r_head];
-        ctx->r_head ^= 1;
-        ctx->r_count -= 1;
         ICP_HIP(ctx, hipEventSynchronize(r.event));
         pinned = (const char*)r.host;
         memcpy(&st, pinned, sizeof(st));
+        // a chunked launch (only ever the newest pending registration, here also the oldest): still running and
+        // iterations held back -> the next chunk, then look again
+        while (ctx->r_count == 1 && ctx->launch_remaining > 0 && !st.done && st.status == ICP_OK) {
+            const int rc2 = continue_launch(ctx, 4);
+            if (rc2) return rc2;
+            ICP_HIP(ctx, hipEventSynchronize(r.event));
+            memcpy(&st, pinned, sizeof(st));
+        }
+        if (ctx->r_count == 1) ctx->launch_remaining = 0;  // (finished early: the rest is never enqueued)
+        ctx->r_head ^= 1;
+        ctx->r_count -= 1;
         had_stats = r.stats;
         stats_m = r.stats_m;
         stats_h = r.stats_h;
@@ -1297,6 +1350,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     memcpy(result->pose, st.pose, sizeof(st.pose));
     memcpy(result->params, st.params, sizeof(st.params));
     result->iterations = st.iter;
+    ctx->last_iterations = st.iter;
     result->converged = st.converged;
     result->status = st.status;
     result->num_targets = st.n_targets;
@@ -1328,9 +1382,11 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     return st.status;
 }
 
-static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
+// enqueues iterations [first, first + count) of the registration in progress (count < 0: all of them)
+static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int count) {
     int rc = ICP_OK;
-    const int iters = ctx->cfg.max_num_alignments;
+    const int iters = count < 0 ? ctx->cfg.max_num_alignments
+                                : (first + count < ctx->cfg.max_num_alignments ? first + count : ctx->cfg.max_num_alignments);
     // the loop never converges early when the threshold is <= 0 (forced iteration count): no point polling
     const int poll = (poll_allowed && ctx->cfg.threshold_delta_pose > 0.f) ? ctx->cfg.poll_every : 0;
     // lead launches: the solve of iteration k rides in the head of launch k + 1 (LeadArgs, icp_internal.h); one summing /
@@ -1338,7 +1394,7 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed) {
     // which would lag one iteration) and not with the in-library exchange (its solve waits for the peers)
     const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0;
     int prev_rows = 0, prev_quad = 1;  // rows a lead launch still has to solve
-    for (int it = 0; it < iters; ++it) {
+    for (int it = first; it < iters; ++it) {
         if (lead) {
             // every launch takes its pose from the mailbox; the NARROW ones (late iterations: one workgroup more fits beside
             // the others) also solve the iteration before them, the others follow a summing / solving launch as before
@@ -1380,12 +1436,25 @@ static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, i
                            const float init_pose[16], bool from_last) {
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
-    int rc = register_begin(ctx, xyz, n, mem, target_mode, init_pose, from_last);
+    int rc = continue_launch(ctx, -1);  // (an older launch still holding iterations back: they come first on the stream)
     if (rc) return rc;
-    // every iteration is enqueued; launches behind an early stop see `done` on the device and return immediately
-    rc = enqueue_iterations(ctx, false);
+    rc = register_begin(ctx, xyz, n, mem, target_mode, init_pose, from_last);
+    if (rc) return rc;
+    // forced iteration count (threshold <= 0): every iteration is enqueued.  Live threshold: a first chunk of as many
+    // iterations as the last frame ran plus one (launches behind an early stop would see `done` on the device and return
+    // at once — but each still costs its slot on the stream, twenty of them more than the three that do the work);
+    // icp_register_end enqueues further chunks while the loop is still running
+    const int iters = ctx->cfg.max_num_alignments;
+    int first_chunk = iters;
+    if (ctx->cfg.threshold_delta_pose > 0.f && ctx->chunked_launch) {
+        first_chunk = (ctx->last_iterations > 0 ? ctx->last_iterations : 3) + 1;
+        if (first_chunk > iters) first_chunk = iters;
+    }
+    rc = enqueue_iterations(ctx, false, 0, first_chunk);
+    ctx->launch_enqueued = first_chunk;
+    ctx->launch_remaining = iters - first_chunk;
     if (!rc) rc = enqueue_result_copy(ctx);
-    ctx->in_registration = false;  // nothing left to enqueue for it: the result waits in its slot
+    ctx->in_registration = false;  // the result waits in its slot
     return rc;
 }
 

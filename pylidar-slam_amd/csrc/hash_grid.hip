@@ -134,22 +134,24 @@ int exclusive_scan_i32(icp_ctx* ctx, const int* in, int* out, int64_t n, int* to
 // ordered compaction of rows
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_compact_scatter(const float* __restrict__ in, const int* __restrict__ flags,
-                                  const int* __restrict__ offs, long long n, int row_floats, float* __restrict__ out) {
+                                  const int* __restrict__ offs, long long n, int row_floats, float* __restrict__ out,
+                                  long long cap) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
     long long o = offs[i];
+    if (o >= cap) return;  // (an output of bounded capacity: icp_compact_targets)
     for (int c = 0; c < row_floats; ++c) out[o * row_floats + c] = in[i * row_floats + c];
 }
 
 int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int row_floats, float* out,
-                 int* count_dev) {
+                 int* count_dev, int64_t cap) {
     ICP_HIP(ctx, ctx->scan_a.reserve((size_t)(n > 0 ? n : 1) * sizeof(int)));
     int* offs = ctx->scan_a.as<int>();
     int rc = exclusive_scan_i32(ctx, flags, offs, n, count_dev);
     if (rc) return rc;
     if (n > 0) {
         hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, flags,
-                           offs, (long long)n, row_floats, out);
+                           offs, (long long)n, row_floats, out, (long long)(cap >= 0 ? cap : n));
         ICP_HIP(ctx, hipGetLastError());
     }
     return ICP_OK;

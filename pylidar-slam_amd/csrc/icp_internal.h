@@ -295,6 +295,8 @@ struct icp_ctx {
     int partials_parity = 0;           // parity the NEXT fused launch writes
     icp::DeviceBuffer posebox;         // pose mailbox of the lead launches (BOX_BYTES)
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
+    long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
+    int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
@@ -321,6 +323,14 @@ struct icp_ctx {
         float stats_h = 0.f;
         int64_t eager_normals = 0;   // normals estimated eagerly for this registration
     } rslot[2];
+    // a launched registration with a live stop threshold is enqueued in CHUNKS (as many iterations as the previous frame
+    // needed, plus one): icp_register_end looks at the result and enqueues the next chunk only if the loop is still
+    // running, instead of paying for max_num_alignments launches of which most find `done` set.  launch_remaining =
+    // iterations of the NEWEST pending registration not enqueued yet (anything that must follow the whole registration on
+    // the stream — a map update by the device pose, another launch — enqueues them first)
+    int launch_remaining = 0;
+    int launch_enqueued = 0;         // iterations enqueued so far for it
+    int last_iterations = 0;         // iterations the last collected registration ran (sizes the next first chunk)
     int r_head = 0;                  // oldest pending slot
     int r_count = 0;                 // results launched and not yet collected (0..2)
     bool result_pending() const { return r_count > 0; }
@@ -363,7 +373,7 @@ int build_grid(icp_ctx* ctx);
 int exclusive_scan_i32(icp_ctx* ctx, const int* in, int* out, int64_t n, int* total_dev);
 // ordered compaction: copies rows (row_floats floats each) whose flag != 0; count to *count_dev
 int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int row_floats, float* out,
-                 int* count_dev);
+                 int* count_dev, int64_t cap = -1);
 
 // ---- search.hip
 int launch_search_raw(icp_ctx* ctx);  // 1-NN without the pose transform (LocalMap seam)

@@ -104,6 +104,7 @@ EXPORTED_SYMBOLS = {
     "icp_voxel_statistics": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, _P, _P, _P, _P, _P, _INT]),
     "icp_align_point_to_point": (_INT, [_P, _P, _P, _I64, _INT, _P, _P, _P, _P, _P, _P]),
     "icp_weighted_procrustes": (_INT, [_P, _P, _P, _P, _I64, _INT, _P]),
+    "icp_compact_targets": (_INT, [_P, _P, _I64, _INT, _P, _I64]),
     "icp_register": (_INT, [_P, _P, _I64, _INT, _INT, _P, C.POINTER(IcpRegisterResult), _P, _P]),
     "icp_register_begin": (_INT, [_P, _P, _I64, _INT, _INT, _P]),
     "icp_register_launch": (_INT, [_P, _P, _I64, _INT, _INT, _P]),

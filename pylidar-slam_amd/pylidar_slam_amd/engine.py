@@ -524,6 +524,21 @@ class IcpContext:
         self._check(self._lib.icp_weighted_procrustes(self._h, t, r, w, int(kt.shape[0]), mem_t, out))
         return np.array(out, np.float64).reshape(4, 4)
 
+    def compact_targets(self, rows: torch.Tensor, cap: int, skip_null: bool = True) -> torch.Tensor:
+        """[cap,3] device tensor: the rows of `rows` [n,3] (a cuda tensor) that a registration with this masking would
+        use, in order, at its head, null rows behind them — so registering it with skip_null walks `cap` rows instead of
+        n.  `cap` must bound the number of passing rows (the caller's knowledge: a vertex map built from N points has at
+        most N non-null pixels).  No host round trip."""
+        if not (isinstance(rows, torch.Tensor) and rows.is_cuda):
+            raise AssertionError("compact_targets works on device tensors")
+        self._bind(rows)
+        t = rows if rows.dtype == torch.float32 and rows.is_contiguous() else rows.to(torch.float32).contiguous()
+        out = torch.empty((max(int(cap), 1), 3), dtype=torch.float32, device=t.device)
+        self._check(self._lib.icp_compact_targets(self._h, t.data_ptr(), int(t.shape[0]),
+                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, out.data_ptr(),
+                                                  int(cap)))
+        return out[:int(cap)]
+
     # ---- registration ------------------------------------------------------------------------------------------------
     def _result(self, res: IcpRegisterResult, losses, dxs) -> RegisterResult:
         k = int(res.iterations)

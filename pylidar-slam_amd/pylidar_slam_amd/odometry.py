@@ -781,7 +781,14 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
     def sample_points(self):  # :301-308 — returns (device rows, skip_null)
         if not self._sample_pointcloud:
             h, w = self._tgt_vmap.shape[-2:]
-            return self._tgt_vmap.permute(1, 2, 0).reshape(h * w, 3).contiguous(), True
+            pixels = self._tgt_vmap.permute(1, 2, 0).reshape(h * w, 3).contiguous()
+            # the non-null pixels (:303-305).  A vertex map projected from N points has at most N of them: when that is
+            # well below H * W (a grid-sampled frame: 6 000 of 131 072) they are compacted on the device, in pixel order,
+            # so the registration walks N rows — and estimates normals lazily for what N rows touch — instead of H * W
+            n_in = self._tgt_pc.shape[0] if (self._tgt_pc is not None and not self._pc_is_pixels) else h * w
+            if pixels.is_cuda and 2 * n_in <= h * w and hasattr(self.ctx, "compact_targets"):
+                return self.ctx.compact_targets(pixels, n_in, skip_null=True), True
+            return pixels, True
         return self._tgt_pc, self._pc_is_pixels
 
     def register_new_frame(self, target_points, initial_estimate=None, skip_null: bool = False, **kwargs):  # :248-299

@@ -77,7 +77,7 @@ def test_map_sharded_normals_equal_the_single_gpu_estimation(torch_cuda):
 
 def test_c4_size_map_sharded_registration_vs_oracle(torch_cuda, O):
     """BASELINE.json configs[3] on one GPU: a 128-beam 200k-point scan against a 1M-point map.  The map is > 2x the scan,
-    so the default schedule estimates normals lazily for the map points the scan touches (unfused iterations); with the
+    so below `eager_normals_limit` normals are estimated lazily for the map points the scan touches (unfused iterations); with the
     map-sharded estimation (here two simulated ranks) the normals are all there and the fused kernel runs.  Both within
     1e-4 m / 1e-4 rad of the oracle."""
     torch = torch_cuda
@@ -92,6 +92,7 @@ def test_c4_size_map_sharded_registration_vs_oracle(torch_cuda, O):
               scheme="geman_mcclure", sigma=0.3)
     dmodel, dscan = torch.from_numpy(model).cuda(), torch.from_numpy(scan).cuda()
     lazy = _ctx(**kw)
+    lazy.set_option("eager_normals_limit", 0)  # (a map of up to 2^20 points is otherwise estimated at once: faster)
     lazy.map_set(dmodel)
     r_lazy = lazy.register(dscan)
     assert r_lazy.iterations == iters and 0 < r_lazy.normals_computed < model.shape[0]  # on demand, like the reference

@@ -319,6 +319,8 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
                 "lanes2": {"knn_lanes": 2}, "scan_gives_up": {"scan_poll_limit": 0},
+                "no_lead_solve": {"lead_solve": 0},  # every solve in a launch of its own (round 2's schedule)
+                "no_lead_never_narrow": {"lead_solve": 0, "narrow_from": -1},
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -359,6 +361,36 @@ def test_schedule_options_are_bit_identical(torch_cuda):
             if not np.array_equal(nrm, ref_nrm):
                 problems.append(f"{name}: normals differ ({np.abs(nrm - ref_nrm).max():.1e})")
     assert not problems, "\n".join(problems)
+
+
+def test_lazy_and_eager_normals_give_the_same_registration(torch_cuda):
+    """Normals of the whole map at once (maps up to `eager_normals_limit` points, or at most twice the scan) or lazily for
+    the map points the scan touches (`KdTreeLocalMap.__get_normals`' cache semantics, local_map.py:397-422): the same
+    normals, hence the same registration up to the order of the float64 sums — on a scan a quarter the size of the map,
+    with the forced iteration count and with a live threshold (polled, launched in chunks)."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 6)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    targets = np.ascontiguousarray(scans[5][::4])
+    for threshold in (0.0, 1.0e-4):
+        got = {}
+        for name, limit in (("eager", 1 << 20), ("lazy", 0)):
+            ctx = _ctx(height=32, width=1024, max_num_alignments=15, threshold_delta_pose=threshold,
+                       scheme="geman_mcclure", sigma=0.3)
+            ctx.set_option("eager_normals_limit", limit)
+            ctx.map_set(model)
+            sync = ctx.register(targets)
+            ctx.register_launch(targets, None)
+            launched = ctx.register_end()
+            assert np.array_equal(sync.pose, launched.pose) and sync.iterations == launched.iterations
+            got[name] = sync
+            ctx.close()
+        assert got["eager"].normals_computed == model.shape[0]
+        assert 0 < got["lazy"].normals_computed < model.shape[0] // 2
+        assert got["eager"].iterations == got["lazy"].iterations
+        np.testing.assert_allclose(got["lazy"].pose, got["eager"].pose, atol=2e-7)
+        np.testing.assert_allclose(got["lazy"].losses, got["eager"].losses, rtol=1e-6)
 
 
 def _knn_clouds():

@@ -326,3 +326,64 @@ def test_insertion_by_the_device_pose_waits_for_the_pending_result(torch_cuda):
     ref.map_update(np.eye(4, dtype=np.float32), scans[0])
     ref.map_update(res.pose, scans[1])
     np.testing.assert_array_equal(ctx.map_points(), ref.map_points())
+
+
+def test_compact_targets_equals_boolean_indexing(torch_cuda):
+    """`icp_compact_targets`: the passing rows in order at the head, zeros behind — and a registration of the compacted
+    rows (skip_null) gives the bits of the registration of all rows."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    scans, _ = _scans(32, 512, 2)
+    ctx = IcpContext(height=32, width=512, max_num_alignments=6, threshold_delta_pose=0.0)
+    rows = scans[1].copy()
+    rows[::3] = 0.0
+    rows[5] = np.nan
+    keep = ~np.isnan(rows).any(axis=1) & (np.abs(rows).max(axis=1) > 0)
+    cap = int(keep.sum()) + 37
+    got = ctx.compact_targets(torch.from_numpy(rows).cuda(), cap).cpu().numpy()
+    assert got.shape == (cap, 3)
+    np.testing.assert_array_equal(got[:keep.sum()], rows[keep])
+    assert not got[keep.sum():].any()
+    tight = ctx.compact_targets(torch.from_numpy(rows).cuda(), int(keep.sum()) - 5).cpu().numpy()  # too small: dropped
+    np.testing.assert_array_equal(tight, rows[keep][:keep.sum() - 5])
+    ctx.map_set(scans[0])
+    a = ctx.register(torch.from_numpy(rows).cuda(), None, skip_null=True)
+    b = ctx.register(torch.from_numpy(got).cuda(), None, skip_null=True)
+    assert a.num_targets == b.num_targets == int(keep.sum())
+    np.testing.assert_allclose(a.pose, b.pose, atol=1e-6)  # (another grouping of the rows into partial sums)
+
+
+@pytest.mark.parametrize("threshold", [1.0e-4, 1.0e-3])
+def test_chunked_launch_equals_the_full_launch(torch_cuda, threshold):
+    """A launched registration with a live stop threshold is enqueued in chunks (first chunk = the iterations of the last
+    frame + 1; `icp_register_end` adds chunks while the loop runs).  Same poses, losses and iteration counts, bit for bit,
+    as with every iteration enqueued up front — over frames whose iteration counts go up and down — and the pose-only
+    map update by the device pose still follows the END of the registration."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 10)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    kw = dict(height=32, width=1024, max_num_alignments=20, threshold_delta_pose=threshold, scheme="geman_mcclure",
+              sigma=0.3)
+    dscans = [torch.from_numpy(s).cuda() for s in scans]
+    runs = {}
+    for chunked in (1, 0):
+        ctx = IcpContext(**kw)
+        ctx.set_option("chunked_launch", chunked)
+        ctx.map_set(model)
+        out, last = [], None
+        for f in (4, 5, 9, 6, 7):  # (9: a jump, more iterations than the frame before; 6: fewer again)
+            ctx.register_launch(dscans[f], last if f != 9 else None)
+            ctx.map_update(None, None)
+            r = ctx.register_end()
+            out.append(r)
+            last = r.pose
+        runs[chunked] = (out, ctx.map_points())
+    iters = [r.iterations for r in runs[1][0]]
+    assert min(iters) < max(iters) < 20, iters
+    for a, b in zip(*[runs[k][0] for k in (1, 0)]):
+        assert a.iterations == b.iterations and a.converged == b.converged
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.losses, b.losses) and np.array_equal(a.dx, b.dx)
+    np.testing.assert_array_equal(runs[1][1], runs[0][1])
