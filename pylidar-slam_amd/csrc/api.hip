@@ -469,11 +469,9 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
     if ((rc = export_target(ctx, indices_out, (size_t)n * 8, out_mem, ctx->stage_out, &idev))) return rc;
     if ((rc = export_target(ctx, points_out, (size_t)n * 12, out_mem, ctx->stage_out2, &pdev))) return rc;
     int* count_dev = ctx->counter.as<int>();
-    if ((rc = grid_sample_device(ctx, (const float*)in, n, voxel_size, (long long*)idev, (float*)pdev, count_dev)))
+    int count = 0;  // (read back inside: the sort of the distinct voxels is sized by it)
+    if ((rc = grid_sample_device(ctx, (const float*)in, n, voxel_size, (long long*)idev, (float*)pdev, count_dev, &count)))
         return rc;
-    int count = 0;
-    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *count_out = count;
     if ((rc = export_finish(ctx, indices_out, idev, (size_t)count * 8, out_mem))) return rc;
     if ((rc = export_finish(ctx, points_out, pdev, (size_t)count * 12, out_mem))) return rc;
@@ -543,11 +541,10 @@ int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, dou
     if ((rc = export_target(ctx, indices_out, (size_t)n * 8, out_mem, ctx->stage_out, &idev))) return rc;
     if ((rc = export_target(ctx, points_out, (size_t)n * 24, out_mem, ctx->stage_out2, &pdev))) return rc;
     int* count_dev = ctx->counter.as<int>();
-    if ((rc = grid_sample_f64_device(ctx, (const double*)in, n, voxel_size, (long long*)idev, (double*)pdev, count_dev)))
-        return rc;
     int count = 0;
-    ICP_HIP(ctx, hipMemcpyAsync(&count, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = grid_sample_f64_device(ctx, (const double*)in, n, voxel_size, (long long*)idev, (double*)pdev, count_dev,
+                                     &count)))
+        return rc;
     *count_out = count;
     if ((rc = export_finish(ctx, indices_out, idev, (size_t)count * 8, out_mem))) return rc;
     if ((rc = export_finish(ctx, points_out, pdev, (size_t)count * 24, out_mem))) return rc;

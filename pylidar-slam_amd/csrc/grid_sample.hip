@@ -7,8 +7,8 @@
 //
 //   voxel  = int64(round_half_even(double(p) / voxel_size))      numba promotes f32 / f64 to f64
 //   hash   = 73856093 x + 19349669 y + 83492791 z                wrapping int64
-//   sort (hash, index) by hash — stable LSD radix sort, so equal hashes keep ascending index — keep run heads.
-// The sort is rocPRIM's device radix sort (a library primitive); everything else is hand-written.
+//   dedupe (hash -> smallest index) through a hash table, then sort the V distinct (hash, index) pairs by hash.
+// The sort of the V pairs is rocPRIM's device radix sort (a library primitive); everything else is hand-written.
 #include <cmath>
 #include <cstring>
 #include <string.h>
@@ -79,50 +79,201 @@ int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxe
     return ICP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The sample of a voxel is the point with the smallest index among those that share its hash: a DEDUPE, then a sort of
+// the V << n distinct hashes (a 64x2048 scan at 0.4 m: 131 072 points, ~6 000 voxels).  Round 2 sorted all n (hash,
+// index) pairs (rocPRIM, 64-bit keys: ~75 of the op's ~100 us at n = 131 072, profiles/r03_secondary_*).
+//   1. k_hash_dedupe: every point claims the slot of its hash in an open-addressing table (atomicCAS on the key) and
+//      lowers the slot's index (atomicMin); consecutive points mostly share their voxel, so a wave first groups its
+//      lanes by hash (ballots) and only the group leaders — carrying the group's smallest index — touch memory;
+//   2. k_hash_collect: the occupied slots -> dense (hash ^ sign bit, index) pairs, appended wave by wave (the order does
+//      not matter: they are sorted next);
+//   3. rocPRIM radix sort of the V pairs by signed hash;  4. k_emit_sorted: indices + gathered points.
+// The empty-slot sentinel is a key value no slot ever stores: the one hash equal to it goes to a side cell.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr unsigned long long DEDUPE_EMPTY = ~0ull;
+
+struct DedupeSlot {
+    unsigned long long key;
+    int idx;
+    int pad;
+};
+
+__global__ void k_dedupe_clear(DedupeSlot* __restrict__ table, unsigned int size, int* __restrict__ side) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < size) {
+        DedupeSlot e;
+        e.key = DEDUPE_EMPTY;
+        e.idx = 0x7fffffff;
+        e.pad = 0;
+        table[i] = e;
+    }
+    if (i == 0) {
+        side[0] = 0x7fffffff;  // smallest index with hash == DEDUPE_EMPTY
+        side[1] = 0;           // pairs collected
+    }
+}
+
+template <typename T>
+__global__ void k_hash_dedupe(const T* __restrict__ xyz, int n, double voxel, DedupeSlot* __restrict__ table,
+                              unsigned int mask, int* __restrict__ side) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    unsigned long long h = 0;
+    if (active) {
+        const long long vx = voxel_coord(xyz[3 * i], voxel), vy = voxel_coord(xyz[3 * i + 1], voxel),
+                        vz = voxel_coord(xyz[3 * i + 2], voxel);
+        h = 73856093ull * (unsigned long long)vx + 19349669ull * (unsigned long long)vy +
+            83492791ull * (unsigned long long)vz;
+    }
+    // lanes of the wave with the same hash: the lowest lane holds the smallest index (indices ascend with the lane)
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    bool leader = false;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const unsigned lo = __shfl((unsigned)(h & 0xffffffffull), l, 64), hi = __shfl((unsigned)(h >> 32), l, 64);
+        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        const unsigned long long same = __ballot(active && h == k);
+        if (lane == l) leader = true;
+        todo &= ~same;
+    }
+    if (!leader) return;
+    if (h == DEDUPE_EMPTY) {
+        atomicMin(&side[0], i);
+        return;
+    }
+    unsigned long long x = h;  // slot from a mixed copy of the hash (its low bits alone cluster: small multiples)
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    unsigned int slot = (unsigned int)x & mask;
+    while (true) {
+        const unsigned long long old = atomicCAS(&table[slot].key, DEDUPE_EMPTY, h);
+        if (old == DEDUPE_EMPTY || old == h) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&table[slot].idx, i);
+}
+
+// (a few large workgroups, ONE atomicAdd each: with one per wave — ~3 000 same-address device-scope atomics at 131 072
+// points, ~16 ns apiece — this kernel alone took 52 us)
+static constexpr int COLLECT_THREADS = 1024;
+static constexpr int COLLECT_BLOCKS = 64;
+
+__global__ __launch_bounds__(COLLECT_THREADS) void k_hash_collect(const DedupeSlot* __restrict__ table,
+                                                                  unsigned int size, int* __restrict__ side,
+                                                                  unsigned long long* __restrict__ keys,
+                                                                  int* __restrict__ vals) {
+    __shared__ int wave_tot[COLLECT_THREADS / 64];
+    __shared__ int base_s;
+    // slots [lo, hi) of this workgroup; the side cell (hash == DEDUPE_EMPTY) rides as slot `size`
+    const unsigned int total = size + 1u;
+    const unsigned int per = (total + COLLECT_BLOCKS - 1) / COLLECT_BLOCKS;
+    const unsigned int lo = blockIdx.x * per, hi = min(lo + per, total);
+    int mine = 0;
+    for (unsigned int i = lo + threadIdx.x; i < hi; i += COLLECT_THREADS)
+        mine += (i < size) ? (table[i].key != DEDUPE_EMPTY ? 1 : 0) : (side[0] != 0x7fffffff ? 1 : 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = incl - mine, tot = 0;
+    for (int w = 0; w < COLLECT_THREADS / 64; ++w) {
+        if (w < wave) off += wave_tot[w];
+        tot += wave_tot[w];
+    }
+    if (threadIdx.x == 0) base_s = tot > 0 ? atomicAdd(&side[1], tot) : 0;
+    __syncthreads();
+    int o = base_s + off;
+    for (unsigned int i = lo + threadIdx.x; i < hi; i += COLLECT_THREADS) {
+        if (i < size) {
+            const DedupeSlot e = table[i];
+            if (e.key == DEDUPE_EMPTY) continue;
+            keys[o] = e.key ^ 0x8000000000000000ull;  // signed order under an unsigned sort
+            vals[o] = e.idx;
+            ++o;
+        } else if (side[0] != 0x7fffffff) {
+            keys[o] = DEDUPE_EMPTY ^ 0x8000000000000000ull;
+            vals[o] = side[0];
+            ++o;
+        }
+    }
+}
+
+template <typename T>
+__global__ void k_emit_sorted(const T* __restrict__ xyz, const int* __restrict__ vals, const int* __restrict__ count,
+                              long long* __restrict__ indices, T* __restrict__ points) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= *count) return;
+    const int src = vals[o];
+    if (indices) indices[o] = src;
+    if (points) {
+        points[3 * o] = xyz[3 * src];
+        points[3 * o + 1] = xyz[3 * src + 1];
+        points[3 * o + 2] = xyz[3 * src + 2];
+    }
+}
+
 template <typename T>
 static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                            T* points_dev, int* count_dev) {
+                            T* points_dev, int* count_dev, int* count_host) {
+    *count_host = 0;
     if (n <= 0) {
         ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
         return ICP_OK;
     }
-    ICP_HIP(ctx, ctx->keys_a.reserve((size_t)n * 8));
-    ICP_HIP(ctx, ctx->keys_b.reserve((size_t)n * 8));
+    unsigned int tsize = 1024;
+    while ((int64_t)tsize < 2 * n) tsize <<= 1;
+    ICP_HIP(ctx, ctx->keys_a.reserve((size_t)tsize * sizeof(DedupeSlot)));  // the table
+    ICP_HIP(ctx, ctx->keys_b.reserve((size_t)n * 8));                        // at most n distinct hashes
     ICP_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
     ICP_HIP(ctx, ctx->vals_b.reserve((size_t)n * 4));
-    ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
-    ICP_HIP(ctx, ctx->scan_a.reserve((size_t)n * 4));
-    unsigned long long* ka = ctx->keys_a.as<unsigned long long>();
-    unsigned long long* kb = ctx->keys_b.as<unsigned long long>();
+    ICP_HIP(ctx, ctx->scan_a.reserve((size_t)n * 8));                        // sorted keys
+    ICP_HIP(ctx, ctx->flags.reserve(64));
+    DedupeSlot* table = ctx->keys_a.as<DedupeSlot>();
+    unsigned long long* ka = ctx->keys_b.as<unsigned long long>();
+    unsigned long long* kb = ctx->scan_a.as<unsigned long long>();
     int* va = ctx->vals_a.as<int>();
     int* vb = ctx->vals_b.as<int>();
+    int* side = ctx->flags.as<int>();
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_voxel_hash<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, (long long*)nullptr,
-                       (long long*)nullptr, ka, va);
+    hipLaunchKernelGGL(k_dedupe_clear, dim3((tsize + 255) / 256), dim3(256), 0, ctx->stream, table, tsize, side);
+    hipLaunchKernelGGL(k_hash_dedupe<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, table, tsize - 1,
+                       side);
+    hipLaunchKernelGGL(k_hash_collect, dim3(COLLECT_BLOCKS), dim3(COLLECT_THREADS), 0, ctx->stream, table, tsize, side,
+                       ka, va);
+    // the number of pairs is only known on the device: the host needs it to size the sort (and returns it anyway)
+    int v = 0;
+    ICP_HIP(ctx, hipMemcpyAsync(&v, side + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ICP_HIP(ctx, hipMemcpyAsync(count_dev, side + 1, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    *count_host = v;
+    if (v <= 0) return ICP_OK;
     size_t tmp_bytes = 0;
-    ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64, ctx->stream));
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)v, 0, 64, ctx->stream));
     ICP_HIP(ctx, ctx->sort_tmp.reserve(tmp_bytes));
-    ICP_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ka, kb, va, vb, (size_t)n, 0, 64,
+    ICP_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ka, kb, va, vb, (size_t)v, 0, 64,
                                            ctx->stream));
-    int* flags = ctx->flags.as<int>();
-    int* offs = ctx->scan_a.as<int>();
-    hipLaunchKernelGGL(k_run_heads, dim3(nb), dim3(256), 0, ctx->stream, kb, (int)n, flags);
-    int rc = exclusive_scan_i32(ctx, flags, offs, n, count_dev);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_emit_samples<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, vb, flags, offs, (int)n,
-                       indices_dev, points_dev);
+    hipLaunchKernelGGL(k_emit_sorted<T>, dim3((unsigned)((v + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, vb,
+                       count_dev, indices_dev, points_dev);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
 
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                       float* points_dev, int* count_dev) {
-    return grid_sample_impl<float>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev);
+                       float* points_dev, int* count_dev, int* count_host) {
+    return grid_sample_impl<float>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host);
 }
 
 int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                           double* points_dev, int* count_dev) {
-    return grid_sample_impl<double>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev);
+                           double* points_dev, int* count_dev, int* count_host) {
+    return grid_sample_impl<double>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

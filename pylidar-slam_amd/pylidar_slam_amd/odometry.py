@@ -816,13 +816,14 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             return
         initial_estimate = self._initial_pose(data_dict)
         targets, skip_null = self.sample_points()
+        want_rows = "distorted" not in data_dict  # (:210-213: the de-skewed frame stands in for `_tgt_pc` when there is one)
+        rows_ready = self._rows_event() if want_rows else None  # (recorded BEFORE the registration is enqueued)
         if self._projective:
             params, pose, _ = self.register_new_frame(targets, initial_estimate, skip_null=skip_null)
-            tgt_np_pc = data_dict["distorted"] if "distorted" in data_dict else self._finish_rows(self._start_rows())
+            tgt_np_pc = self._rows_to_host(rows_ready) if want_rows else data_dict["distorted"]
         else:
-            rows_job = None if "distorted" in data_dict else self._start_rows()  # (a device frame: copy on a side stream)
             self.ctx.register_launch(targets, initial_estimate, skip_null=skip_null)
-            tgt_np_pc = data_dict["distorted"] if rows_job is None else self._finish_rows(rows_job)  # GPU busy meanwhile
+            tgt_np_pc = self._rows_to_host(rows_ready) if want_rows else data_dict["distorted"]  # GPU busy meanwhile
             res = self.ctx.register_end()  # raises before the map is touched (:286)
             self.last_result = res
             params, pose = res.params, res.pose
@@ -868,47 +869,48 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         main.wait_event(self._pin_in_free)
         return dev
 
-    def _start_rows(self):
-        """Begins producing `odometry_pc` = the frame's points as a host array (`self._tgt_pc.cpu().numpy()`, :213).
-        A numpy frame already is on the host; a tensor frame is copied device -> pinned memory on a side stream that
-        waits for what has been enqueued so far (the frame exists) and NOT for the registration enqueued next."""
+    def _rows_event(self):
+        """Marks, on the registration stream, the point from which the frame's device rows exist — so that their copy to
+        the host can wait for THAT and not for the registration enqueued right after it."""
+        if self._host_rows is not None or not self._tgt_pc.is_cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _rows_to_host(self, ready) -> np.ndarray:
+        """`odometry_pc` = the frame's points as a host array (`self._tgt_pc.cpu().numpy()`, :213; for a vertex-map frame
+        its non-null pixels, :342-344; rows with a NaN removed, :357).  A numpy frame already is on the host.  A tensor
+        frame is filtered on the device and copied into pinned memory on a side stream that waits for `ready` only: the
+        host blocks in here while the GPU runs the registration (a numpy filter over 131 072 x 3 values took 2-3 ms per
+        frame, on the critical path of the projective loop)."""
         if self._host_rows is not None:
-            return ("host", self._host_rows)
+            a = self._host_rows
+            if not np.isnan(a).any():
+                return a.copy()  # a fresh array per frame, like the reference's
+            return a[~np.isnan(a).any(axis=1)]
         pc = self._tgt_pc
-        if not pc.is_cuda:
-            return ("host_pixels" if self._pc_is_pixels else "host", pc.numpy().reshape(-1, 3))
-        n = int(pc.shape[0])
-        if self._pin_out is None or self._pin_out.shape[0] < n:
-            self._pin_out = torch.empty((max(n, 1), 3), dtype=torch.float32, pin_memory=True)
+        if not pc.is_cuda:  # (tensor placement only — the host logic is exercised without a GPU in tests/)
+            a = pc.numpy().reshape(-1, 3)
+            keep = ~np.isnan(a).any(axis=1)
+            if self._pc_is_pixels:
+                keep &= np.abs(a).max(axis=1) > 0
+            return a.copy() if keep.all() else a[keep]
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         side = self._copy_stream
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        done = torch.cuda.Event()
+        side.wait_event(ready)
         with torch.cuda.stream(side):
-            self._pin_out[:n].copy_(pc, non_blocking=True)
-            done.record(side)
-        return ("device", done, n)
-
-    def _finish_rows(self, job) -> np.ndarray:
-        if job[0] == "host":
-            a = job[1]
-            if not np.isnan(a).any():
-                return a.copy()  # a fresh array per frame, like the reference's (:213)
-            return a[~np.isnan(a).any(axis=1)]
-        if job[0] == "host_pixels":
-            a = job[1]
-        else:
-            _, done, n = job
-            done.synchronize()
-            a = self._pin_out[:n].numpy()
-        keep = None
-        if np.isnan(a).any():
-            keep = ~np.isnan(a).any(axis=1)
-        if self._pc_is_pixels:  # vertex-map input: `_tgt_pc` = the non-null pixels (:342-344)
-            nz = np.abs(a).max(axis=1) > 0
-            keep = nz if keep is None else keep & nz
-        return a.copy() if keep is None or keep.all() else a[keep]
+            keep = ~torch.isnan(pc).any(dim=1)
+            if self._pc_is_pixels:
+                keep &= pc.abs().amax(dim=1) > 0
+            rows = pc[keep]  # (synchronises the side stream only)
+            n = int(rows.shape[0])
+            if self._pin_out is None or self._pin_out.shape[0] < n:
+                self._pin_out = torch.empty((max(n, 1), 3), dtype=torch.float32, pin_memory=True)
+            self._pin_out[:n].copy_(rows, non_blocking=True)
+            side.synchronize()
+        return self._pin_out[:n].numpy().copy()
 
     def __update_map(self, new_rpose: np.ndarray):  # :360-380
         new_delta = (self._delta_since_map_update @ new_rpose).astype(np.float32)
