@@ -19,6 +19,9 @@ ICPFrameToModelConfig / KdTreeLocalMapConfig: 1e-4, 0.1 m / 0.3 deg, 10.)  36 se
 drive (pylidar_slam_amd.synthetic, 0.4 m and 0.01 rad per frame): the local map takes a new key frame on every frame
 and, from frame 30 on, evicts the oldest one (local_map.py:350-360).
 
+A second run of the same loop with the stop test off (threshold 0, exactly 6 iterations per frame) is stored next to it
+(`forced_*`): per-frame poses that do not hinge on a threshold decision.
+
 Stored: per-frame relative poses, iteration counts and final losses, the inserted-cloud sizes, the trajectory metrics of
 the reference's own slam/eval/eval_odometry.py (ATE / ARE on the relative poses; the KITTI segment error with segment
 lengths scaled to a 14 m drive: 2, 4, 6, 8 m) against the generator's ground truth, sha1 of every input scan, and the
@@ -50,6 +53,7 @@ from slam.slam import SLAM, SLAMConfig  # noqa: E402
 from pylidar_slam_amd.synthetic import SceneConfig, make_sequence  # noqa: E402
 
 H, W, FRAMES = 64, 2048, 36
+FORCED_ITERS = 6
 SEGMENTS = [2.0, 4.0, 6.0, 8.0]
 OUT = os.path.join(ROOT, "tests", "golden", "loop_reference.npz")
 
@@ -72,12 +76,8 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def main():
-    # GridSample of the reference: numba types the f32 / f64 division as f64 (slam/common/pointcloud.py:73-75); under
-    # the pure-Python numba stub the harness feeds float64 copies (exact), as oracle/make_golden.py does
-    pp.voxelise = lambda pc, a, b, c: voxelise(pc.astype(np.float64), a, b, c)
-    scans, gt_abs = make_sequence(SceneConfig(height=H, width=W), FRAMES)
-    cfg = OmegaConf.create({"slam": PUBLISHED})
+def run_loop(scans, gt_abs, published, tag):
+    cfg = OmegaConf.create({"slam": published})
     slam = SLAM(SLAMConfig(**cfg.slam), projector=SphericalProjector(H, W, 3, 3.0, -24.0), pose=Pose("euler"),
                 device=torch.device("cpu"), viz_num_pointclouds=1)
     slam.init()
@@ -113,14 +113,34 @@ def main():
     ate, ate_std = E.compute_ate(rel, gt_rel)
     are, are_std = E.compute_are(rel, gt_rel)
     tr, rot, errors = E.compute_kitti_metrics(est_abs, gt0, SEGMENTS)
-    out = dict(hw=np.array([H, W]), scan_sha=np.array([sha(s) for s in scans]), gt_abs=gt_abs, rel=rel.astype(np.float32),
-               iters=np.array(trace["iters"]), loss=np.array(trace["loss"]), samples=np.array(samples),
-               map_sizes=np.array(map_sizes), ate=np.array([ate, ate_std]), are=np.array([are, are_std]),
-               kitti=np.array([tr, rot]), segments=np.array(SEGMENTS), num_segments=np.int64(len(errors)),
-               reference_seconds_per_frame=np.array(seconds), reference_threads=np.int64(torch.get_num_threads()))
-    np.savez_compressed(OUT, **out)
-    print(f"ATE {ate:.3e} +- {ate_std:.1e} m, ARE {are:.3e}, tr_err {tr:.3e} m/m, r_err {rot:.3e} rad/m over "
+    out = dict(rel=rel.astype(np.float32), iters=np.array(trace["iters"]), loss=np.array(trace["loss"]),
+               samples=np.array(samples), map_sizes=np.array(map_sizes), ate=np.array([ate, ate_std]),
+               are=np.array([are, are_std]), kitti=np.array([tr, rot]), num_segments=np.int64(len(errors)),
+               reference_seconds_per_frame=np.array(seconds))
+    print(f"[{tag}] ATE {ate:.3e} +- {ate_std:.1e} m, ARE {are:.3e}, tr_err {tr:.3e} m/m, r_err {rot:.3e} rad/m over "
           f"{len(errors)} segments; reference median {np.median(seconds[1:]) * 1e3:.0f} ms per frame (1 torch thread)")
+    return out
+
+
+def main():
+    # GridSample of the reference: numba types the f32 / f64 division as f64 (slam/common/pointcloud.py:73-75); under
+    # the pure-Python numba stub the harness feeds float64 copies (exact), as oracle/make_golden.py does
+    pp.voxelise = lambda pc, a, b, c: voxelise(pc.astype(np.float64), a, b, c)
+    scans, gt_abs = make_sequence(SceneConfig(height=H, width=W), FRAMES)
+    out = dict(hw=np.array([H, W]), scan_sha=np.array([sha(s) for s in scans]), gt_abs=gt_abs,
+               segments=np.array(SEGMENTS), reference_threads=np.int64(torch.get_num_threads()))
+    out.update(run_loop(scans, gt_abs, PUBLISHED, "published"))
+    # the same loop with the stop test switched off (threshold 0, exactly FORCED_ITERS iterations per frame): a run whose
+    # per-frame poses do not hinge on a `|dx| < 1e-4` decided within float32 noise of the threshold (such a flip moves a
+    # frame — and, through the map and the constant-velocity guess, its successors — by up to the threshold itself,
+    # whoever evaluates the loop: another CPU code path of the reference included)
+    import copy
+    forced = copy.deepcopy(PUBLISHED)
+    forced["odometry"]["max_num_alignments"] = FORCED_ITERS
+    forced["odometry"]["threshold_delta_pose"] = 0.0
+    out.update({f"forced_{k}": v for k, v in run_loop(scans, gt_abs, forced, "forced").items()})
+    out["forced_iters_per_frame"] = np.int64(FORCED_ITERS)
+    np.savez_compressed(OUT, **out)
 
 
 if __name__ == "__main__":

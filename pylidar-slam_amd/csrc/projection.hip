@@ -6,6 +6,7 @@
 // (range bits << 32 | ~index) per pixel, then a resolve pass gathers the winner: nearest point wins, equal ranges go to
 // the highest point index (the outcome of a stable descending sort + last-write-wins).
 #include "icp_internal.h"
+#include "projection_device.h"
 
 namespace icp {
 
@@ -15,9 +16,11 @@ struct ProjParams {
     float fov;           // |down| + |up| in rad
 };
 
-// float pixel coordinates, float32 operations in the reference's order (:52-73)
+// float pixel coordinates, float32 operations in the reference's order (:52-73).  `exact`: the angles correctly rounded
+// everywhere (the diagnostic output); otherwise only where the rounding to a pixel could depend on them
+// (projection_device.h)
 __device__ inline void spherical_pixel(float x, float y, float z, const ProjParams& pp, float& row, float& col,
-                                       float& range) {
+                                       float& range, bool exact = false) {
     const float r_raw = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
     range = r_raw;
     if (r_raw == 0.0f) {  // mask_0: row = col = -1 (:55-57,:73)
@@ -25,12 +28,10 @@ __device__ inline void spherical_pixel(float x, float y, float z, const ProjPara
         col = -1.0f;
         return;
     }
-    const float theta = -atan2f(y, x);                                            // :64
-    const float phi = asinf(z / r_raw);                                           // :65
-    const float pc = 0.5f * (theta / 3.14159265358979323846f + 1.0f);             // :67
-    const float pr = 1.0f - (phi + pp.fov_down_abs) / pp.fov;                     // :68
-    col = pc * (float)pp.width;                                                   // :70
-    row = pr * (float)pp.height;                                                  // :71
+    if (exact)
+        spherical_rowcol(x, y, z, r_raw, pp.fov_down_abs, pp.fov, pp.height, pp.width, true, row, col);
+    else
+        spherical_rowcol_for_rounding(x, y, z, r_raw, pp.fov_down_abs, pp.fov, pp.height, pp.width, row, col);
 }
 
 __global__ void k_zbuf_clear(unsigned long long* __restrict__ zbuf, int npix) {
@@ -80,7 +81,7 @@ __global__ void k_project_pixels(const float* __restrict__ xyz, int n, ProjParam
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float row, col, r;
-    spherical_pixel(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], pp, row, col, r);
+    spherical_pixel(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], pp, row, col, r, true);
     rows[i] = row;
     cols[i] = col;
 }

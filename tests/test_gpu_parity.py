@@ -38,19 +38,47 @@ def test_library_loaded_is_in_tree(torch_cuda):
 
 
 def test_projection(torch_cuda, O, golden_components):
+    """Pixel coordinates and the vertex map against the reference's own (tests/golden/components.npz).
+
+    The float coordinates agree to a few ulp; the INTEGER pixel of a point is the rounding of that float, so a point whose
+    coordinate sits within those few ulp of x.5 is a coin toss — in the reference itself: its own CPU code paths
+    (AVX2 / AVX512 Sleef vs scalar libm) disagree on 2 % of the coordinates by up to 2.3e-5 pixel
+    (tests/golden/projection_spread.npz, oracle/make_golden_projection_spread.py).  The bound proven here: every point
+    the HIP kernel assigns to another pixel than the reference did has its REFERENCE coordinate within the band (4 ulp, or
+    1.5 x the reference's own spread on this cloud) of a half-integer, and the vertex map differs from the reference's only at pixels such a point leaves or enters."""
+    import os
+    from conftest import GOLDEN
     g = golden_components
     h, w = (int(v) for v in g["proj_hw"])
     up, down = (float(v) for v in g["proj_fov"])
     ctx = _ctx(height=h, width=w, up_fov=up, down_fov=down)
     rows, cols = ctx.project_pixels(g["proj_pc"])
-    np.testing.assert_allclose(rows, g["proj_pixels"][:, 0], atol=2e-4)
-    np.testing.assert_allclose(cols, g["proj_pixels"][:, 1], atol=2e-3)
+    ref_r, ref_c = g["proj_pixels"][:, 0], g["proj_pixels"][:, 1]
+    spread = np.load(os.path.join(GOLDEN, "projection_spread.npz"))
+    own = max(float(spread[k]) for k in spread.files if k.startswith("small_") and k.endswith("max_pixel_difference"))
+    # the band: 4 ulp of the largest coordinate, and no tighter than 1.5 x what the reference's own code paths differ by
+    # on this very cloud (2.3e-5: the cancellation in 1 - (phi + fov_down) / fov carries asin's last bit into the row)
+    band_r = band_c = max(4 * float(np.spacing(np.float32(max(h, w)))), 1.5 * own)
+    assert own > 0.0
+    np.testing.assert_allclose(rows, ref_r, atol=band_r)
+    np.testing.assert_allclose(cols, ref_c, atol=band_c)
+    print(f"projection: max |d row| {np.abs(rows - ref_r).max():.2e} (band {band_r:.1e}), max |d col| "
+          f"{np.abs(cols - ref_c).max():.2e} (band {band_c:.1e}); the reference differs from itself by up to {own:.2e}")
     vmap, idx = ctx.project(g["proj_pc"], with_index=True)
-    # vs the reference's own vertex map: identical except where 1-ulp libm differences flip a half-pixel rounding
-    mism_ref = (np.abs(vmap - g["proj_vmap"]).max(axis=0) > 0).sum()
-    assert mism_ref <= 2, mism_ref
+    # points that land in another pixel than in the reference's run: each one a coin toss by the criterion above
+    moved = (np.rint(rows) != np.rint(ref_r)) | (np.rint(cols) != np.rint(ref_c))
+    toss = (np.abs(ref_r - np.floor(ref_r) - 0.5) < band_r) | (np.abs(ref_c - np.floor(ref_c) - 0.5) < band_c)
+    assert not (moved & ~toss).any(), np.nonzero(moved & ~toss)[0]
+    assert moved.sum() <= 4
+    touched = np.zeros((h, w), bool)
+    for i in np.nonzero(moved)[0]:
+        for r_, c_ in ((np.rint(rows[i]), np.rint(cols[i])), (np.rint(ref_r[i]), np.rint(ref_c[i]))):
+            if 0 <= r_ < h and 0 <= c_ < w:
+                touched[int(r_), int(c_)] = True
+    differs = np.abs(vmap - g["proj_vmap"]).max(axis=0) > 0
+    assert not (differs & ~touched).any(), np.argwhere(differs & ~touched)
     ovmap, oidx = O.build_projection_map(g["proj_pc"], h, w, up, down, return_index=True)
-    assert (idx != oidx).sum() <= 2
+    assert (idx != oidx).sum() <= 2 * max(1, int(moved.sum())) + 2  # (the oracle rounds numpy's libm values: its own tosses)
     # device-resident variant gives the same bits
     t = torch_cuda.from_numpy(g["proj_pc"]).cuda()
     dv = ctx.project(t)

@@ -57,10 +57,12 @@ def trajectory_metrics(rel, gt_abs, segments):
 
 def test_fixture_metrics_are_reproduced_by_eval(golden_loop):
     g = golden_loop
-    ate, are, tr, rot, n = trajectory_metrics(g["rel"], g["gt_abs"], g["segments"])
-    assert n == int(g["num_segments"]) > 0
-    np.testing.assert_allclose([ate, are], [g["ate"][0], g["are"][0]], rtol=1e-9)
-    np.testing.assert_allclose([tr, rot], g["kitti"], rtol=1e-9)
+    for pre in ("", "forced_"):
+        ate, are, tr, rot, n = trajectory_metrics(g[pre + "rel"], g["gt_abs"], g["segments"])
+        assert n == int(g[pre + "num_segments"]) > 0
+        np.testing.assert_allclose([ate, are], [g[pre + "ate"][0], g[pre + "are"][0]], rtol=1e-9)
+        np.testing.assert_allclose([tr, rot], g[pre + "kitti"], rtol=1e-9)
+    assert int(g["forced_iters"][1:].min()) == int(g["forced_iters"][1:].max()) == int(g["forced_iters_per_frame"])
     # the run the fixture holds: an insertion per frame, evictions from frame 30 on, live convergence well below the cap
     assert g["map_sizes"][29] > g["map_sizes"][30] and int(g["iters"][1:].max()) < 20 and g["ate"][0] < 5e-3
 
