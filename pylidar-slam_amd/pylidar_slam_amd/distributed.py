@@ -80,6 +80,10 @@ def sharded_map_normals(engine, group=None):
     use_dist = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if use_dist else 0
     world = dist.get_world_size(group) if use_dist else 1
+    if hasattr(engine, "set_option"):
+        # this driver estimates the map's normals, shard by shard: the library must not ALSO estimate all of them on
+        # every rank behind each map update (its schedule for maps of up to 2^20 points)
+        engine.set_option("eager_normals_limit", 0)
     shard = engine.map_normals_owned(rank, world)
     if use_dist:
         dist.all_reduce(shard, op=dist.ReduceOp.SUM, group=group)

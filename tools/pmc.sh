@@ -2,7 +2,7 @@
 # HBM traffic of the dominant kernel from PMC counters (separate passes, --kernel-trace only; MI355X_MICROARCH.md §HBM)
 # usage: tools/pmc.sh <kernel-name-substring>  -> gpurun_out/pmc_<name>.json
 R=$PWD; K=${1:-k_iterate_compact}
-HEAD_SHA=$(cat $R/gpurun_out/.head_sha 2>/dev/null || echo unknown)
+HEAD_SHA=$(cat $R/tools/.head_sha 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 100 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-profile --loop-steps 0 > $R/gpurun_out/pmc_$C.log 2>&1
