@@ -70,10 +70,13 @@ static void prof_collect(icp_ctx* ctx) {
 }
 
 // ---- small kernels owned by the API layer ---------------------------------------------------------------------------
-__global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned long long* box, unsigned gen) {
+__global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned long long* box, unsigned gen,
+                             float* hist) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     state_init(st, init.m, keep_pose);
     if (box) box_publish_serial(box, gen, st->pose, 0, 0);  // generation `gen` of the pose mailbox: the initial guess
+    if (hist)
+        for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // pose history, entry 0
 }
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
@@ -175,6 +178,8 @@ static int ensure_state(icp_ctx* ctx) {
         ICP_HIP(ctx, hipMemsetAsync(ctx->state.ptr, 0, STATE_BLOCK, ctx->stream));
         ctx->loss_hist = (double*)(ctx->state.as<char>() + STATE_BLOCK);
         ctx->dx_hist = (float*)(ctx->state.as<char>() + STATE_BLOCK + (size_t)newcap * sizeof(double));
+        ICP_HIP(ctx, ctx->pose_hist_buf.reserve((size_t)(newcap + 1) * 12 * sizeof(float)));
+        ctx->pose_hist = ctx->pose_hist_buf.as<float>();
     }
     ICP_HIP(ctx, ctx->neq_own.reserve(NEQ * sizeof(double)));
     if (!ctx->neq) ctx->neq = ctx->neq_own.as<double>();
@@ -203,7 +208,7 @@ static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_
     const Pose16 p = pose_or_identity(init_pose);
     if (n > 0) return prepare_targets(ctx, ctx->tgt_ptr, n, &p, keep_pose);
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0,
-                       pose_box(ctx), next_box_generation(ctx));
+                       pose_box(ctx), next_box_generation(ctx), ctx->pose_hist);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
@@ -211,7 +216,7 @@ static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_
 static int init_state(icp_ctx* ctx, const float* init_pose, bool keep_pose = false) {
     const Pose16 p = pose_or_identity(init_pose);
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0,
-                       pose_box(ctx), next_box_generation(ctx));
+                       pose_box(ctx), next_box_generation(ctx), ctx->pose_hist);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -419,6 +419,7 @@ AlignParams make_align_params(const icp_ctx* ctx) {
     ap.sigma = ctx->cfg.sigma;
     ap.threshold_delta_pose = ctx->cfg.threshold_delta_pose;
     ap.max_iters = ctx->cfg.max_num_alignments;
+    ap.pose_hist = ctx->pose_hist;
     return ap;
 }
 

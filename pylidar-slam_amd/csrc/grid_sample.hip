@@ -455,11 +455,12 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 // in the iteration kernels.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __restrict__ out, RegState* st, Pose16 init,
-                               int keep_pose, unsigned long long* box, unsigned gen) {
+                               int keep_pose, unsigned long long* box, unsigned gen, float* hist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (st && i == 0) {
         state_init(st, init.m, keep_pose);  // the registration state, by the same launch
         box_publish_serial(box, gen, st->pose, 0, 0);  // ... and the initial guess as generation `gen` of the pose mailbox
+        for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // ... and as entry 0 of the pose history
     }
     if (i >= n) return;
     out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
@@ -473,7 +474,7 @@ int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16*
     if (init) p = *init;
     hipLaunchKernelGGL(k_pack_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
                        ctx->tgt4.as<float4>(), init ? reg_state(ctx) : (RegState*)nullptr, p, keep_pose ? 1 : 0,
-                       pose_box(ctx), init ? next_box_generation(ctx) : 0u);
+                       pose_box(ctx), init ? next_box_generation(ctx) : 0u, ctx->pose_hist);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -182,9 +182,9 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
         table[i] = e;
     }
     if ((int)i < seed_n) {
-        const int pos = nn_cache[i].x;
+        const int x = nn_cache[i].x, pos = x & 0xffffff;  // (.x = position | iteration << 24, search.hip)
         int o = -1;
-        if (pos >= 0 && pos < old_m) o = __float_as_int(old_pts[pos].w) - evicted;
+        if (x >= 0 && pos < old_m) o = __float_as_int(old_pts[pos].w) - evicted;
         seed[i] = o;
     }
     if (moves) {

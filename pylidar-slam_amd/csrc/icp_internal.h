@@ -198,6 +198,7 @@ struct AlignParams {
     float sigma;
     float threshold_delta_pose;
     int max_iters;
+    float* pose_hist;  // [iteration][12]: rows 0-2 of the pose every iteration of the registration runs with (NN cache)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -293,6 +294,8 @@ struct icp_ctx {
     icp::DeviceBuffer partials;        // double[2][blocks][NEQ]: two parities (a lead launch sums the rows of the previous launch while its own workgroups write theirs)
     size_t partials_half = 0;          // bytes of one parity
     int partials_parity = 0;           // parity the NEXT fused launch writes
+    icp::DeviceBuffer pose_hist_buf;   // float[hist_cap + 1][12]: pose history of the registration in progress
+    float* pose_hist = nullptr;
     icp::DeviceBuffer posebox;         // pose mailbox of the lead launches (BOX_BYTES)
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size

@@ -478,9 +478,13 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 // The kernel, with in-block compaction of the cache misses.
 //
 // NN cache (exact): a search leaves, besides the neighbour, a lower bound L on the distance to EVERY OTHER map point
-// (second-best candidate, box distance of every pruned cell, the bound of the last ring).  The target moved by delta
-// since, so every other point is still >= L - delta away: if the cached neighbour is strictly closer than that it is
-// still THE nearest neighbour and the search is skipped.
+// (second-best candidate, box distance of every pruned cell, the bound of the last ring) — and the iteration k it ran in.
+// The target has moved by delta = |T_now p - T_k p| since (T_k from the pose history of the registration), so every other
+// point is still >= L - delta away: if the cached neighbour is strictly closer than that it is still THE nearest
+// neighbour and the search is skipped.  (Round 2 subtracted the step of every iteration from L instead: a sum of
+// |steps| that keeps growing while the pose merely jitters around its fixed point — it eroded the slack of the same few
+// dozen boundary queries in every late iteration, and rewrote the 1 MB cache per launch to do so.  The displacement since
+// the search stops growing once the pose has converged, and a hit writes nothing.)
 // From the third iteration on most queries keep their neighbour, but a wave holds 16 queries
 // and runs the whole search path as soon as ONE of them misses: with a few per cent of misses nearly every wave still
 // paid for a search.  Here the block works in two phases:
@@ -496,12 +500,25 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 struct IterInputs {
     const float4* tgt;       // targets (x, y, z, row)
     const float4* normals;   // by cell-sorted position
-    int2* nn_cache;          // (position, bits(L)) per query
+    int2* nn_cache;          // (position | iteration of the search << 24, bits(L)) per query
+    const float* pose_hist;  // [iteration][12]: the pose every earlier iteration of this registration ran with
     const int* frame_seed;   // original map index per query or nullptr
     double* partials;
     int n, mode, max_rings, use_cache;
+    int iter;                // index of this iteration within the registration (0, 1, ..)
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
 };
+
+// cache entry .x = cell-sorted position of the neighbour | iteration of the search << 24 (-1: no neighbour); a position
+// needs 24 bits (maps of up to 16.7 M points use the cache), iterations wrap into 7 bits — harmlessly: an entry older
+// than CACHE_HIST launches is a miss
+static constexpr int CACHE_ITER_SHIFT = 24;
+static constexpr int CACHE_POS_MASK = (1 << CACHE_ITER_SHIFT) - 1;
+static constexpr int CACHE_HIST = 24;  // poses kept in LDS (1152 B: what the 128-query shape has left of its 40 KB)
+
+__device__ inline int pack_cache(int pos, int iteration) {
+    return pos < 0 ? -1 : (pos | ((iteration & 127) << CACHE_ITER_SHIFT));
+}
 
 // MINW = minimum waves per SIMD the register allocation must leave room for: 8 keeps all 4 blocks of a CU (the whole
 // 131 072-point scan) resident in one round at 64 VGPRs (some spilled dwords), 6 allows 80 VGPRs (3 blocks per CU, a
@@ -559,7 +576,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     __shared__ float4 miss_p[Q];   // transformed target + bits(query slot)
     __shared__ int4 miss_seed[Q];  // bits(seed d2), seed index, seed position
     __shared__ int nmiss;
-    __shared__ float pose_s[12], prev_s[12];  // rows 0-2 of the pose of this iteration and of the previous one
+    __shared__ float pose_s[12];               // rows 0-2 of the pose of this iteration
+    __shared__ float hist_s[CACHE_HIST][12];   // ... and of the CACHE_HIST iterations before it (slot = iteration % CACHE_HIST)
     __shared__ int ctl_s[4];                  // logical block | done | iteration | hand-off failures
     static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ) * sizeof(double), "the lead's scratch lives in the cell stacks");
     // In a lead launch (LeadArgs) workgroup 0 is the lead: it solves the previous iteration and publishes the pose the
@@ -597,8 +615,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             if (in.use_cache) {
                 c = in.nn_cache[qi];
                 if (c.x >= 0) {
-                    cq = g.pts[c.x];
-                    cn = in.normals[c.x];  // speculative: needed on a hit only
+                    cq = g.pts[c.x & CACHE_POS_MASK];
+                    cn = in.normals[c.x & CACHE_POS_MASK];  // speculative: needed on a hit only
                 }
             } else if (in.frame_seed) {
                 const int o = in.frame_seed[qi];
@@ -609,6 +627,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 }
             }
         }
+    }
+    // the poses of the last CACHE_HIST iterations, for the cache test (written by the solves of EARLIER launches: plain
+    // loads, requested before the wait below like everything else that does not need this launch's pose)
+    if (in.use_cache && (int)threadIdx.x < 12 * CACHE_HIST) {
+        const int e = threadIdx.x / 12, j = in.iter - 1 - e;  // iteration j, most recent first
+        if (j >= 0) hist_s[j % CACHE_HIST][threadIdx.x % 12] = in.pose_hist[(size_t)j * 12 + threadIdx.x % 12];
     }
     // ---- the pose: from the mailbox (lead launch) or from the RegState (classic launch)
     if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
@@ -630,27 +654,20 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             const unsigned bits = (unsigned)(v & 0xffffffffull);
             if (threadIdx.x < 12) pose_s[threadIdx.x] = __uint_as_float(bits);
             else ctl_s[threadIdx.x - 11] = (int)bits;  // 12 -> done, 13 -> iteration
-        } else if (threadIdx.x >= 64 && threadIdx.x < 76 && in.use_cache) {
-            // the pose of the previous launch (generation gen - 1, the other parity): what the cache bounds refer to
-            const int k = threadIdx.x - 64;
-            const unsigned long long v = __hip_atomic_load(box_granule(lead.box, lead.gen - 1u, vb % BOX_REPLICAS, k),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) != lead.gen - 1u) atomicAdd(&ctl_s[3], 1);
-            prev_s[k] = __uint_as_float((unsigned)(v & 0xffffffffull));
         }
     } else if (threadIdx.x < 12) {
         pose_s[threadIdx.x] = st->pose[threadIdx.x];
-        prev_s[threadIdx.x] = st->pose_prev[threadIdx.x];
         if (threadIdx.x == 0) ctl_s[2] = st->iter;
     }
     if (threadIdx.x == 0) nmiss = 0;
     __syncthreads();
+
     if (ctl_s[3]) {  // never seen: the hand-off did not arrive within its wall-clock budget -> a loud error, not a hang
         if (threadIdx.x == 0) atomicAdd(&st->handoff_timeouts, 1);
         return;
     }
     if (ctl_s[1]) return;  // the loop is finished (block-uniform)
-    const int iter_now = ctl_s[2];
+    const int iter_now = in.iter;  // (= the RegState's / the mailbox's iteration count while the loop is running)
     // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
     // counters
     long long* stamps = nullptr;
@@ -670,21 +687,22 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             int seed_idx = 0x7fffffff, seed_pos = -1;
             if (in.use_cache) {
                 if (c.x >= 0) {
-                    float ox, oy, oz;
-                    transform_point(prev_s, t4.x, t4.y, t4.z, ox, oy, oz);
-                    const float mx = px - ox, my = py - oy, mz = pz - oz;
-                    const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                    const float L = __int_as_float(c.y) - delta;
+                    const int k = (int)((unsigned)c.x >> CACHE_ITER_SHIFT), age = iter_now - k;  // searched `age` launches ago
                     const float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
                     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    hit = sqrtf(d2) * 1.000001f < L;
-                    if (hit) {
-                        in.nn_cache[qi] = make_int2(c.x, __float_as_int(L));
+                    if (age >= 1 && age <= CACHE_HIST) {
+                        float ox, oy, oz;  // where the target was when its neighbour was searched
+                        transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
+                        const float mx = px - ox, my = py - oy, mz = pz - oz;
+                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta;
+                    }
+                    if (hit) {  // (nothing to write: the entry stays as the search left it)
                         point_to_plane_row(px, py, pz, cq.x, cq.y, cq.z, cn.x, cn.y, cn.z, ap.scheme, ap.sigma, row);
                     } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
                         seed_d2 = d2;
                         seed_idx = __float_as_int(cq.w);
-                        seed_pos = c.x;
+                        seed_pos = c.x & CACHE_POS_MASK;
                     }
                 }
             } else if (seed_sp >= 0) {
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b)) continue;
             if (lane == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[q0 + lq] = make_int2(b.pos, __float_as_int(sqrtf(b.second) * 0.999999f));
+                in.nn_cache[q0 + lq] = make_int2(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f));
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -758,7 +776,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                                              THREADS, __int_as_float(ms.x), ms.y, ms.z);
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[q0 + lq] = make_int2(b.pos, __float_as_int(sqrtf(b.second) * 0.999999f));
+                in.nn_cache[q0 + lq] = make_int2(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f));
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -783,9 +801,9 @@ __global__ void k_cache_to_seed(const int2* __restrict__ nn_cache, const float4*
                                 int evicted, int* __restrict__ seed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int pos = nn_cache[i].x;
+    const int x = nn_cache[i].x, pos = x & CACHE_POS_MASK;
     int o = -1;
-    if (pos >= 0 && pos < m) o = __float_as_int(pts[pos].w) - evicted;
+    if (x >= 0 && pos < m) o = __float_as_int(pts[pos].w) - evicted;
     seed[i] = o;
 }
 
@@ -1622,14 +1640,19 @@ unsigned next_box_generation(icp_ctx* ctx) {
 
 // from iteration `narrow_from` on (few NN-cache misses expected) 512 queries per block, one lane each: a wrong guess costs
 // time only
+static int fused_cache_mode(const icp_ctx* ctx) {
+    // (positions share the cache word with the iteration tag: maps of 2^24 points and more search every iteration)
+    return (ctx->use_nn_cache && ctx->iter_in_registration > 0 && ctx->map_m < (1 << 24)) ? ctx->use_nn_cache : 0;
+}
+
 bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
-    const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
+    const int use_cache = fused_cache_mode(ctx);
     return use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
 }
 
 int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad) {
     const int n = (int)ctx->tgt_n;
-    const int use_cache = (ctx->use_nn_cache && ctx->iter_in_registration > 0) ? ctx->use_nn_cache : 0;
+    const int use_cache = fused_cache_mode(ctx);
     const bool narrow = next_fused_launch_is_narrow(ctx);
     const int per_block = narrow ? IT_THREADS : IT_QUERIES;
     const int blocks = n > 0 ? (n + per_block - 1) / per_block : 1;
@@ -1646,6 +1669,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.tgt = ctx->tgt4.as<float4>();
     in.normals = ctx->normals.as<float4>();
     in.nn_cache = ctx->nn_cache.as<int2>();
+    in.pose_hist = ctx->pose_hist;
     // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
     in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
                         ? ctx->seed_orig.as<int>() : nullptr;
@@ -1669,6 +1693,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     }
     const int grid = blocks + (lead_mode ? lead.solve : 0);
     in.n = n;
+    in.iter = ctx->iter_in_registration;
     in.mode = ctx->tgt_mode;
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;

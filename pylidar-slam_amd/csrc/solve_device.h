@@ -225,6 +225,7 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
                                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
                                         int it, const float* pose_in, const float* params_in,
                                         unsigned long long* __restrict__ box = nullptr, unsigned gen = 0) {
+    float* __restrict__ pose_hist = ap.pose_hist;
     SolveOut o;
     solve_core(neq, ap, it, pose_in, params_in, o);
     if (box) {  // the pose mailbox first (workgroups of this very launch may be polling for it), one granule per lane
@@ -250,6 +251,9 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
         for (int k2 = 0; k2 < 16; ++k2) st->pose_prev[k2] = pose_in[k2];
         for (int a = 0; a < 6; ++a) st->params[a] = o.params[a];
         for (int k2 = 0; k2 < 16; ++k2) st->pose[k2] = o.pose[k2];
+        // the pose iteration it + 1 runs with: the NN cache measures how far a target has moved since its search
+        if (pose_hist && it + 1 < hist_cap)
+            for (int k2 = 0; k2 < 12; ++k2) pose_hist[(size_t)(it + 1) * 12 + k2] = o.pose[k2];
     }
     if (o.done) st->done = 1;
 }
