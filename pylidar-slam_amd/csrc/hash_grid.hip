@@ -165,7 +165,7 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // cell-sorted positions still mean something, i.e. before the scatter of this build: it shares the first launch.
 // + (move.m > 0) the re-expression of the kept map points in the new frame (local_map.py:346-348): independent of the
 // other two, one launch less per frame.
-__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int2* __restrict__ nn_cache,
+__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
                              int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket) {
     __shared__ float T[16];
@@ -595,7 +595,7 @@ int build_grid(icp_ctx* ctx) {
         ctx->move_job = MapMoveJob();
         if (move.m > span) span = move.m;
         hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
-                           (unsigned int)n2, ctx->nn_cache.as<int2>(), ctx->sorted_pts.as<float4>(), seed_n,
+                           (unsigned int)n2, ctx->nn_cache.as<int4>(), ctx->sorted_pts.as<float4>(), seed_n,
                            ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket);
     }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,

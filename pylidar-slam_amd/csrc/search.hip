@@ -300,7 +300,13 @@ __device__ inline void wave_min64(Best& b) {
 // `wl` = 64 ints of LDS private to the wave.  Returns false (b undefined) when ring 2 does not settle the search either:
 // the caller hands the query to the generic 4-lane path (coarse level, exhaustive scan).
 __device__ inline bool search_rows_wave(const GridView& g, float px, float py, float pz, int lane, int max_rings,
-                                        int* __restrict__ wl, float seed_d2, int seed_idx, int seed_pos, Best& b) {
+                                        int* __restrict__ wl, float seed_d2, int seed_idx, int seed_pos, Best& b,
+                                        Best* runner = nullptr) {
+    // `runner` (optional): the SECOND nearest map point, with runner->second = a lower bound on the squared distance of
+    // every point other than the two — what lets the NN cache settle a query that sits between two map points by
+    // comparing the pair instead of searching again (pos = -1 when the search cannot name it cheaply: more than 128
+    // candidates, or not settled by ring 1)
+    if (runner) runner->pos = -1;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -334,12 +340,14 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
     b.pos = seed_pos;
     b.second = INFINITY;
     int cnt = 0;
+    float pruned_gap = INFINITY;  // this lane's pruned cell (if any): all its points are at least that far
     if (lane < 27) {
         const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h), gz = axis_gap(c / 9 - 1, fz, h);
         const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
         cnt = rc.y;
         if (cnt > 0 && gap2 > seed_d2) {
             b.second = gap2;  // every point of a pruned cell is at least that far
+            pruned_gap = gap2;
             cnt = 0;
         }
     }
@@ -358,6 +366,8 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;  // (the last trip's candidates stay around for the runner-up)
+    int pa = -1, pb = -1;
     for (int j0 = 0; j0 < total; j0 += 128) {
         const int ja = j0 + lane, jb = j0 + 64 + lane;
         int ca = 0, cb = 0;
@@ -366,17 +376,35 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
             if (wl[ca + s2] <= ja) ca += s2;
             if (wl[cb + s2] <= jb) cb += s2;
         }
-        const int pa = ja + wl[32 + ca], pb = jb + wl[32 + cb];
-        float4 qa, qb;
-        if (ja < total) qa = g.pts[pa];
-        if (jb < total) qb = g.pts[pb];
-        if (ja < total) consider(qa, pa, px, py, pz, b);
-        if (jb < total) consider(qb, pb, px, py, pz, b);
+        pa = ja < total ? ja + wl[32 + ca] : -1;
+        pb = jb < total ? jb + wl[32 + cb] : -1;
+        if (pa >= 0) qa = g.pts[pa];
+        if (pb >= 0) qb = g.pts[pb];
+        if (pa >= 0) consider(qa, pa, px, py, pz, b);
+        if (pb >= 0) consider(qb, pb, px, py, pz, b);
     }
     wave_min64(b);
     float bound = h + edge;
     if (b.d2 <= bound * bound * 0.999999f) {
         b.second = fminf(b.second, bound * bound * 0.999999f);  // nothing outside the 27-cell block is closer
+        if (runner && total <= 128 && b.pos >= 0) {
+            // every candidate is still in a register: the nearest of those that are not the winner, and what bounds the rest
+            Best r;
+            r.d2 = INFINITY;
+            r.idx = 0x7fffffff;
+            r.pos = -1;
+            r.second = pruned_gap;
+            if (pa >= 0 && __float_as_int(qa.w) != b.idx) consider(qa, pa, px, py, pz, r);
+            if (pb >= 0 && __float_as_int(qb.w) != b.idx) consider(qb, pb, px, py, pz, r);
+            if (seed_pos >= 0 && seed_idx != b.idx && lane == 0) {
+                // (the seed is a map point like any other; if a cell the box test pruned holds it, no lane has seen it)
+                const float4 qs = g.pts[seed_pos];
+                consider(qs, seed_pos, px, py, pz, r);
+            }
+            wave_min64(r);
+            r.second = fminf(r.second, bound * bound * 0.999999f);
+            *runner = r;
+        }
         return true;
     }
     if (max_rings < 2) return false;
@@ -500,7 +528,8 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 struct IterInputs {
     const float4* tgt;       // targets (x, y, z, row)
     const float4* normals;   // by cell-sorted position
-    int2* nn_cache;          // (position | iteration of the search << 24, bits(L)) per query
+    int4* nn_cache;          // per query: (position | iteration of the search << 24, bits(L), position of the runner-up
+                             // or -1, 0) — L bounds every map point other than the neighbour (and the runner-up, if named)
     const float* pose_hist;  // [iteration][12]: the pose every earlier iteration of this registration ran with
     const int* frame_seed;   // original map index per query or nullptr
     double* partials;
@@ -601,15 +630,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // are in flight while the lead workgroup solves
     const int lq = threadIdx.x, qi = q0 + lq;
     bool valid = false;
-    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq;
-    int2 c = make_int2(-1, 0);
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq, cq2 = cq, cn2 = cq;
+    int4 c = make_int4(-1, 0, -1, 0);
     int seed_o = -1, seed_sp = -1;
     if (lq < Q) {
         valid = qi < in.n;
         if (valid) {
             t4 = in.tgt[qi];
             valid = target_valid(t4.x, t4.y, t4.z, in.mode);
-            if (!valid && !in.use_cache) in.nn_cache[qi] = make_int2(-1, 0);  // masked row: no neighbour, no seed
+            if (!valid && !in.use_cache) in.nn_cache[qi] = make_int4(-1, 0, -1, 0);  // masked row: no neighbour, no seed
         }
         if (valid) {
             if (in.use_cache) {
@@ -617,6 +646,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 if (c.x >= 0) {
                     cq = g.pts[c.x & CACHE_POS_MASK];
                     cn = in.normals[c.x & CACHE_POS_MASK];  // speculative: needed on a hit only
+                    if (Q == THREADS && c.z >= 0) {         // the runner-up a whole-wave search named (late iterations)
+                        cq2 = g.pts[c.z];
+                        cn2 = in.normals[c.z];
+                    }
                 }
             } else if (in.frame_seed) {
                 const int o = in.frame_seed[qi];
@@ -688,8 +721,22 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             if (in.use_cache) {
                 if (c.x >= 0) {
                     const int k = (int)((unsigned)c.x >> CACHE_ITER_SHIFT), age = iter_now - k;  // searched `age` launches ago
-                    const float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
+                    float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    int hit_pos = c.x & CACHE_POS_MASK;
+                    if (Q == THREADS && c.z >= 0) {
+                        // a pair: the nearer of the two is THE neighbour as long as everything else (>= L) stays farther
+                        dx = cq2.x - px, dy = cq2.y - py, dz = cq2.z - pz;
+                        const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(cq.w))) {
+                            d2 = e2;
+                            cq = cq2;
+                            cn = cn2;
+                            hit_pos = c.z;
+                        }
+                    } else if (c.z >= 0) {
+                        c.y = 0;  // (a pair met by the 128-query shape — the shapes never alternate that way: a miss)
+                    }
                     if (age >= 1 && age <= CACHE_HIST) {
                         float ox, oy, oz;  // where the target was when its neighbour was searched
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
@@ -702,7 +749,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                     } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
                         seed_d2 = d2;
                         seed_idx = __float_as_int(cq.w);
-                        seed_pos = c.x & CACHE_POS_MASK;
+                        seed_pos = hit_pos;
                     }
                 }
             } else if (seed_sp >= 0) {
@@ -736,11 +783,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         for (int m = wave; m < listed; m += THREADS / 64) {
             const float4 mp = miss_p[m];
             const int4 ms = miss_seed[m];
-            Best b;
-            if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b)) continue;
+            Best b, r2;
+            if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b,
+                                  Q == THREADS ? &r2 : nullptr))
+                continue;
             if (lane == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[q0 + lq] = make_int2(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f));
+                // (512-query shape: the runner-up rides along, and L then bounds everything but the pair)
+                const bool pair = Q == THREADS && r2.pos >= 0 && b.pos >= 0;
+                in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now),
+                                                 __float_as_int(sqrtf(pair ? r2.second : b.second) * 0.999999f),
+                                                 pair ? r2.pos : -1, 0);
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -776,7 +829,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                                              THREADS, __int_as_float(ms.x), ms.y, ms.z);
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[q0 + lq] = make_int2(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f));
+                in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
+                                                 -1, 0);
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -797,7 +851,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
 
 // nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
 // coming map update drops (runs right before the grid is rebuilt, while the positions still mean something)
-__global__ void k_cache_to_seed(const int2* __restrict__ nn_cache, const float4* __restrict__ pts, int n, int m,
+__global__ void k_cache_to_seed(const int4* __restrict__ nn_cache, const float4* __restrict__ pts, int n, int m,
                                 int evicted, int* __restrict__ seed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1663,12 +1717,12 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
             ctx->partials_half = ctx->partials.bytes / 2 / (NEQ * sizeof(double)) * (NEQ * sizeof(double));
         }
     }
-    ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int2)));
+    ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int4)));
     const int tok = prof_begin(ctx, 0);
     IterInputs in;
     in.tgt = ctx->tgt4.as<float4>();
     in.normals = ctx->normals.as<float4>();
-    in.nn_cache = ctx->nn_cache.as<int2>();
+    in.nn_cache = ctx->nn_cache.as<int4>();
     in.pose_hist = ctx->pose_hist;
     // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
     in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
@@ -1739,7 +1793,7 @@ int run_seed_job(icp_ctx* ctx) {
     const int n = ctx->seed_job_n;
     ctx->seed_job_n = 0;
     if (n <= 0) return ICP_OK;
-    hipLaunchKernelGGL(k_cache_to_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nn_cache.as<int2>(),
+    hipLaunchKernelGGL(k_cache_to_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->nn_cache.as<int4>(),
                        ctx->sorted_pts.as<float4>(), n, ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>());
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
