@@ -1316,6 +1316,12 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                     b_over2 += db > 2.0;
                     b_over5 += db > 5.0;
                 }
+                if (seen < 1023 && t[4 * 1023] != 0) {  // the lead workgroup of a lead launch left its stamps in slot 1023
+                    const long long* q = t + 4 * 1023;
+                    fprintf(stderr, "[icp lead] it %2d: starts %.2f us after the first workgroup; rows summed after %.2f, solved "
+                                    "and published after %.2f more\n",
+                            it, (q[0] - first) * 0.01, (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01);
+                }
                 fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
                         it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / seen, amax, b / seen, bmax, bmax_miss,
                         b_over2, b_over5, total_miss, with_miss, r / seen, rmax);

@@ -566,9 +566,11 @@ __device__ inline int pack_cache(int pos, int iteration) {
 // shape, every launch 20 % slower), and as a non-inlined call it was itself three times slower (both measured).
 // `scratch` = LDS the iteration does not use yet.
 template <int THREADS>
-__device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ st, AlignParams ap, double* scratch) {
+__device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ st, AlignParams ap, double* scratch,
+                                  long long* stamps) {
     double(*lds)[NEQ] = reinterpret_cast<double(*)[NEQ]>(scratch);
     double* total = scratch + 32 * NEQ;
+    if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();  // dev: entry | rows summed | solved and published
     const int done = st->done;  // block-uniform
     int it = 0;
     float pose_in[16], params_in[6];
@@ -579,6 +581,10 @@ __device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ s
 #pragma unroll
         for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
     }
+    // (the rows are requested before `done` is looked at: one round trip instead of two in a row; behind the end of the
+    // loop the sum is simply discarded)
+    sum_partials_vt<THREADS>(lead.prev_partials, lead.prev_rows, lead.prev_quad, total, lds);
+    __syncthreads();
     if (done) {  // the loop ended earlier: this launch has nothing to do, and its workgroups must hear it
         if (threadIdx.x < BOX_USED) {
             const int k = threadIdx.x;
@@ -587,12 +593,12 @@ __device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ s
         }
         return;
     }
-    sum_partials_vt<THREADS>(lead.prev_partials, lead.prev_rows, lead.prev_quad, total, lds);
-    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
     if (threadIdx.x < NEQ) lead.neq[threadIdx.x] = total[threadIdx.x];
     if (threadIdx.x < 64)
         solve_and_update(st, total, ap, lead.loss_hist, lead.dx_hist, lead.hist_cap, it, pose_in, params_in, lead.box,
                          lead.gen);
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
 }
 
 template <int MINW, int THREADS, int Q>
@@ -617,7 +623,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     const int vb = (int)blockIdx.x - (lead.box ? lead.solve : 0);  // logical workgroup: which queries, which partial row
     if (lead.box) {
         if (vb < 0) {  // block-uniform
-            lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]));
+            lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]),
+                                (g.stamps && in.iter < 24) ? g.stamps + 4 * ((size_t)in.iter * 1024 + 1023) : nullptr);
             return;
         }
     } else if (st->done) {

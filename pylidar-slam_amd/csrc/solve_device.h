@@ -34,10 +34,8 @@ __device__ inline double solve6(double A[6][6], double* b, double* x) {
         for (int k = 0; k < 6; ++k)
             if (k < j) d -= L[j][k] * L[j][k];
         if (!(d > 0.0)) ok = false;
-        const double ljj = sqrt(d);
-        L[j][j] = ljj;
         det *= d;
-        const double inv = 1.0 / ljj;
+        const double inv = rsqrt(d);  // 1 / L[j][j] (L[j][j] itself is never needed: one rsqrt instead of a sqrt and a divide)
         rinv[j] = inv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -283,6 +281,32 @@ __device__ inline void sum_partials_vt(const double* __restrict__ partials, int 
                                        double (*lds)[NEQ]) {
     static_assert(1024 % THREADS == 0, "virtual threads");
     const int ns = quad ? (nrows + 3) / 4 : nrows;  // super-rows
+    if (!quad && ns == 256 && THREADS < 1024) {
+        // 256 super-rows (a 131 072-point scan in the 512-query shape): every virtual thread makes exactly one eight-wide
+        // trip of the loop below (its accumulators are then the loaded values themselves), so a thread can have the loads
+        // of ALL its virtual threads in flight at once instead of one dependent round per virtual thread.  Same additions.
+        constexpr int V = 1024 / THREADS;
+        double x[V][8];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int v = threadIdx.x + k * THREADS, col = v & 31, grp = v >> 5;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[k][i] = partials[(size_t)(grp + 32 * i) * NEQ + col];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int v = threadIdx.x + k * THREADS;
+            lds[v >> 5][v & 31] = ((x[k][0] + x[k][1]) + (x[k][2] + x[k][3])) + ((x[k][4] + x[k][5]) + (x[k][6] + x[k][7]));
+        }
+        __syncthreads();
+        if (threadIdx.x < NEQ) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) t += lds[g][threadIdx.x];
+            out[threadIdx.x] = t;
+        }
+        return;
+    }
 #pragma unroll 1
     for (int v = threadIdx.x; v < 1024; v += THREADS) {
         const int col = v & 31, grp = v >> 5;
