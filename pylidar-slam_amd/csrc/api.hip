@@ -299,7 +299,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->rows,       &ctx->row_of_pos, &ctx->cslot_of,
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
-                            &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc};
+                            &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
+                            &ctx->hood};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -350,6 +351,8 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
+    else if (k == "flat_rows") ctx->flat_rows = value != 0.0 ? 1 : 0;
+    else if (k == "hoods") ctx->hoods = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
     else if (k == "search_stats") {

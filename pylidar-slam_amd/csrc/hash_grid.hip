@@ -506,6 +506,73 @@ __global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const 
                       crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Neighbourhood lists ("hoods"): for every occupied fine cell the points of its 27-neighbourhood, copied END TO END into
+// one contiguous run (header = entry 27 of the cell's row: start, count).  The kNN normal estimation then streams ~120
+// candidates per map point from one address range — no 27 (start, count) pairs to walk, no per-cell loop state: that
+// bookkeeping, not the candidates, was 90 % of the 6 700 VALU instructions a wave of 16 points spent there (round 2's
+// counters).  Memory for speed: every point appears in up to 27 lists (19 MB for the 100 000-point map, bounded by
+// 27 x 16 B x M), rebuilt with the grid — an HBM3E-sized trade.
+// 32 lanes per cell (lane c = neighbour c of the row), 32 cells per workgroup, ONE atomicAdd per workgroup for its share
+// of the list space (the order of the runs in memory is immaterial; within a run: neighbour by neighbour, cell order).
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int HOOD_THREADS = 1024;
+
+__global__ __launch_bounds__(HOOD_THREADS) void k_hood_build(const int* __restrict__ slot_of_cell,
+                                                             const int* __restrict__ ncells_dev, int2* __restrict__ rows,
+                                                             const float4* __restrict__ pts, float4* __restrict__ hood,
+                                                             long long capacity, unsigned long long* __restrict__ used) {
+    __shared__ int cell_tot[HOOD_THREADS / 32];
+    __shared__ unsigned long long base_s;
+    const int ncells = *ncells_dev;
+    const int j = blockIdx.x * (HOOD_THREADS / 32) + (threadIdx.x >> 5), c = threadIdx.x & 31;
+    if (blockIdx.x * (HOOD_THREADS / 32) >= ncells) return;  // block-uniform
+    int2 e = make_int2(0, 0);
+    size_t row = 0;
+    if (j < ncells) {
+        row = (size_t)slot_of_cell[j] * ROW_STRIDE;
+        if (c < 27) e = rows[row + c];
+    }
+    const int cnt = e.y;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(incl, o, 32);
+        if (c >= o) incl += t;
+    }
+    const int tot = __shfl(incl, 31, 32);
+    if (c == 0) cell_tot[threadIdx.x >> 5] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (int k = 0; k < HOOD_THREADS / 32; ++k) sum += (unsigned long long)cell_tot[k];
+        base_s = atomicAdd(used, sum);
+    }
+    __syncthreads();
+    long long start = (long long)base_s;
+    for (int k = 0; k < (int)(threadIdx.x >> 5); ++k) start += cell_tot[k];
+    if (j >= ncells) return;
+    if (start + tot > capacity) {  // (cannot happen: the capacity is the 27 M bound)
+        if (c == 0) rows[row + 27] = make_int2(0, 0);
+        return;
+    }
+    if (c == 0) rows[row + 27] = make_int2((int)start, tot);
+    // the 32 lanes of the cell copy its run together, entry i by lane i % 32 (coalesced stores; the segment of entry i =
+    // the first neighbour whose inclusive count exceeds i, found by a 5-step search over the lanes' counts)
+    const int excl = incl - cnt;
+    float4* dst = hood + start;
+    for (int i = c; i < ((tot + 31) & ~31); i += 32) {  // (same trip count in all 32 lanes: the shuffles below need them)
+        int seg = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) {
+            const int v = __shfl(incl, seg + step - 1, 32);
+            if (v <= i) seg += step;
+        }
+        const int seg_start = __shfl(e.x, seg & 31, 32), seg_excl = __shfl(excl, seg & 31, 32);
+        if (i < tot) dst[i] = pts[seg_start + (i - seg_excl)];
+    }
+}
+
 static unsigned int next_pow2(unsigned int v) {
     unsigned int p = 1024;
     while (p < v) p <<= 1;
@@ -612,6 +679,20 @@ int build_grid(icp_ctx* ctx) {
                            ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(), ctx->csorted.as<float4>(),
                            ctx->normals.as<float4>(), ctx->nflag.as<int>(), ctx->row_of_pos.as<int>(),
                            ctx->pos_of_orig.as<int>());
+    }
+    // neighbourhood lists for the kNN normals (option "hoods"; maps beyond 2^22 points keep the row walk: 27 x 16 B per
+    // point would be gigabytes).  The start of a run is an int: 27 M < 2^31 holds for every map that gets here
+    ctx->hoods_valid = false;
+    if (ctx->hoods && m <= (1ll << 22)) {
+        const size_t cap = (size_t)27 * (size_t)m;
+        ICP_HIP(ctx, ctx->hood.reserve(cap * sizeof(float4) + 64));
+        unsigned long long* used = (unsigned long long*)(ctx->hood.as<char>() + cap * sizeof(float4));
+        ICP_HIP(ctx, hipMemsetAsync(used, 0, sizeof(unsigned long long), ctx->stream));
+        const unsigned hb = (unsigned)((m + HOOD_THREADS / 32 - 1) / (HOOD_THREADS / 32));  // (cells <= points)
+        hipLaunchKernelGGL(k_hood_build, dim3(hb), dim3(HOOD_THREADS), 0, ctx->stream, ctx->slot_of_cell.as<int>(),
+                           ncells_dev, ctx->rows.as<int2>(), ctx->sorted_pts.as<float4>(), ctx->hood.as<float4>(),
+                           (long long)cap, used);
+        ctx->hoods_valid = true;
     }
     ctx->ctable_ptr = table + tsize;
     ctx->ctable_size = tsize;

@@ -41,6 +41,8 @@ struct GridView {
     float ch, cinv_h;
     const float4* cpts;
     const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
+    const float4* hood;      // neighbourhood lists (hash_grid.hip::k_hood_build; header = row entry 27) or nullptr
+    int flat_rows;           // option "flat_rows": the 4-lane search scans its surviving neighbour cells laid end to end
     int* dbg;                // dev-only path counters (option "search_stats" = 1), nullptr in production
     long long* stamps;       // dev-only phase timestamps (option "search_stats" = 1 | 2), nullptr in production
 };
@@ -299,6 +301,10 @@ struct icp_ctx {
     icp::DeviceBuffer posebox;         // pose mailbox of the lead launches (BOX_BYTES)
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
+    int flat_rows = 1;                 // "flat_rows" (GridView)
+    int hoods = 1;                     // "hoods": neighbourhood lists for the kNN normals
+    bool hoods_valid = false;          // ... built for the current grid
+    icp::DeviceBuffer hood;            // float4[<= 27 M] + the fill counter behind it
     int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs

@@ -197,6 +197,69 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
             ++nl;
         }
+        if (g.flat_rows) {
+            // The surviving neighbour cells of the GROUP laid end to end (round 3): every lane's cells are announced in a
+            // list the four lanes share (their four LDS columns, 28 slots), with the running candidate count in front of
+            // each; the four lanes then walk candidates 0 .. T-1 together, four loads in flight each, finding the cell of
+            // candidate j by a 5-step search of the list.  ~25 surviving candidates are two rounds of loads instead of one
+            // round per (cell, 4 candidates) of whichever lane drew the most cells.
+            int tl = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (i < nl) tl += stack[i * stride].y & 0xffffff;
+            const int lane0 = (int)(threadIdx.x & 63) & ~3;
+            int cbase = 0, tbase = 0, C = 0, T = 0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int n_l = __shfl(nl, lane0 + l, 64), t_l = __shfl(tl, lane0 + l, 64);
+                if (l < sub) {
+                    cbase += n_l;
+                    tbase += t_l;
+                }
+                C += n_l;
+                T += t_l;
+            }
+            int2 mine[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) mine[i] = i < nl ? stack[i * stride] : make_int2(0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (every lane has read its own column: the columns now hold the shared list)
+            {
+                int cum = tbase;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < nl) {
+                        const int e = cbase + i;
+                        stack[(e >> 2) * stride + ((e & 3) - sub)] = make_int2(mine[i].x - cum, cum);
+                        cum += mine[i].y & 0xffffff;
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j0 = 0; j0 < T; j0 += 16) {  // group-uniform
+                int pos[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = min(j0 + 4 * m + sub, T - 1);  // (a clamped tail re-reads the last candidate: harmless)
+                    int e = 0;
+#pragma unroll
+                    for (int s2 = 16; s2 > 0; s2 >>= 1) {
+                        const int t = e + s2;
+                        if (t < C && stack[(t >> 2) * stride + ((t & 3) - sub)].y <= j) e = t;
+                    }
+                    pos[m] = j + stack[(e >> 2) * stride + ((e & 3) - sub)].x;
+                }
+                const float4 q0 = g.pts[pos[0]], q1 = g.pts[pos[1]], q2 = g.pts[pos[2]], q3 = g.pts[pos[3]];
+                consider(q0, pos[0], px, py, pz, b);
+                consider(q1, pos[1], px, py, pz, b);
+                consider(q2, pos[2], px, py, pz, b);
+                consider(q3, pos[3], px, py, pz, b);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the columns go back to their lanes)
+            nl = 0;
+        }
         int ci = 0, st = 0, cnt = 0, k = 0;
         for (;;) {
             if (k >= cnt) {
@@ -986,31 +1049,50 @@ __device__ inline void smallest_eigenvector(float a00, float a01, float a02, flo
 
 // covariance of the k neighbours (first of the k+1 dropped, :407) centred on the query point (:411-413), f32:
 // cov = {c00, c01, c02, c11, c12, c22}
+// The six sums of a covariance, ORDER-INDEPENDENT: every float32 product is first rounded to a multiple of 2^-40
+// ((v + C) - C in float64 with ulp(C) = 2^-40: exact for |v| < 2^11, i.e. neighbours up to 45 m away), and sums of such
+// multiples below 2^13 are exact in float64 whatever their order.  The kernels that estimate a normal reach its
+// neighbours in different orders (sorted by distance here, in list order in estimate_cov_hood, lane by lane and wave by
+// wave elsewhere) and must agree bit for bit.
+struct CovSums {
+    double c[6];
+    __device__ inline void zero() {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = 0.0;
+    }
+    static __device__ inline double grid(float v) {
+        const double C = 6144.0;  // 1.5 * 2^12: ulp = 2^-40
+        return ((double)v + C) - C;
+    }
+    __device__ inline void add(float dx, float dy, float dz) {
+        c[0] += grid(dx * dx);
+        c[1] += grid(dx * dy);
+        c[2] += grid(dx * dz);
+        c[3] += grid(dy * dy);
+        c[4] += grid(dy * dz);
+        c[5] += grid(dz * dz);
+    }
+    __device__ inline void store(int used, float* __restrict__ cov) const {
+        const float invk = used > 0 ? 1.0f / (float)used : 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov[k] = (float)c[k] * invk;
+    }
+};
+
 template <int KN>
 __device__ inline void neighbourhood_cov(const GridView& g, float px, float py, float pz, const TopK<KN>& t,
                                          float* __restrict__ cov) {
-    float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    CovSums cs;
+    cs.zero();
     int used = 0;
 #pragma unroll
     for (int k = 1; k < KN; ++k) {
         if (t.key[k] == KEY_EMPTY) continue;  // map smaller than k + 1 points
         const float4 q = g.pts[g.pos_of_orig[key_idx(t.key[k])]];
-        const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-        c00 += dx * dx;
-        c01 += dx * dy;
-        c02 += dx * dz;
-        c11 += dy * dy;
-        c12 += dy * dz;
-        c22 += dz * dz;
+        cs.add(q.x - px, q.y - py, q.z - pz);
         ++used;
     }
-    const float invk = used > 0 ? 1.0f / (float)used : 0.f;
-    cov[0] = c00 * invk;
-    cov[1] = c01 * invk;
-    cov[2] = c02 * invk;
-    cov[3] = c11 * invk;
-    cov[4] = c12 * invk;
-    cov[5] = c22 * invk;
+    cs.store(used, cov);
 }
 
 __device__ inline void normal_from_cov(const float* __restrict__ cov, int s, float4* __restrict__ normals,
@@ -1245,6 +1327,115 @@ __device__ inline bool estimate_cov(const GridView& g, int s, int sub, float* __
     return exact;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring 1 of the kNN from the cell's NEIGHBOURHOOD LIST (hash_grid.hip::k_hood_build), 4 lanes per map point:
+//   pass 1  every lane streams its quarter of the list (4 loads in flight) into a sorted list of its KN smallest squared
+//           DISTANCES — plain floats, updated branch-free by one v_med3 per slot; two butterfly rounds (element-wise min
+//           of one sorted list with the other reversed = the KN smallest of both) give T, the KN-th smallest distance of
+//           the whole list;
+//   pass 2  the list again (L1-hot): candidates with d < T, and those with d == T, are noted in LDS and counted;
+//   pass 3  the ~KN noted ones feed the order-independent covariance sums.
+// The k + 1 nearest neighbours are exactly {d < T} plus the ties at T when together they are KN; more ties than that
+// (duplicates, lattices) need the (distance, index) order — and a T beyond what ring 1 certifies needs more rings: both
+// return false and the point goes to the whole-wave continuation with 64-bit keys (finish_cov_wave), like before.
+// The first neighbour the reference drops (:407) is the point itself or a twin at distance 0: it adds nothing to the sums.
+// Returns true when the covariance has been written (by lane 0 of the group).  `sel` = this lane's column of an LDS array
+// [KN][blockDim] of 16-bit list positions.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KN>
+__device__ inline void sorted_insert_med3(float (&D)[KN], float c) {
+#pragma unroll
+    for (int i = KN - 1; i > 0; --i) D[i] = __builtin_amdgcn_fmed3f(c, D[i - 1], D[i]);  // (old D[i - 1]: going down)
+    D[0] = fminf(c, D[0]);
+}
+
+template <int KN>
+__device__ inline bool estimate_cov_hood(const GridView& g, int s, int sub, float* __restrict__ cov,
+                                         unsigned short* __restrict__ sel, int stride) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    const float h = g.h;
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const int2 hh = g.rows[(size_t)g.row_of_pos[s] * ROW_STRIDE + 27];
+    const float4* __restrict__ H = g.hood + hh.x;
+    const int n = hh.y;
+    // ---- pass 1
+    float D[KN];
+#pragma unroll
+    for (int i = 0; i < KN; ++i) D[i] = INFINITY;
+    for (int j = sub; j < n; j += 16) {
+        const bool v1 = j + 4 < n, v2 = j + 8 < n, v3 = j + 12 < n;
+        const float4 q0 = H[j], q1 = H[v1 ? j + 4 : j], q2 = H[v2 ? j + 8 : j], q3 = H[v3 ? j + 12 : j];
+        float dx = q0.x - px, dy = q0.y - py, dz = q0.z - pz;
+        sorted_insert_med3<KN>(D, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        dx = q1.x - px, dy = q1.y - py, dz = q1.z - pz;
+        sorted_insert_med3<KN>(D, v1 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY);  // (+inf changes nothing)
+        dx = q2.x - px, dy = q2.y - py, dz = q2.z - pz;
+        sorted_insert_med3<KN>(D, v2 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY);
+        dx = q3.x - px, dy = q3.y - py, dz = q3.z - pz;
+        sorted_insert_med3<KN>(D, v3 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY);
+    }
+    // ---- the KN-th smallest of the four lists
+    float T;
+    {
+        float E[KN];
+#pragma unroll
+        for (int i = 0; i < KN; ++i) E[i] = INFINITY;
+#pragma unroll
+        for (int i = 0; i < KN; ++i)  // the KN smallest of this lane's and its neighbour's lists, sorted again
+            sorted_insert_med3<KN>(E, fminf(D[i], __shfl_xor(D[KN - 1 - i], 1, 64)));
+        T = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < KN; ++i) T = fmaxf(T, fminf(E[i], __shfl_xor(E[KN - 1 - i], 2, 64)));
+    }
+    const float bound = h + edge;
+    if (!(T <= bound * bound * 0.999999f)) return false;  // group-uniform (T is): ring 1 does not certify the KN-th neighbour
+    if (n > 65535) return false;                          // (the notes below are 16-bit list positions)
+    // ---- pass 2: who is in
+    int nsel = 0, over = 0;
+    for (int j = sub; j < n; j += 16) {
+        const bool v1 = j + 4 < n, v2 = j + 8 < n, v3 = j + 12 < n;
+        const float4 q0 = H[j], q1 = H[v1 ? j + 4 : j], q2 = H[v2 ? j + 8 : j], q3 = H[v3 ? j + 12 : j];
+        float dx = q0.x - px, dy = q0.y - py, dz = q0.z - pz;
+        const float d0 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        dx = q1.x - px, dy = q1.y - py, dz = q1.z - pz;
+        const float d1 = v1 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY;
+        dx = q2.x - px, dy = q2.y - py, dz = q2.z - pz;
+        const float d2 = v2 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY;
+        dx = q3.x - px, dy = q3.y - py, dz = q3.z - pz;
+        const float d3 = v3 ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : INFINITY;
+        // (a lane that meets more than KN candidates within T has met ties beyond the KN-th place)
+        if (d0 <= T) { if (nsel < KN) { sel[nsel * stride] = (unsigned short)j;        ++nsel; } else over = 1; }
+        if (d1 <= T) { if (nsel < KN) { sel[nsel * stride] = (unsigned short)(j + 4);  ++nsel; } else over = 1; }
+        if (d2 <= T) { if (nsel < KN) { sel[nsel * stride] = (unsigned short)(j + 8);  ++nsel; } else over = 1; }
+        if (d3 <= T) { if (nsel < KN) { sel[nsel * stride] = (unsigned short)(j + 12); ++nsel; } else over = 1; }
+    }
+    int tot = nsel;
+    tot += __shfl_xor(tot, 1, 64);
+    tot += __shfl_xor(tot, 2, 64);
+    over |= __shfl_xor(over, 1, 64);
+    over |= __shfl_xor(over, 2, 64);
+    if (tot != KN || over) return false;  // ties at T beyond the KN-th place: the keyed (distance, index) search decides
+    // ---- pass 3: the covariance sums
+    CovSums cs;
+    cs.zero();
+    for (int i = 0; i < nsel; ++i) {
+        const float4 q = H[sel[i * stride]];
+        cs.add(q.x - px, q.y - py, q.z - pz);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        cs.c[k] += __shfl_xor(cs.c[k], 1, 64);
+        cs.c[k] += __shfl_xor(cs.c[k], 2, 64);
+    }
+    if (sub == 0) cs.store(KN - 1, cov);
+    return true;
+}
+
 // The points ring 1 does not settle (isolated points: 1-2 % of a LiDAR map) are finished by a WHOLE WAVE each: a few of
 // them per launch walked the hashed rings and the coarse level with 4 lanes — 25 dependent probes per lane and ring,
 // coarse cells of hundreds of points — and set the duration of the kernel (the same tail as in the iteration kernel).
@@ -1281,6 +1472,7 @@ struct PendingKnn {
     unsigned long long key[PTS][KN];
     int s[PTS];
     int lq[PTS];
+
     int wl[NRM_THREADS / 64][128];  // per-wave scratch of wave_knn_rings
     int n;
 };
@@ -1397,6 +1589,77 @@ __global__ __launch_bounds__(NRM_THREADS, NL == 4 ? 5 : 2) void k_normals_all(Gr
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     const int s2 = blockIdx.x * PTS + threadIdx.x;
     if (threadIdx.x < PTS && s2 < g.m) normal_from_cov(covs[threadIdx.x], s2, normals, nflag);
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+}
+
+// The eager estimation through the neighbourhood lists (round 3; kernel of its own so that its lighter register and LDS
+// footprint — 7 workgroups per CU: every workgroup of a 100 000-point map resident at once — is not set by the row walk
+// above, which stays for 2 lanes per point, k > 13 and maps without lists).  Phase 1: estimate_cov_hood, 4 lanes per
+// point.  Phase 2: what it does not settle (1.5 % of a LiDAR map: isolated points; everything with ties at the k-th
+// distance) is finished by a whole wave each, exactly like before: the wave first rebuilds the merged (distance, index)
+// list of ring 1 from the neighbourhood list, then continues with finish_cov_wave (fine ring 2, coarse level,
+// exhaustive).  Phase 3: the eigen-solves on dense waves.  OWNED: the map-sharded variant (only the points whose
+// spatial bucket `rank` owns, results by original index).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline int bucket_owner(float x, float y, float z, int world);
+
+template <int KN, bool OWNED>
+__global__ __launch_bounds__(NRM_THREADS, 7) void k_normals_hood(GridView g, int max_rings, int rank, int world,
+                                                                 float4* __restrict__ out, int* __restrict__ nflag) {
+    constexpr int PTS = NRM_THREADS / 4;
+    __shared__ unsigned short sel[KN][NRM_THREADS];
+    __shared__ float covs[PTS][7];
+    __shared__ int pend_s[PTS], pend_lq[PTS], owned[PTS];
+    __shared__ int wl[NRM_THREADS / 64][128];
+    __shared__ int npend;
+    long long* stamps = (g.stamps && gridDim.x <= 8192) ? g.stamps + 24 * 1024 * 4 + 4 * blockIdx.x : nullptr;  // dev
+    if (threadIdx.x == 0) {
+        npend = 0;
+        if (stamps) stamps[0] = wall_clock64();
+    }
+    __syncthreads();
+    const int lq = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int s = blockIdx.x * PTS + lq;
+    bool mine = s < g.m;
+    if (OWNED && mine) {
+        const float4 P = g.pts[s];
+        mine = bucket_owner(P.x, P.y, P.z, world) == rank;  // group-uniform
+    }
+    if (mine && !estimate_cov_hood<KN>(g, s, sub, covs[lq], &sel[0][threadIdx.x], NRM_THREADS) && sub == 0) {
+        const int k = atomicAdd(&npend, 1);
+        pend_s[k] = s;
+        pend_lq[k] = lq;
+    }
+    if (sub == 0) owned[lq] = mine ? 1 : 0;
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < npend; k += NRM_THREADS / 64) {  // wave-uniform
+            const int ps = pend_s[k];
+            const float4 P = g.pts[ps];
+            const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
+            TopK<KN> t, m;
+            t.init();
+            for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
+            merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
+            finish_cov_wave<KN>(g, ps, lane, max_rings, m, covs[pend_lq[k]], wl[wave]);
+        }
+    }
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+    const int s2 = blockIdx.x * PTS + threadIdx.x;
+    if (threadIdx.x < PTS && s2 < g.m && owned[threadIdx.x]) {
+        float nx, ny, nz;
+        const float* c = covs[threadIdx.x];
+        smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
+        if (OWNED) {
+            out[__float_as_int(g.pts[s2].w)] = make_float4(nx, ny, nz, 1.f);
+        } else {
+            out[s2] = make_float4(nx, ny, nz, 1.f);
+            nflag[s2] = 1;
+        }
+    }
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
 }
 
@@ -1561,6 +1824,8 @@ static GridView make_view(icp_ctx* ctx) {
     g.cinv_h = 1.0f / g.ch;
     g.cpts = ctx->csorted.as<float4>();
     g.pos_of_orig = ctx->pos_of_orig.as<int>();
+    g.flat_rows = ctx->flat_rows;
+    g.hood = ctx->hoods_valid ? ctx->hood.as<float4>() : nullptr;
     g.dbg = ctx->search_stats == 1 ? ctx->dbg_counts.as<int>() : nullptr;
     g.stamps = ctx->search_stats ? reinterpret_cast<long long*>(ctx->dbg_counts.as<int>() + 16) : nullptr;
     return g;
@@ -1632,6 +1897,15 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
+    if (NL == 4 && g.hood && (kn == 11 || kn == 6)) {  // through the neighbourhood lists
+        if (kn == 11)
+            hipLaunchKernelGGL((k_normals_hood<11, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, 0, 1,
+                               nrm, nf);
+        else
+            hipLaunchKernelGGL((k_normals_hood<6, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, 0, 1,
+                               nrm, nf);
+        return;
+    }
     if (kn == 11)
         hipLaunchKernelGGL((k_normals_all<11, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
     else if (kn == 6)
@@ -1670,7 +1944,13 @@ int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev)
     const int rings = knn_fine_rings(ctx);
     float4* out = (float4*)by_index_dev;
     const int tok = prof_begin(ctx, 2);
-    if (kn == 11)
+    if (g.hood && kn == 11)
+        hipLaunchKernelGGL((k_normals_hood<11, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank,
+                           world, out, (int*)nullptr);
+    else if (g.hood && kn == 6)
+        hipLaunchKernelGGL((k_normals_hood<6, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank,
+                           world, out, (int*)nullptr);
+    else if (kn == 11)
         hipLaunchKernelGGL((k_normals_owned<11, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);
     else if (kn == 6)
         hipLaunchKernelGGL((k_normals_owned<6, 4>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank, world, out);

@@ -348,6 +348,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "no_frame_seed": {"frame_seed": 0},
                 "lanes2": {"knn_lanes": 2}, "scan_gives_up": {"scan_poll_limit": 0},
                 "no_lead_solve": {"lead_solve": 0},  # every solve in a launch of its own (round 2's schedule)
+                "no_flat_rows": {"flat_rows": 0},    # neighbour cells walked lane by lane (round 2's schedule)
                 "no_lead_never_narrow": {"lead_solve": 0, "narrow_from": -1},
                 "unfused": {"fuse_iteration": 0}}
     results = {}
