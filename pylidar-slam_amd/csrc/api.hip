@@ -1,6 +1,7 @@
 // C ABI of libicp_mi355x.so: context management, staging, and the orchestration of the kernels in the other
 // translation units.  Signatures and the reference interfaces they replace: include/icp_mi355x.h.
 #include <math.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -352,6 +353,8 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
     else if (k == "flat_rows") ctx->flat_rows = value != 0.0 ? 1 : 0;
+    else if (k == "xcd_sectors") ctx->xcd_sectors = value != 0.0 ? 1 : 0;
+    else if (k == "lead_after_dense") ctx->lead_after_dense = value != 0.0 ? 1 : 0;
     else if (k == "hoods") ctx->hoods = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
@@ -1300,16 +1303,22 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 double a = 0, b = 0, r = 0, amax = 0, bmax = 0, rmax = 0;
                 int bmax_miss = 0, with_miss = 0, total_miss = 0, b_over2 = 0, b_over5 = 0;
                 int seen = 0;
+                first &= MASK, last_start &= MASK, last_end &= MASK;
+                // (search_stats = 1: the top 16 bits of stamps 0 / 2 / 3 carry the workgroup's queries that went to the
+                // coarse level / beyond ring 1 / found their own cell empty)
+                struct Blk { double b; int miss, ring2, empty, coarse; };
+                std::vector<Blk> blks;
                 for (int i = 0; i < nb; ++i) {
                     const long long* q = t + 4 * i;
                     if (q[0] == 0) continue;  // the 512-queries-per-block shape launches a quarter of the blocks
                     ++seen;
-                    const long long t1 = q[1] & MASK;
+                    const long long t0 = q[0] & MASK, t1 = q[1] & MASK, t2 = q[2] & MASK, t3 = q[3] & MASK;
                     const int miss = (int)(q[1] >> 48);
-                    if (q[0] < first) first = q[0];
-                    if (q[0] > last_start) last_start = q[0];
-                    if (q[3] > last_end) last_end = q[3];
-                    const double da = (t1 - q[0]) * 0.01, db = (q[2] - t1) * 0.01, dr = (q[3] - q[2]) * 0.01;
+                    if (t0 < first) first = t0;
+                    if (t0 > last_start) last_start = t0;
+                    if (t3 > last_end) last_end = t3;
+                    const double da = (t1 - t0) * 0.01, db = (t2 - t1) * 0.01, dr = (t3 - t2) * 0.01;
+                    blks.push_back(Blk{db, miss, (int)(q[2] >> 48), (int)(q[3] >> 48), (int)(q[0] >> 48)});
                     a += da; b += db; r += dr;
                     if (da > amax) amax = da;
                     if (db > bmax) { bmax = db; bmax_miss = miss; }
@@ -1319,7 +1328,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                     b_over2 += db > 2.0;
                     b_over5 += db > 5.0;
                 }
-                if (seen < 1023 && t[4 * 1023] != 0) {  // the lead workgroup of a lead launch left its stamps in slot 1023
+                if (seen < 1023 && t[4 * 1023] != 0) {  // (the lead's stamps carry no counters)  // the lead workgroup of a lead launch left its stamps in slot 1023
                     const long long* q = t + 4 * 1023;
                     fprintf(stderr, "[icp lead] it %2d: starts %.2f us after the first workgroup; rows summed after %.2f, solved "
                                     "and published after %.2f more\n",
@@ -1328,6 +1337,22 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
                         it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / seen, amax, b / seen, bmax, bmax_miss,
                         b_over2, b_over5, total_miss, with_miss, r / seen, rmax);
+                if (ctx->search_stats == 1 && it < 8 && blks.size() >= 16) {
+                    // what the slow workgroups have that the others do not: deciles of the search phase
+                    std::sort(blks.begin(), blks.end(), [](const Blk& x, const Blk& y) { return x.b < y.b; });
+                    const size_t nbk = blks.size();
+                    fprintf(stderr, "[icp deciles] it %2d (B us: misses / beyond ring 1 / own cell empty / coarse, means):", it);
+                    for (int d = 0; d < 10; ++d) {
+                        const size_t lo = nbk * d / 10, hi = nbk * (d + 1) / 10;
+                        double sb = 0, sm = 0, s2 = 0, se = 0, sc = 0;
+                        for (size_t i = lo; i < hi; ++i) {
+                            sb += blks[i].b; sm += blks[i].miss; s2 += blks[i].ring2; se += blks[i].empty; sc += blks[i].coarse;
+                        }
+                        const double k = (double)(hi - lo);
+                        fprintf(stderr, " %.1f: %.0f/%.1f/%.1f/%.1f", sb / k, sm / k, s2 / k, se / k, sc / k);
+                    }
+                    fprintf(stderr, "\n");
+                }
             }
             {   // eager normal estimation: 4 stamps per block (start, ring 1 done, stragglers done, eigen done)
                 const long long* t = (const long long*)(raw.data() + DBG_ITER_BYTES);
@@ -1413,7 +1438,9 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
             rc = launch_iterate_fused(ctx, &rows, &quad, true, prev_rows, prev_quad);
             prev_rows = rows;
             prev_quad = quad;
-            if (!rc && (it + 1 == iters || !next_fused_launch_is_narrow(ctx))) {
+            // (rows of a dense launch: four times as many, a quarter of a microsecond each for ONE lead workgroup — with
+            // "lead_after_dense" = 0 they keep their own summing launch and the lead chain starts one iteration later)
+            if (!rc && (it + 1 == iters || !next_fused_launch_is_narrow(ctx) || (quad && !ctx->lead_after_dense))) {
                 // the rows of this launch: the parity it has just written
                 rc = launch_sum_solve(ctx, rows, quad, (const double*)(ctx->partials.as<char>() +
                                                                        (size_t)(ctx->partials_parity ^ 1) * ctx->partials_half),

@@ -302,6 +302,8 @@ struct icp_ctx {
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
     int flat_rows = 1;                 // "flat_rows" (GridView)
+    int lead_after_dense = 1;          // "lead_after_dense": the first narrow launch solves the last dense one (enqueue_iterations)
+    int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
     int hoods = 1;                     // "hoods": neighbourhood lists for the kNN normals
     bool hoods_valid = false;          // ... built for the current grid
     icp::DeviceBuffer hood;            // float4[<= 27 M] + the fill counter behind it

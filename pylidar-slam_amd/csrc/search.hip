@@ -41,21 +41,23 @@ __device__ inline int shell_mid(int e) {
     return 25 * (slab + 1) + cell;
 }
 
-__device__ inline void group_min4(Best& b) {
-#pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-        const float d2 = __shfl_xor(b.d2, o, 64);
-        const int idx = __shfl_xor(b.idx, o, 64);
-        const int pos = __shfl_xor(b.pos, o, 64);
-        float sec = fminf(b.second, __shfl_xor(b.second, o, 64));
-        if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
-        if (better(d2, idx, b.d2, b.idx)) {
-            b.d2 = d2;
-            b.idx = idx;
-            b.pos = pos;
-        }
-        b.second = sec;
+template <int X>
+__device__ inline void group_min_step(Best& b) {
+    const float d2 = quad_xor<X>(b.d2);
+    const int idx = quad_xor<X>(b.idx);
+    const int pos = quad_xor<X>(b.pos);
+    float sec = fminf(b.second, quad_xor<X>(b.second));
+    if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
+    if (better(d2, idx, b.d2, b.idx)) {
+        b.d2 = d2;
+        b.idx = idx;
+        b.pos = pos;
     }
+    b.second = sec;
+}
+__device__ inline void group_min4(Best& b) {
+    group_min_step<1>(b);
+    group_min_step<2>(b);
 }
 
 __device__ inline void scan_strided4(const GridView& g, int start, int count, int sub, float px, float py, float pz,
@@ -83,7 +85,6 @@ __device__ inline bool coop_rings(const GridView& lv, float px, float py, float 
     const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
     const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
-    const int lane0 = (int)(threadIdx.x & 63) & ~3;  // first lane of the group within its wave
     for (int r = r_begin; r <= r_end; ++r) {
         int start, count;
         if (r == 0) {
@@ -114,8 +115,10 @@ __device__ inline bool coop_rings(const GridView& lv, float px, float py, float 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int n_of[4] = {quad_bcast<0>(nl), quad_bcast<1>(nl), quad_bcast<2>(nl), quad_bcast<3>(nl)};
+#pragma unroll
                 for (int l = 0; l < 4; ++l) {
-                    const int n_l = __shfl(nl, lane0 + l, 64);  // group-uniform
+                    const int n_l = n_of[l];  // group-uniform
                     for (int k = 0; k < n_l; ++k) {
                         const int2 e = stack[k * stride + (l - sub)];  // lane l's column sits next to this lane's
                         scan_strided4(lv, e.x, e.y, sub, px, py, pz, b);
@@ -207,11 +210,12 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
 #pragma unroll
             for (int i = 0; i < 7; ++i)
                 if (i < nl) tl += stack[i * stride].y & 0xffffff;
-            const int lane0 = (int)(threadIdx.x & 63) & ~3;
             int cbase = 0, tbase = 0, C = 0, T = 0;
+            const int n_of[4] = {quad_bcast<0>(nl), quad_bcast<1>(nl), quad_bcast<2>(nl), quad_bcast<3>(nl)};
+            const int t_of[4] = {quad_bcast<0>(tl), quad_bcast<1>(tl), quad_bcast<2>(tl), quad_bcast<3>(tl)};
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
-                const int n_l = __shfl(nl, lane0 + l, 64), t_l = __shfl(tl, lane0 + l, 64);
+                const int n_l = n_of[l], t_l = t_of[l];
                 if (l < sub) {
                     cbase += n_l;
                     tbase += t_l;
@@ -599,7 +603,27 @@ struct IterInputs {
     int n, mode, max_rings, use_cache;
     int iter;                // index of this iteration within the registration (0, 1, ..)
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
+    // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
+    // an L2 of its own — with consecutive queries in consecutive workgroups every L2 has to hold the rows and points of
+    // the WHOLE map.  With swz_bpr_shift >= 0 the workgroups of one XCD take one azimuth sector (x elevation band) of the
+    // range image instead: physical workgroup p -> XCD c = p % 8 -> sector c % swz_sectors, band c / swz_sectors; the
+    // j-th workgroup of the class -> row band * swz_band_rows + (j >> swz_bpr_shift), block (j & bpr - 1) of the
+    // sector's bpr blocks of that row.  A permutation of the logical workgroups (queries and partial rows belong to the
+    // LOGICAL index): same bits.
+    int swz_bpr_shift;       // log2(blocks per row and sector), -1: identity
+    int swz_sectors;         // azimuth sectors (8, 4, 2 or 1)
+    int swz_band_rows;       // image rows per elevation band
+    int swz_row_blocks;      // blocks per image row
 };
+
+// logical workgroup of physical workgroup `p` (`off` = 1 when workgroup 0 is the lead of a lead launch)
+__device__ inline int logical_block(const IterInputs& in, int p, int off) {
+    if (in.swz_bpr_shift < 0) return p - off;
+    const int c = p & 7, first = off + ((c - off) & 7), j = (p - first) >> 3;
+    const int sector = c % in.swz_sectors, band = c / in.swz_sectors;
+    return (band * in.swz_band_rows + (j >> in.swz_bpr_shift)) * in.swz_row_blocks +
+           (sector << in.swz_bpr_shift) + (j & ((1 << in.swz_bpr_shift) - 1));
+}
 
 // cache entry .x = cell-sorted position of the neighbour | iteration of the search << 24 (-1: no neighbour); a position
 // needs 24 bits (maps of up to 16.7 M points use the cache), iterations wrap into 7 bits — harmlessly: an entry older
@@ -677,15 +701,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     __shared__ float pose_s[12];               // rows 0-2 of the pose of this iteration
     __shared__ float hist_s[CACHE_HIST][12];   // ... and of the CACHE_HIST iterations before it (slot = iteration % CACHE_HIST)
     __shared__ int ctl_s[4];                  // logical block | done | iteration | hand-off failures
+    __shared__ int dbg_s[16];                 // dev-only ("search_stats" = 1): this workgroup's path counters
     static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ) * sizeof(double), "the lead's scratch lives in the cell stacks");
     // In a lead launch (LeadArgs) workgroup 0 is the lead: it solves the previous iteration and publishes the pose the
     // others poll for.  The hardware dispatches workgroups in ascending order, so whoever polls, polls for a workgroup
     // placed before it (a role ticket drawn from a counter would make that independent of the dispatch order — and costs
     // a thousand same-address device-scope atomics per launch, ~10 us: measured); should the order ever differ, the
     // wall-clock bound of the poll turns the wait into ICP_ERR_HIP instead of a hang.
-    const int vb = (int)blockIdx.x - (lead.box ? lead.solve : 0);  // logical workgroup: which queries, which partial row
+    const int lead_blocks = lead.box ? lead.solve : 0;
     if (lead.box) {
-        if (vb < 0) {  // block-uniform
+        if ((int)blockIdx.x < lead_blocks) {  // block-uniform
             lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]),
                                 (g.stamps && in.iter < 24) ? g.stamps + 4 * ((size_t)in.iter * 1024 + 1023) : nullptr);
             return;
@@ -694,6 +719,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         return;  // classic launch behind the end of the loop (block-uniform)
     }
     const long long t_entry = g.stamps ? wall_clock64() : 0;
+    const int vb = logical_block(in, (int)blockIdx.x, lead_blocks);  // which queries, which partial row
     const int q0 = vb * Q;
     // ---- phase A, first half: everything that does not depend on the pose is requested now — target, cache entry and,
     // behind it, the cached neighbour and its normal (or the frame seed and its map point): in a lead launch these loads
@@ -739,6 +765,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     // ---- the pose: from the mailbox (lead launch) or from the RegState (classic launch)
     if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
+    int* const dbg_global = g.dbg;
+    if (g.dbg) {  // the search paths count into LDS (flat atomics); flushed, and stored per workgroup, at the end
+        if (threadIdx.x < 16) dbg_s[threadIdx.x] = 0;
+        g.dbg = dbg_s;
+    }
     __syncthreads();
     if (lead.box) {
         if (threadIdx.x < BOX_USED) {
@@ -917,6 +948,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+    if (dbg_global) {  // dev: counters to the context's totals; per workgroup: beyond ring 1 | own cell empty | coarse level
+        if (threadIdx.x < 16 && dbg_s[threadIdx.x]) atomicAdd(&dbg_global[threadIdx.x], dbg_s[threadIdx.x]);
+        if (stamps && threadIdx.x == 0) {
+            stamps[2] |= (long long)dbg_s[2] << 48;
+            stamps[3] |= (long long)dbg_s[5] << 48;
+            stamps[0] |= (long long)dbg_s[3] << 48;
+        }
+    }
 }
 
 // nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
@@ -1387,10 +1426,10 @@ __device__ inline bool estimate_cov_hood(const GridView& g, int s, int sub, floa
         for (int i = 0; i < KN; ++i) E[i] = INFINITY;
 #pragma unroll
         for (int i = 0; i < KN; ++i)  // the KN smallest of this lane's and its neighbour's lists, sorted again
-            sorted_insert_med3<KN>(E, fminf(D[i], __shfl_xor(D[KN - 1 - i], 1, 64)));
+            sorted_insert_med3<KN>(E, fminf(D[i], quad_xor<1>(D[KN - 1 - i])));
         T = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < KN; ++i) T = fmaxf(T, fminf(E[i], __shfl_xor(E[KN - 1 - i], 2, 64)));
+        for (int i = 0; i < KN; ++i) T = fmaxf(T, fminf(E[i], quad_xor<2>(E[KN - 1 - i])));
     }
     const float bound = h + edge;
     if (!(T <= bound * bound * 0.999999f)) return false;  // group-uniform (T is): ring 1 does not certify the KN-th neighbour
@@ -1415,10 +1454,10 @@ __device__ inline bool estimate_cov_hood(const GridView& g, int s, int sub, floa
         if (d3 <= T) { if (nsel < KN) { sel[nsel * stride] = (unsigned short)(j + 12); ++nsel; } else over = 1; }
     }
     int tot = nsel;
-    tot += __shfl_xor(tot, 1, 64);
-    tot += __shfl_xor(tot, 2, 64);
-    over |= __shfl_xor(over, 1, 64);
-    over |= __shfl_xor(over, 2, 64);
+    tot += quad_xor<1>(tot);
+    tot += quad_xor<2>(tot);
+    over |= quad_xor<1>(over);
+    over |= quad_xor<2>(over);
     if (tot != KN || over) return false;  // ties at T beyond the KN-th place: the keyed (distance, index) search decides
     // ---- pass 3: the covariance sums
     CovSums cs;
@@ -1429,8 +1468,8 @@ __device__ inline bool estimate_cov_hood(const GridView& g, int s, int sub, floa
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        cs.c[k] += __shfl_xor(cs.c[k], 1, 64);
-        cs.c[k] += __shfl_xor(cs.c[k], 2, 64);
+        cs.c[k] += quad_xor<1>(cs.c[k]);
+        cs.c[k] += quad_xor<2>(cs.c[k]);
     }
     if (sub == 0) cs.store(KN - 1, cov);
     return true;
@@ -1504,10 +1543,23 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 #pragma unroll
     for (int round = 0; round < KN; ++round) {
         unsigned long long best = t.key[0];
+        if (NL > 4) {  // a whole wave: the LDS crossbar
 #pragma unroll
-        for (int o = 1; o < NL; o <<= 1) {
-            const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
-            const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+            for (int o = 1; o < NL; o <<= 1) {
+                const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
+                const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                best = other < best ? other : best;
+            }
+        } else {
+            const unsigned lo = (unsigned)quad_xor<1>((int)(best & 0xffffffffull));
+            const unsigned hi = (unsigned)quad_xor<1>((int)(best >> 32));
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        if (NL == 4) {
+            const unsigned lo = (unsigned)quad_xor<2>((int)(best & 0xffffffffull));
+            const unsigned hi = (unsigned)quad_xor<2>((int)(best >> 32));
             const unsigned long long other = ((unsigned long long)hi << 32) | lo;
             best = other < best ? other : best;
         }
@@ -2039,6 +2091,28 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
     in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
+    in.swz_bpr_shift = -1;
+    in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;
+    if (ctx->xcd_sectors && blocks >= 64 && blocks % 8 == 0) {
+        // a range image of cfg.height x cfg.width pixels in row-major order: azimuth sectors (x elevation bands when a
+        // row has fewer than 8 blocks); any other target array: eight contiguous runs of workgroups
+        const int W = ctx->cfg.width, H = ctx->cfg.height;
+        int row_blocks = 1, rows = blocks;
+        if ((int64_t)H * W == n && W % per_block == 0) {
+            row_blocks = W / per_block;
+            rows = H;
+        }
+        const int sectors = row_blocks >= 8 ? 8 : row_blocks;  // 8, or a divisor of 8 when row_blocks is one
+        int bpr = row_blocks / (sectors > 0 ? sectors : 1), shift = 0;
+        while ((1 << shift) < bpr) ++shift;
+        if (sectors > 0 && 8 % sectors == 0 && row_blocks % sectors == 0 && (1 << shift) == bpr &&
+            rows % (8 / sectors) == 0) {
+            in.swz_bpr_shift = shift;
+            in.swz_sectors = sectors;
+            in.swz_band_rows = rows / (8 / sectors);
+            in.swz_row_blocks = row_blocks;
+        }
+    }
     if (narrow)
         hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);

@@ -4,6 +4,34 @@
 
 namespace icp {
 
+// Exchanges inside a 4-lane group (the lanes of one query) by DPP quad permutes: one VALU instruction each, where
+// __shfl_xor is an address computation + ds_bpermute + a wait for the LDS crossbar.  All four lanes must be active (the
+// groups' control flow is group-uniform).  X = 1, 2, 3: the lane `sub ^ X`.
+template <int X>
+__device__ inline int quad_xor(int v) {
+    static_assert(X >= 1 && X <= 3, "lane ^ X within a quad");
+    constexpr int ctrl = X == 1 ? 0xB1 : (X == 2 ? 0x4E : 0x1B);  // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+    return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);
+}
+template <int X>
+__device__ inline float quad_xor(float v) { return __int_as_float(quad_xor<X>(__float_as_int(v))); }
+template <int X>
+__device__ inline double quad_xor(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_xor<X>((int)(b & 0xffffffffll)), hi = quad_xor<X>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// the value of lane L (0..3) of the group, in all four lanes
+template <int L>
+__device__ inline int quad_bcast(int v) {
+    static_assert(L >= 0 && L <= 3, "lane of the quad");
+    return __builtin_amdgcn_update_dpp(v, v, L * 0x55, 0xf, 0xf, false);
+}
+__device__ inline float quad_min(float v) {
+    v = fminf(v, quad_xor<1>(v));
+    return fminf(v, quad_xor<2>(v));
+}
+
 struct Best {
     float d2;
     int idx;       // original index (tie-break)

@@ -21,3 +21,7 @@ for v in 1 0; do
   timeout 120 python bench.py --steps 3 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-profile --option $OPT=$v --option search_stats=2 > /dev/null 2> $OUT/phases_$v.err
   echo "== phases with $OPT=$v (last frame)"; grep "icp phases" $OUT/phases_$v.err | tail -20 | cut -c1-260
 done
+# path counters per workgroup (search_stats = 1): what the slow workgroups have that the others do not
+timeout 120 python bench.py --steps 3 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-profile --option $OPT=1 --option search_stats=1 > /dev/null 2> $OUT/phases_stats.err
+grep "icp deciles" $OUT/phases_stats.err | tail -16 | head -8 | cut -c1-400
+grep "icp stats" $OUT/phases_stats.err | tail -2 | cut -c1-300
