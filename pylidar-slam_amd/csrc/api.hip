@@ -355,6 +355,9 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "flat_rows") ctx->flat_rows = value != 0.0 ? 1 : 0;
     else if (k == "xcd_sectors") ctx->xcd_sectors = value != 0.0 ? 1 : 0;
     else if (k == "lead_after_dense") ctx->lead_after_dense = value != 0.0 ? 1 : 0;
+    else if (k == "refresh_margin") ctx->refresh_margin = value > 0.0 ? (float)value : 0.f;
+    else if (k == "refresh_at") ctx->refresh_at = iv;
+    else if (k == "prune_guard") ctx->prune_guard = value > 0.0 ? (float)value : 0.f;
     else if (k == "hoods") ctx->hoods = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;

@@ -43,6 +43,7 @@ struct GridView {
     const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
     const float4* hood;      // neighbourhood lists (hash_grid.hip::k_hood_build; header = row entry 27) or nullptr
     int flat_rows;           // option "flat_rows": the 4-lane search scans its surviving neighbour cells laid end to end
+    float prune_guard;       // option "prune_guard" (m): neighbour cells closer than best + guard are scanned, not pruned
     int* dbg;                // dev-only path counters (option "search_stats" = 1), nullptr in production
     long long* stamps;       // dev-only phase timestamps (option "search_stats" = 1 | 2), nullptr in production
 };
@@ -281,7 +282,7 @@ struct icp_ctx {
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
-    int narrow_from = 6;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
+    int narrow_from = 3;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
     int wave_misses = 24;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
@@ -302,6 +303,9 @@ struct icp_ctx {
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
     int flat_rows = 1;                 // "flat_rows" (GridView)
+    float prune_guard = 2e-3f;         // "prune_guard" (GridView)
+    float refresh_margin = 1e-4f;      // "refresh_margin" (m) / "refresh_at" (iteration): NN-cache entries with less slack than
+    int refresh_at = 6;                // that are searched again in that one launch, which searches anyway (IterInputs)
     int lead_after_dense = 1;          // "lead_after_dense": the first narrow launch solves the last dense one (enqueue_iterations)
     int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
     int hoods = 1;                     // "hoods": neighbourhood lists for the kNN normals

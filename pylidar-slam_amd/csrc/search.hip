@@ -61,16 +61,16 @@ __device__ inline void group_min4(Best& b) {
 }
 
 __device__ inline void scan_strided4(const GridView& g, int start, int count, int sub, float px, float py, float pz,
-                                     Best& b) {
+                                     Best& b, int skip = -2) {
     // 4 independent loads per lane and round (16 candidates per group): a cell of ~10 points is one round
     const int last = start + count - 1;
     for (int k = start + sub; k <= last; k += 16) {
         const int k1 = min(k + 4, last), k2 = min(k + 8, last), k3 = min(k + 12, last);
         const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
-        consider(q0, k, px, py, pz, b);
-        consider(q1, k1, px, py, pz, b);
-        consider(q2, k2, px, py, pz, b);
-        consider(q3, k3, px, py, pz, b);
+        consider(q0, k, px, py, pz, b, skip);
+        consider(q1, k1, px, py, pz, b, skip);
+        consider(q2, k2, px, py, pz, b, skip);
+        consider(q3, k3, px, py, pz, b, skip);
     }
 }
 
@@ -146,14 +146,21 @@ __device__ inline bool coop_rings(const GridView& lv, float px, float py, float 
 // `seed_*` (optional, seed_pos < 0: none): a map point already known to be a candidate — the neighbour cached by the
 // previous iteration.  It only tightens the starting upper bound (neighbour cells farther than it are pruned before
 // they are read); the (distance, index) minimum over the map is the same with or without it.
-__device__ inline Best search_rows_group(const GridView& g, float px, float py, float pz, int sub, int max_rings,
-                                         int2* __restrict__ stack, int stride, float seed_d2 = INFINITY,
-                                         int seed_idx = 0x7fffffff, int seed_pos = -1) {
-    Best b;
-    b.d2 = seed_d2;
-    b.idx = seed_idx;
-    b.pos = seed_pos;
+__device__ inline Near3 search_rows_group(const GridView& g, float px, float py, float pz, int sub, int max_rings,
+                                          int2* __restrict__ stack, int stride, float seed_d2 = INFINITY,
+                                          int seed_idx = 0x7fffffff, int seed_pos = -1) {
+    // Through ring 1 every lane keeps its LOCAL best (and the bound of the other points it has seen or pruned): only the
+    // pruning radius r2 — the best squared distance any lane has found — is shared.  What the four lanes hold at the end
+    // is the candidate set of Near3; a merge after every step would throw three of the four away.
+    Near3 out;
+    out.pos1 = out.pos2 = -1;
+    Best& b = out.b;
+    const int skip = sub == 0 ? -2 : seed_idx;  // the seed is lane 0's
+    b.d2 = sub == 0 ? seed_d2 : INFINITY;
+    b.idx = sub == 0 ? seed_idx : 0x7fffffff;
+    b.pos = sub == 0 ? seed_pos : -1;
     b.second = INFINITY;
+    float r2 = seed_d2;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -183,8 +190,10 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
     }
     if (e.key == key) {
         // ---- row path
-        scan_strided4(g, e.start, e.count, sub, px, py, pz, b);
-        group_min4(b);
+        scan_strided4(g, e.start, e.count, sub, px, py, pz, b, skip);
+        r2 = fminf(r2, quad_min(b.d2));
+        // neighbour cells are pruned when their box is farther than the best so far by `prune_guard` (see search_rows_wave)
+        const float prune_r = sqrtf(r2) + g.prune_guard, prune2 = prune_r * prune_r;
         int nl = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -193,7 +202,7 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                         gz = axis_gap(c / 9 - 1, fz, h);
             const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
-            if (gap2 > b.d2) {
+            if (gap2 > prune2) {
                 b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
                 continue;
             }
@@ -255,10 +264,10 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
                     pos[m] = j + stack[(e >> 2) * stride + ((e & 3) - sub)].x;
                 }
                 const float4 q0 = g.pts[pos[0]], q1 = g.pts[pos[1]], q2 = g.pts[pos[2]], q3 = g.pts[pos[3]];
-                consider(q0, pos[0], px, py, pz, b);
-                consider(q1, pos[1], px, py, pz, b);
-                consider(q2, pos[2], px, py, pz, b);
-                consider(q3, pos[3], px, py, pz, b);
+                consider(q0, pos[0], px, py, pz, b, skip);
+                consider(q1, pos[1], px, py, pz, b, skip);
+                consider(q2, pos[2], px, py, pz, b, skip);
+                consider(q3, pos[3], px, py, pz, b, skip);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the columns go back to their lanes)
@@ -275,7 +284,7 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
                 const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h),
                             gz = axis_gap(c / 9 - 1, fz, h);
                 const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
-                if (gap2 > b.d2) {
+                if (gap2 > prune2) {
                     b.second = fminf(b.second, gap2);
                     continue;
                 }
@@ -286,13 +295,13 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             const int last = st + cnt - 1, k0 = st + k;
             const int k1 = min(k0 + 1, last), k2 = min(k0 + 2, last), k3 = min(k0 + 3, last);
             const float4 q0 = g.pts[k0], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
-            consider(q0, k0, px, py, pz, b);
-            consider(q1, k1, px, py, pz, b);
-            consider(q2, k2, px, py, pz, b);
-            consider(q3, k3, px, py, pz, b);
+            consider(q0, k0, px, py, pz, b, skip);
+            consider(q1, k1, px, py, pz, b, skip);
+            consider(q2, k2, px, py, pz, b, skip);
+            consider(q3, k3, px, py, pz, b, skip);
             k += 4;
         }
-        group_min4(b);
+        r2 = fminf(r2, quad_min(b.d2));
     } else {
         // ---- own cell empty: hashed probes of the 26 neighbours, split over the 4 lanes
         for (int c0 = sub; c0 < 26; c0 += 4) {
@@ -300,23 +309,66 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             const int ox = c % 3 - 1, oy = (c / 3) % 3 - 1, oz = c / 9 - 1;
             const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
             const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
-            if (gap2 > b.d2) {
+            if (gap2 > fminf(r2, b.d2)) {
                 b.second = fminf(b.second, gap2);
                 continue;
             }
             int start, count;
-            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count)) scan_cell_1nn(g, start, count, px, py, pz, b);
+            if (grid_lookup(g, cx + ox, cy + oy, cz + oz, start, count))
+                scan_cell_1nn(g, start, count, px, py, pz, b, skip);
         }
-        group_min4(b);
+        r2 = fminf(r2, quad_min(b.d2));
     }
     float bound = h + edge;
-    bool resolved = b.d2 <= bound * bound * 0.999999f;  // group-uniform: b is shared after the reduction
-    // nothing outside the 27-cell block is closer than `bound` (when that settles the search); otherwise b.second keeps
-    // bounding the OTHER points seen or pruned so far and the rings below extend it
-    if (resolved) b.second = fminf(b.second, bound * bound * 0.999999f);
+    bool resolved = r2 <= bound * bound * 0.999999f;  // group-uniform: r2 is shared
     if (g.dbg && sub == 0) atomicAdd(&g.dbg[resolved ? 0 : 1], 1);
     if (g.dbg && sub == 0 && e.key != key) atomicAdd(&g.dbg[5], 1);
-    if (!resolved) {
+    if (resolved) {
+        // ---- settled by ring 1: the candidate set.  Nothing outside the 27-cell block is closer than `bound`; every
+        // point inside it that is not one of the four local bests is bounded by its lane's `second`.
+        float L2 = fminf(quad_min(b.second), bound * bound * 0.999999f);
+        {   // the same point in two lanes (a clamped tail of a 4-wide fetch): the higher lane gives it up
+            const int i1 = quad_xor<1>(b.idx), i2 = quad_xor<2>(b.idx), i3 = quad_xor<3>(b.idx);
+            const bool dup = (i1 == b.idx && (sub ^ 1) < sub) || (i2 == b.idx && (sub ^ 2) < sub) ||
+                             (i3 == b.idx && (sub ^ 3) < sub);
+            if (dup || b.pos < 0) {
+                b.d2 = INFINITY;
+                b.idx = 0x7fffffff;
+                b.pos = -1;
+            }
+        }
+        int rank = 0;  // place of this lane's candidate among the four, by (distance, index, lane)
+        {
+            float od2 = quad_xor<1>(b.d2);
+            int oi = quad_xor<1>(b.idx);
+            rank += (better(od2, oi, b.d2, b.idx) || (od2 == b.d2 && oi == b.idx && (sub ^ 1) < sub)) ? 1 : 0;
+            od2 = quad_xor<2>(b.d2);
+            oi = quad_xor<2>(b.idx);
+            rank += (better(od2, oi, b.d2, b.idx) || (od2 == b.d2 && oi == b.idx && (sub ^ 2) < sub)) ? 1 : 0;
+            od2 = quad_xor<3>(b.d2);
+            oi = quad_xor<3>(b.idx);
+            rank += (better(od2, oi, b.d2, b.idx) || (od2 == b.d2 && oi == b.idx && (sub ^ 3) < sub)) ? 1 : 0;
+        }
+        int p0 = rank == 0 ? b.pos : -1, p1 = rank == 1 ? b.pos : -1, p2 = rank == 2 ? b.pos : -1;
+        int i0 = rank == 0 ? b.idx : -1;
+        float d0 = rank == 0 ? b.d2 : INFINITY, d3 = rank == 3 ? b.d2 : INFINITY;
+        p0 = max(p0, quad_xor<1>(p0)), p1 = max(p1, quad_xor<1>(p1)), p2 = max(p2, quad_xor<1>(p2));
+        i0 = max(i0, quad_xor<1>(i0));
+        d0 = fminf(d0, quad_xor<1>(d0)), d3 = fminf(d3, quad_xor<1>(d3));
+        p0 = max(p0, quad_xor<2>(p0)), p1 = max(p1, quad_xor<2>(p1)), p2 = max(p2, quad_xor<2>(p2));
+        i0 = max(i0, quad_xor<2>(i0));
+        d0 = fminf(d0, quad_xor<2>(d0)), d3 = fminf(d3, quad_xor<2>(d3));
+        b.d2 = d0;
+        b.idx = p0 >= 0 ? i0 : 0x7fffffff;
+        b.pos = p0;
+        b.second = fminf(L2, d3);  // the fourth local best is one of the others
+        out.pos1 = p1;
+        out.pos2 = p2;
+        return out;
+    }
+    // ---- not settled: the merged best of the group from here on (shared by the four lanes, as the rings expect)
+    group_min4(b);
+    {
         // rings 2..max_rings of the fine level, then the coarse level (4x cells), every ring split over the 4 lanes
         if (g.dbg && sub == 0) atomicAdd(&g.dbg[2], 1);
         resolved = max_rings >= 2 && coop_rings(g, px, py, pz, sub, 2, max_rings, b, stack, stride);
@@ -336,7 +388,7 @@ __device__ inline Best search_rows_group(const GridView& g, float px, float py, 
             scan_cell_1nn(g, 0, g.m, px, py, pz, b);  // every other point is seen: b.second = the second-nearest
         }
     }
-    return b;
+    return out;
 }
 
 __device__ inline void wave_min64(Best& b) {
@@ -368,12 +420,14 @@ __device__ inline void wave_min64(Best& b) {
 // the caller hands the query to the generic 4-lane path (coarse level, exhaustive scan).
 __device__ inline bool search_rows_wave(const GridView& g, float px, float py, float pz, int lane, int max_rings,
                                         int* __restrict__ wl, float seed_d2, int seed_idx, int seed_pos, Best& b,
-                                        Best* runner = nullptr) {
+                                        Best* runner = nullptr, Best* third = nullptr) {
     // `runner` (optional): the SECOND nearest map point, with runner->second = a lower bound on the squared distance of
     // every point other than the two — what lets the NN cache settle a query that sits between two map points by
     // comparing the pair instead of searching again (pos = -1 when the search cannot name it cheaply: more than 128
     // candidates, or not settled by ring 1)
+    // `third` (with `runner`): the third nearest, third->second bounding every point other than the three
     if (runner) runner->pos = -1;
+    if (third) third->pos = -1;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -406,13 +460,17 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
     b.idx = seed_idx;
     b.pos = seed_pos;
     b.second = INFINITY;
+    const float prune_r = sqrtf(seed_d2) + g.prune_guard, prune2 = prune_r * prune_r;
     int cnt = 0;
     float pruned_gap = INFINITY;  // this lane's pruned cell (if any): all its points are at least that far
     if (lane < 27) {
         const float gx = axis_gap(c % 3 - 1, fx, h), gy = axis_gap((c / 3) % 3 - 1, fy, h), gz = axis_gap(c / 9 - 1, fz, h);
         const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
         cnt = rc.y;
-        if (cnt > 0 && gap2 > seed_d2) {
+        // (pruned only when the box is farther than the seed by `prune_guard`: the gap of a pruned cell bounds L, and a
+        // ball that all but touches a cell face would leave the entry a slack of micrometres — such queries, ~20 of a
+        // 131 072-point scan, missed in every late launch; inside the guard band the cell is scanned and its POINTS bound L)
+        if (cnt > 0 && gap2 > prune2) {
             b.second = gap2;  // every point of a pruned cell is at least that far
             pruned_gap = gap2;
             cnt = 0;
@@ -471,6 +529,23 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
             wave_min64(r);
             r.second = fminf(r.second, bound * bound * 0.999999f);
             *runner = r;
+            if (third && r.pos >= 0) {
+                Best t;
+                t.d2 = INFINITY;
+                t.idx = 0x7fffffff;
+                t.pos = -1;
+                t.second = pruned_gap;
+                const int ia = __float_as_int(qa.w), ib = __float_as_int(qb.w);
+                if (pa >= 0 && ia != b.idx && ia != r.idx) consider(qa, pa, px, py, pz, t);
+                if (pb >= 0 && ib != b.idx && ib != r.idx) consider(qb, pb, px, py, pz, t);
+                if (seed_pos >= 0 && seed_idx != b.idx && seed_idx != r.idx && lane == 0) {
+                    const float4 qs = g.pts[seed_pos];
+                    consider(qs, seed_pos, px, py, pz, t);
+                }
+                wave_min64(t);
+                t.second = fminf(t.second, bound * bound * 0.999999f);
+                *third = t;
+            }
         }
         return true;
     }
@@ -512,7 +587,7 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
     }
     float px = t4.x, py = t4.y, pz = t4.z;
     if (transform) transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
-    const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], 256);
+    const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], 256).b;
     if (sub != 0) return;
     nn_pos[qi] = b.pos;
     if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
@@ -610,6 +685,8 @@ struct IterInputs {
     // j-th workgroup of the class -> row band * swz_band_rows + (j >> swz_bpr_shift), block (j & bpr - 1) of the
     // sector's bpr blocks of that row.  A permutation of the logical workgroups (queries and partial rows belong to the
     // LOGICAL index): same bits.
+    float refresh_margin;    // ONE early launch (it searches anyway): an entry whose slack is about to run out counts as
+                             // a miss and is searched again there, not alone in a late launch that nothing else holds up
     int swz_bpr_shift;       // log2(blocks per row and sector), -1: identity
     int swz_sectors;         // azimuth sectors (8, 4, 2 or 1)
     int swz_band_rows;       // image rows per elevation band
@@ -726,15 +803,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // are in flight while the lead workgroup solves
     const int lq = threadIdx.x, qi = q0 + lq;
     bool valid = false;
-    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq, cq2 = cq, cn2 = cq;
-    int4 c = make_int4(-1, 0, -1, 0);
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq, cq2 = cq, cn2 = cq,
+           cq3 = cq, cn3 = cq;
+    int4 c = make_int4(-1, 0, -1, -1);
     int seed_o = -1, seed_sp = -1;
     if (lq < Q) {
         valid = qi < in.n;
         if (valid) {
             t4 = in.tgt[qi];
             valid = target_valid(t4.x, t4.y, t4.z, in.mode);
-            if (!valid && !in.use_cache) in.nn_cache[qi] = make_int4(-1, 0, -1, 0);  // masked row: no neighbour, no seed
+            if (!valid && !in.use_cache) in.nn_cache[qi] = make_int4(-1, 0, -1, -1);  // masked row: no neighbour, no seed
         }
         if (valid) {
             if (in.use_cache) {
@@ -742,9 +820,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 if (c.x >= 0) {
                     cq = g.pts[c.x & CACHE_POS_MASK];
                     cn = in.normals[c.x & CACHE_POS_MASK];  // speculative: needed on a hit only
-                    if (Q == THREADS && c.z >= 0) {         // the runner-up a whole-wave search named (late iterations)
+                    if (c.z >= 0) {  // the other members of the candidate set the search left
                         cq2 = g.pts[c.z];
                         cn2 = in.normals[c.z];
+                    }
+                    if (c.w >= 0) {
+                        cq3 = g.pts[c.w];
+                        cn3 = in.normals[c.w];
                     }
                 }
             } else if (in.frame_seed) {
@@ -825,8 +907,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                     float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
                     float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     int hit_pos = c.x & CACHE_POS_MASK;
-                    if (Q == THREADS && c.z >= 0) {
-                        // a pair: the nearer of the two is THE neighbour as long as everything else (>= L) stays farther
+                    // the candidate set: its nearest member is THE neighbour as long as everything else (>= L) stays farther
+                    if (c.z >= 0) {
                         dx = cq2.x - px, dy = cq2.y - py, dz = cq2.z - pz;
                         const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                         if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(cq.w))) {
@@ -835,15 +917,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                             cn = cn2;
                             hit_pos = c.z;
                         }
-                    } else if (c.z >= 0) {
-                        c.y = 0;  // (a pair met by the 128-query shape — the shapes never alternate that way: a miss)
+                    }
+                    if (c.w >= 0) {
+                        dx = cq3.x - px, dy = cq3.y - py, dz = cq3.z - pz;
+                        const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (better(e2, __float_as_int(cq3.w), d2, __float_as_int(cq.w))) {
+                            d2 = e2;
+                            cq = cq3;
+                            cn = cn3;
+                            hit_pos = c.w;
+                        }
                     }
                     if (age >= 1 && age <= CACHE_HIST) {
                         float ox, oy, oz;  // where the target was when its neighbour was searched
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
                         const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta;
+                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta - in.refresh_margin;
                     }
                     if (hit) {  // (nothing to write: the entry stays as the search left it)
                         point_to_plane_row(px, py, pz, cq.x, cq.y, cq.z, cn.x, cn.y, cn.z, ap.scheme, ap.sigma, row);
@@ -884,17 +974,18 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         for (int m = wave; m < listed; m += THREADS / 64) {
             const float4 mp = miss_p[m];
             const int4 ms = miss_seed[m];
-            Best b, r2;
-            if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b,
-                                  Q == THREADS ? &r2 : nullptr))
+            Best b, r2, r3;
+            if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b, &r2,
+                                  &r3))
                 continue;
             if (lane == 0) {
                 const int lq = __float_as_int(mp.w);
-                // (512-query shape: the runner-up rides along, and L then bounds everything but the pair)
-                const bool pair = Q == THREADS && r2.pos >= 0 && b.pos >= 0;
+                // the runner-up and the third ride along: L then bounds everything but the set
+                const bool pair = r2.pos >= 0 && b.pos >= 0, triple = pair && r3.pos >= 0;
                 in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now),
-                                                 __float_as_int(sqrtf(pair ? r2.second : b.second) * 0.999999f),
-                                                 pair ? r2.pos : -1, 0);
+                                                 __float_as_int(sqrtf(triple ? r3.second : (pair ? r2.second : b.second)) *
+                                                                0.999999f),
+                                                 pair ? r2.pos : -1, triple ? r3.pos : -1);
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -926,12 +1017,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         for (int grp = threadIdx.x >> 2; grp < nmiss; grp += THREADS / 4) {  // group-uniform
             const float4 mp = miss_p[grp];
             const int4 ms = miss_seed[grp];
-            const Best b = search_rows_group(g, mp.x, mp.y, mp.z, sub, in.max_rings, &cellstack[0][threadIdx.x],
-                                             THREADS, __int_as_float(ms.x), ms.y, ms.z);
+            const Near3 near = search_rows_group(g, mp.x, mp.y, mp.z, sub, in.max_rings, &cellstack[0][threadIdx.x],
+                                                 THREADS, __int_as_float(ms.x), ms.y, ms.z);
+            const Best& b = near.b;
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
                 in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
-                                                 -1, 0);
+                                                 near.pos1, near.pos2);
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -1877,6 +1969,7 @@ static GridView make_view(icp_ctx* ctx) {
     g.cpts = ctx->csorted.as<float4>();
     g.pos_of_orig = ctx->pos_of_orig.as<int>();
     g.flat_rows = ctx->flat_rows;
+    g.prune_guard = ctx->prune_guard;
     g.hood = ctx->hoods_valid ? ctx->hood.as<float4>() : nullptr;
     g.dbg = ctx->search_stats == 1 ? ctx->dbg_counts.as<int>() : nullptr;
     g.stamps = ctx->search_stats ? reinterpret_cast<long long*>(ctx->dbg_counts.as<int>() + 16) : nullptr;
@@ -2091,6 +2184,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
     in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
+    in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;
     in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;
     if (ctx->xcd_sectors && blocks >= 64 && blocks % 8 == 0) {

@@ -41,6 +41,14 @@ struct Best {
 
 __device__ inline bool better(float d2, int idx, float bd2, int bidx) { return d2 < bd2 || (d2 == bd2 && idx < bidx); }
 
+// What a 4-lane search of the row path knows at its end: the nearest map point (b: distance, original index, position),
+// up to two more candidates by position (-1: none) and, in b.second, a lower bound on the squared distance of every map
+// point that is NOT one of those — the NN cache keeps the set and settles later iterations by comparing its members.
+struct Near3 {
+    Best b;
+    int pos1, pos2;
+};
+
 __device__ inline bool grid_lookup(const GridView& g, int cx, int cy, int cz, int& start, int& count) {
     const unsigned long long key = pack_cell(cx, cy, cz);
     unsigned int slot = hash_cell(key) & g.mask;
@@ -62,12 +70,15 @@ __device__ inline float axis_gap(int o, float f, float h) {
     return o < 0 ? f + (float)(-o - 1) * h : (h - f) + (float)(o - 1) * h;
 }
 
-__device__ inline void consider(const float4 q, int pos, float px, float py, float pz, Best& b) {
+// `skip` (optional): an original index this lane must not take — the seed of a 4-lane search belongs to lane 0 alone
+// (the lanes keep local bests until the end: the same point in two of them would waste a place of the candidate set)
+__device__ inline void consider(const float4 q, int pos, float px, float py, float pz, Best& b, int skip = -2) {
     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const int idx = __float_as_int(q.w);
-    if (idx == b.idx) return;  // the current best again (clamped tail of a 4-wide fetch, a seed met in its cell, or the
-                               // same point seen through the coarse level): original indices are unique
+    if (idx == b.idx || idx == skip) return;  // the current best again (clamped tail of a 4-wide fetch, a seed met in its
+                                              // cell, or the same point seen through the coarse level): original indices
+                                              // are unique
     if (better(d2, idx, b.d2, b.idx)) {
         b.second = fminf(b.second, b.d2);
         b.d2 = d2;
@@ -80,15 +91,16 @@ __device__ inline void consider(const float4 q, int pos, float px, float py, flo
 
 // candidates are fetched four at a time (independent 16-byte loads in flight together); the tail re-reads the last
 // point of the cell, which cannot change the (d2, index) minimum
-__device__ inline void scan_cell_1nn(const GridView& g, int start, int count, float px, float py, float pz, Best& b) {
+__device__ inline void scan_cell_1nn(const GridView& g, int start, int count, float px, float py, float pz, Best& b,
+                                     int skip = -2) {
     const int last = start + count - 1;
     for (int k = start; k <= last; k += 4) {
         const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
         const float4 q0 = g.pts[k], q1 = g.pts[k1], q2 = g.pts[k2], q3 = g.pts[k3];
-        consider(q0, k, px, py, pz, b);
-        consider(q1, k1, px, py, pz, b);
-        consider(q2, k2, px, py, pz, b);
-        consider(q3, k3, px, py, pz, b);
+        consider(q0, k, px, py, pz, b, skip);
+        consider(q1, k1, px, py, pz, b, skip);
+        consider(q2, k2, px, py, pz, b, skip);
+        consider(q3, k3, px, py, pz, b, skip);
     }
 }
 
