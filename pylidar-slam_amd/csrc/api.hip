@@ -345,6 +345,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "narrow_from") ctx->narrow_from = (int)iv;
     else if (k == "profile_every") ctx->prof.every = iv < 1 ? 1 : (int)iv;
     else if (k == "wave_misses") ctx->wave_misses = iv < 0 ? 0 : (int)iv;
+    else if (k == "wave_misses_dense") ctx->wave_misses_dense = iv < 0 ? 0 : (int)iv;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
     else if (k == "knn_rings") ctx->knn_rings = iv;
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;

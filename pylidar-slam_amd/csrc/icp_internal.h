@@ -283,6 +283,7 @@ struct icp_ctx {
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
     int narrow_from = 3;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
+    int wave_misses_dense = 4;         // "wave_misses_dense": the same threshold in the 128-query shape (early iterations)
     int wave_misses = 24;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one

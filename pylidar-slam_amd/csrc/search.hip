@@ -2183,7 +2183,9 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.mode = ctx->tgt_mode;
     in.max_rings = ctx->cfg.max_rings;
     in.use_cache = use_cache;
-    in.wave_misses = min(ctx->wave_misses, IT_QUERIES);
+    // (the 128-query shape runs while most workgroups search: a wave per miss is a round of ~8 us under that load, the
+    // 4-lane groups take up to 128 misses in 10-15 us — whole waves only for a handful)
+    in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;
     in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;

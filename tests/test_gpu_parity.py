@@ -341,9 +341,10 @@ def test_schedule_options_are_bit_identical(torch_cuda):
     model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
     variants = {"default": {}, "nocache": {"nn_cache": 0}, "cache_noseed": {"nn_cache": 1},
                 "sparse_build": {"iterate_dense": 0},
-                "no_wave_search": {"wave_misses": 0},
+                "no_wave_search": {"wave_misses": 0, "wave_misses_dense": 0},
                 "never_narrow": {"narrow_from": -1}, "narrow_early": {"narrow_from": 1},
-                "wave_search_always": {"wave_misses": 128},
+                "wave_search_always": {"wave_misses": 128, "wave_misses_dense": 128},
+                "no_prune_guard": {"prune_guard": 0.0}, "no_refresh": {"refresh_margin": 0.0},
                 "big_cells": {"target_occupancy": 40}, "small_cells": {"target_occupancy": 2},
                 "no_frame_seed": {"frame_seed": 0},
                 "lanes2": {"knn_lanes": 2}, "scan_gives_up": {"scan_poll_limit": 0},
