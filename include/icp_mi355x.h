@@ -111,13 +111,19 @@ int icp_synchronize(icp_ctx* ctx);
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "wave_misses" n (24)            workgroups with up to n cache misses search each of them with a whole wave
- *   "narrow_from" n (6; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each (few
+ *   "wave_misses_dense" n (4)       the same threshold in the 128-queries-per-block launches of the early iterations
+ *   "narrow_from" n (3; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each (few
  *                                   searches expected), instead of 128 with a 4-lane group each; same bits
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
- *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (10), "search_stats" 0 | 1 | 2 (0)
+ *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (16), "search_stats" 0 | 1 | 2 (0)
  *   "scan_poll_limit" n (2^20)      grid build: polls of a predecessor tile's descriptor before a tile of the one-launch table
  *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
+ *   "prune_guard" m (0.002)         searches scan neighbour cells whose box is within m metres of the best distance instead of
+ *                                   pruning them (the gap of a pruned cell bounds the cache's L: a guard keeps L off the best)
+ *   "refresh_at" n (6), "refresh_margin" m (1e-4)   in launch n, NN-cache entries with less slack than m are searched again
+ *   "xcd_sectors" 0 | 1 (1)         the workgroups one XCD receives take one azimuth sector of the range image
+ *   "lead_after_dense" 0 | 1 (1)    the first 512-query launch also solves the last 128-query one
  *   "lead_solve" 0 | 1 (1)          launched / unpolled registrations: the 6x6 solve of iteration k runs in an extra workgroup
  *                                   at the head of the (late, 512-queries-per-block) launch k + 1, which publishes the pose to
  *                                   the workgroups of that launch through a mailbox, instead of a launch of its own; same bits

@@ -361,7 +361,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "prune_guard") ctx->prune_guard = value > 0.0 ? (float)value : 0.f;
     else if (k == "hoods") ctx->hoods = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
-    else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 10.0;
+    else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 16.0;
     else if (k == "search_stats") {
         ctx->search_stats = (int)iv;  // 1: path counters + phase stamps, 2: stamps only (no atomics)
         if (ctx->search_stats) {  // 16 path counters + 4 phase timestamps per workgroup and iteration

@@ -263,7 +263,7 @@ struct icp_ctx {
     int64_t normals_eager_count = 0;
     float cell_h = 0.5f;               // cell edge of the current grid (auto-tuned when cfg.cell_size <= 0)
     int occupied_cells = 0;
-    double target_occupancy = 10.0;    // auto-tuning target, map points per occupied cell (option "target_occupancy")
+    double target_occupancy = 16.0;    // auto-tuning target, map points per occupied cell (option "target_occupancy")
     int64_t stats_m = 0;               // map size the occupancy figure belongs to
     bool stats_pending = false;
     int64_t stats_m_pending = 0;
