@@ -167,9 +167,13 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // other two, one launch less per frame.
 __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
-                             int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket) {
+                             int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket,
+                             unsigned long long* __restrict__ hood_used) {
     __shared__ float T[16];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *scan_ticket = 0;  // the tile numbers of this build's k_grid_scan
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
+        if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
+    }
     const long long first = (long long)blockIdx.x * blockDim.x;
     const bool moves = first < move.m;  // block-uniform
     if (moves && threadIdx.x == 0) map_move_prepare(move, T);
@@ -651,6 +655,14 @@ int build_grid(icp_ctx* ctx) {
             ICP_HIP(ctx, hipMemsetAsync(ctx->scan_desc.ptr, 0, ctx->scan_desc.bytes, ctx->stream));
         }
     }
+    // (the neighbourhood lists are allocated before the first launch of the build: their space counter is zeroed by it)
+    const bool with_hoods = ctx->hoods && m <= (1ll << 22);
+    const size_t hood_cap = (size_t)27 * (size_t)m;
+    unsigned long long* hood_used = nullptr;
+    if (with_hoods) {
+        ICP_HIP(ctx, ctx->hood.reserve(hood_cap * sizeof(float4) + 64));
+        hood_used = (unsigned long long*)(ctx->hood.as<char>() + hood_cap * sizeof(float4));
+    }
     int* scan_ticket = ctx->scan_desc.as<int>();
     unsigned long long* desc = ctx->scan_desc.as<unsigned long long>() + 8;
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
@@ -663,7 +675,7 @@ int build_grid(icp_ctx* ctx) {
         if (move.m > span) span = move.m;
         hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
                            (unsigned int)n2, ctx->nn_cache.as<int4>(), ctx->sorted_pts.as<float4>(), seed_n,
-                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket);
+                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket, hood_used);
     }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
@@ -683,11 +695,9 @@ int build_grid(icp_ctx* ctx) {
     // neighbourhood lists for the kNN normals (option "hoods"; maps beyond 2^22 points keep the row walk: 27 x 16 B per
     // point would be gigabytes).  The start of a run is an int: 27 M < 2^31 holds for every map that gets here
     ctx->hoods_valid = false;
-    if (ctx->hoods && m <= (1ll << 22)) {
-        const size_t cap = (size_t)27 * (size_t)m;
-        ICP_HIP(ctx, ctx->hood.reserve(cap * sizeof(float4) + 64));
-        unsigned long long* used = (unsigned long long*)(ctx->hood.as<char>() + cap * sizeof(float4));
-        ICP_HIP(ctx, hipMemsetAsync(used, 0, sizeof(unsigned long long), ctx->stream));
+    if (with_hoods) {
+        const size_t cap = hood_cap;
+        unsigned long long* used = hood_used;
         const unsigned hb = (unsigned)((m + HOOD_THREADS / 32 - 1) / (HOOD_THREADS / 32));  // (cells <= points)
         hipLaunchKernelGGL(k_hood_build, dim3(hb), dim3(HOOD_THREADS), 0, ctx->stream, ctx->slot_of_cell.as<int>(),
                            ncells_dev, ctx->rows.as<int2>(), ctx->sorted_pts.as<float4>(), ctx->hood.as<float4>(),
