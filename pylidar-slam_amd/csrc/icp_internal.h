@@ -274,7 +274,7 @@ struct icp_ctx {
     int64_t tgt_n = 0;
     int tgt_mode = 0;
     icp::DeviceBuffer nn_pos;          // int[N]
-    icp::DeviceBuffer nn_cache;        // int4[N]: (NN position | iteration << 24, bits(L), runner-up position or -1, 0) — L = lower bound on the distance to every other map point
+    icp::DeviceBuffer nn_cache;        // int4[N]: (NN position | iteration << 24, bits(L), two more candidate positions or -1) — L = lower bound on the distance to every map point outside that set
     int iter_in_registration = 0;
     int cost = 0;                      // icp_cost of the registration loop (icp_set_cost)
     // tuning options (icp_set_option; none of them changes a result)

@@ -647,11 +647,16 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 // ---------------------------------------------------------------------------------------------------------------------
 // The kernel, with in-block compaction of the cache misses.
 //
-// NN cache (exact): a search leaves, besides the neighbour, a lower bound L on the distance to EVERY OTHER map point
-// (second-best candidate, box distance of every pruned cell, the bound of the last ring) — and the iteration k it ran in.
-// The target has moved by delta = |T_now p - T_k p| since (T_k from the pose history of the registration), so every other
-// point is still >= L - delta away: if the cached neighbour is strictly closer than that it is still THE nearest
-// neighbour and the search is skipped.  (Round 2 subtracted the step of every iteration from L instead: a sum of
+// NN cache (exact): a search leaves a CANDIDATE SET — the neighbour and up to two more map points (the local bests of
+// the other lanes of a 4-lane search; the runner-up and the third of a whole-wave search) — and a lower bound L on the
+// distance to EVERY map point outside the set (the next candidate, the box distance of every pruned cell, the bound of
+// the last ring), plus the iteration k it ran in.  The target has moved by delta = |T_now p - T_k p| since (T_k from the
+// pose history of the registration), so every point outside the set is still >= L - delta away: if the nearest member of
+// the set is strictly closer than that it is THE nearest neighbour and the search is skipped.  (One cached point made
+// the slack the gap between the first and the second neighbour: in a map merged from eight scans that is millimetres,
+// and half the scan searched again after a 5 mm step.  Cells are pruned only beyond a guard band of the best distance
+// — "prune_guard" — because the box distance of a pruned cell is part of L: a ball that all but touches a cell face left
+// a slack of micrometres, and those ~20 queries of a scan missed in every late launch.)  (Round 2 subtracted the step of every iteration from L instead: a sum of
 // |steps| that keeps growing while the pose merely jitters around its fixed point — it eroded the slack of the same few
 // dozen boundary queries in every late iteration, and rewrote the 1 MB cache per launch to do so.  The displacement since
 // the search stops growing once the pose has converged, and a hit writes nothing.)
@@ -670,8 +675,8 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
 struct IterInputs {
     const float4* tgt;       // targets (x, y, z, row)
     const float4* normals;   // by cell-sorted position
-    int4* nn_cache;          // per query: (position | iteration of the search << 24, bits(L), position of the runner-up
-                             // or -1, 0) — L bounds every map point other than the neighbour (and the runner-up, if named)
+    int4* nn_cache;          // per query: (position | iteration of the search << 24, bits(L), positions of up to two more
+                             // candidates or -1) — L bounds every map point that is not a member of that candidate set
     const float* pose_hist;  // [iteration][12]: the pose every earlier iteration of this registration ran with
     const int* frame_seed;   // original map index per query or nullptr
     double* partials;

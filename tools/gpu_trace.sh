@@ -19,9 +19,9 @@ print("per-iteration kernel us (median over last 20 frames):", [round(statistics
 half=rows[len(rows)//2:]
 tot=collections.Counter()
 for r in half: tot[r["Kernel_Name"].split("(")[0][:60]]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
-n=len([r for r in half if "k_sum_solve" in r["Kernel_Name"]])/20
+n=max(1,len([r for r in half if "k_project(" in r["Kernel_Name"]]))  # frames: one projection each
 span=(int(half[-1]["End_Timestamp"])-int(half[0]["Start_Timestamp"]))/1e3/n
 busy=sum(tot.values())/n
-print(f"frames {n:.1f}: wall {span:.1f} us/frame, kernel time {busy:.1f} us/frame, gaps {span-busy:.1f}")
+print(f"frames {n}: wall {span:.1f} us/frame, kernel time {busy:.1f} us/frame, gaps {span-busy:.1f}")
 for k,v in tot.most_common(14): print(f"{k:62s} {v/n:8.1f} us/frame")
 PY

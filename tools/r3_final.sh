@@ -30,3 +30,4 @@ timeout 600 python bench.py --workload c4 --steps 6 --warmup 2 > $OUT/bench_c4.j
 bash tools/gpu_trace.sh $TAG/trace | tail -20
 bash tools/pmc.sh k_iterate_compact > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_k_iterate_compact.json $OUT/ 2>/dev/null; tail -c 400 $OUT/pmc.log; echo
 bash tools/pmc_kernel.sh k_iterate_compact > $OUT/pmc_sq_iterate.txt 2>&1; cat $OUT/pmc_sq_iterate.txt
+bash tools/pmc_by_iter.sh $TAG > /dev/null 2>&1; head -30 $OUT/pmc_by_iter.txt | cut -c1-240
