@@ -1162,6 +1162,7 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     if (!ctx->normals_ready && wants_eager_normals(ctx, n) && (rc = launch_normals_all(ctx))) return rc;
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
+    ctx->searches_in_registration = 0;
     return ICP_OK;
 }
 

@@ -307,6 +307,9 @@ struct icp_ctx {
     float prune_guard = 2e-3f;         // "prune_guard" (GridView)
     float refresh_margin = 1e-4f;      // "refresh_margin" (m) / "refresh_at" (iteration): NN-cache entries with less slack than
     int refresh_at = 6;                // that are searched again in that one launch, which searches anyway (IterInputs)
+    int searches_in_registration = 0;  // k_search_rows launches of the registration in progress (unfused loops): from the
+    long long nn_pos_n = -1;           // second on, nn_pos (of nn_pos_n targets against grid generation nn_pos_gen) seeds
+    unsigned long long nn_pos_gen = 0; // the searches
     int lead_after_dense = 1;          // "lead_after_dense": the first narrow launch solves the last dense one (enqueue_iterations)
     int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
     int hoods = 1;                     // "hoods": neighbourhood lists for the kNN normals

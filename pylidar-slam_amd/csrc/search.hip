@@ -571,10 +571,14 @@ __device__ inline bool search_rows_wave(const GridView& g, float px, float py, f
     return true;
 }
 
+// `seeded`: nn_pos holds the neighbours the previous iteration of this registration found for the same targets — each
+// seeds its query's search (a candidate with a tight bound: most neighbour cells fail the box test unread; like any seed
+// it cannot change the minimum).  The unfused loops (point-to-point alignment, lazily estimated normals) searched from
+// scratch in every iteration: 128 us per launch at the headline sizes.
 __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* __restrict__ tgt, int n, int mode,
                                                      int transform, RegState* __restrict__ st, int max_rings,
-                                                     int* __restrict__ nn_pos, int* __restrict__ nflag,
-                                                     int* __restrict__ worklist, int queue_normals) {
+                                                     int* nn_pos, int* __restrict__ nflag,
+                                                     int* __restrict__ worklist, int queue_normals, int seeded) {
     __shared__ int2 cellstack[7][256];
     if (st->done) return;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,7 +591,20 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
     }
     float px = t4.x, py = t4.y, pz = t4.z;
     if (transform) transform_point(st->pose, t4.x, t4.y, t4.z, px, py, pz);
-    const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], 256).b;
+    float seed_d2 = INFINITY;
+    int seed_idx = 0x7fffffff, seed_pos = -1;
+    if (seeded) {
+        const int sp = nn_pos[qi];  // (read by the four lanes before lane 0 replaces it below)
+        if (sp >= 0 && sp < g.m) {
+            const float4 q = g.pts[sp];
+            const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+            seed_d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            seed_idx = __float_as_int(q.w);
+            seed_pos = sp;
+        }
+    }
+    const Best b = search_rows_group(g, px, py, pz, sub, max_rings, &cellstack[0][threadIdx.x], 256, seed_d2, seed_idx,
+                                     seed_pos).b;
     if (sub != 0) return;
     nn_pos[qi] = b.pos;
     if (queue_normals && b.pos >= 0 && nflag[b.pos] == 0) {
@@ -1981,20 +1998,27 @@ static GridView make_view(icp_ctx* ctx) {
     return g;
 }
 
-static void launch_search_rows(icp_ctx* ctx, int n, int mode, int transform) {
+static void launch_search_rows(icp_ctx* ctx, int n, int mode, int transform, int seeded) {
     hipLaunchKernelGGL(k_search_rows, dim3((unsigned)(((long long)n * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
                        make_view(ctx), ctx->tgt4.as<float4>(), n, mode, transform, reg_state(ctx), ctx->cfg.max_rings,
                        ctx->nn_pos.as<int>(), ctx->nflag.as<int>(), ctx->worklist.as<int>(),
-                       (ctx->normals_ready || ctx->cost == ICP_COST_POINT_TO_POINT) ? 0 : 1);  // p2p needs no normals
+                       (ctx->normals_ready || ctx->cost == ICP_COST_POINT_TO_POINT) ? 0 : 1,  // p2p needs no normals
+                       seeded);
 }
 
 int launch_search(icp_ctx* ctx) {
     const int n = (int)ctx->tgt_n;
     if (n <= 0) return ICP_OK;
     const int tok = prof_begin(ctx, 0);
-    launch_search_rows(ctx, n, ctx->tgt_mode, 1);
+    // from the second search of a registration on, nn_pos describes these targets against this grid: seeds
+    const int seeded = (ctx->use_nn_cache > 1 && ctx->searches_in_registration > 0 && ctx->nn_pos_n == n &&
+                        ctx->nn_pos_gen == ctx->grid_gen) ? 1 : 0;
+    launch_search_rows(ctx, n, ctx->tgt_mode, 1, seeded);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
+    ctx->searches_in_registration += 1;
+    ctx->nn_pos_n = n;
+    ctx->nn_pos_gen = ctx->grid_gen;
     return ICP_OK;
 }
 
@@ -2002,8 +2026,9 @@ int launch_search(icp_ctx* ctx) {
 int launch_search_raw(icp_ctx* ctx) {
     const int n = (int)ctx->tgt_n;
     if (n <= 0) return ICP_OK;
-    launch_search_rows(ctx, n, ICP_TARGETS_ALL, 0);
+    launch_search_rows(ctx, n, ICP_TARGETS_ALL, 0, 0);
     ICP_HIP(ctx, hipGetLastError());
+    ctx->nn_pos_n = -1;  // (other queries: no seeds for a registration)
     return ICP_OK;
 }
 
