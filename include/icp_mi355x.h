@@ -129,8 +129,9 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   the workgroups of that launch through a mailbox, instead of a launch of its own; same bits
  *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last
  *                                   registration ran, plus one; icp_register_end enqueues more while the loop is still running
- *   "flat_rows" 0 | 1 (1)           the 4-lane search lays the surviving neighbour cells of a query end to end and walks them
- *                                   with all four lanes (0: every lane walks its own cells, round 2's schedule)
+ *   "flat_rows" 0 | 1 | 2 (2)       how the 4-lane search reads the neighbour cells that survive the box test: 2 = cell by cell,
+ *                                   the four lanes striding each cell together; 1 = laid end to end and dealt out candidate by
+ *                                   candidate; 0 = every lane walks its own cells (round 2's schedule)
  *   "hoods" 0 | 1 (1)               neighbourhood lists: the points of every occupied cell's 27-neighbourhood copied into one
  *                                   contiguous run at each grid build (<= 27 x 16 B per map point, maps up to 2^22 points); the
  *                                   kNN normals stream ring 1 from it (0: they walk the 27 cells of the neighbour row)

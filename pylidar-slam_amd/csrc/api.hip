@@ -353,7 +353,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
-    else if (k == "flat_rows") ctx->flat_rows = value != 0.0 ? 1 : 0;
+    else if (k == "flat_rows") ctx->flat_rows = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
     else if (k == "xcd_sectors") ctx->xcd_sectors = value != 0.0 ? 1 : 0;
     else if (k == "lead_after_dense") ctx->lead_after_dense = value != 0.0 ? 1 : 0;
     else if (k == "refresh_margin") ctx->refresh_margin = value > 0.0 ? (float)value : 0.f;

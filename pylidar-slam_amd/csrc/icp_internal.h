@@ -42,7 +42,7 @@ struct GridView {
     const float4* cpts;
     const int* pos_of_orig;  // original map index -> position in the fine cell-sorted array
     const float4* hood;      // neighbourhood lists (hash_grid.hip::k_hood_build; header = row entry 27) or nullptr
-    int flat_rows;           // option "flat_rows": the 4-lane search scans its surviving neighbour cells laid end to end
+    int flat_rows;           // option "flat_rows": how the 4-lane search scans its surviving neighbour cells (0 / 1 / 2)
     float prune_guard;       // option "prune_guard" (m): neighbour cells closer than best + guard are scanned, not pruned
     int* dbg;                // dev-only path counters (option "search_stats" = 1), nullptr in production
     long long* stamps;       // dev-only phase timestamps (option "search_stats" = 1 | 2), nullptr in production
@@ -303,7 +303,7 @@ struct icp_ctx {
     icp::DeviceBuffer posebox;         // pose mailbox of the lead launches (BOX_BYTES)
     unsigned box_gen = 0;              // last pose generation published (or enqueued to be)
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
-    int flat_rows = 1;                 // "flat_rows" (GridView)
+    int flat_rows = 2;                 // "flat_rows" (GridView): 0 lane by lane, 1 flattened list, 2 cell by cell with four lanes
     float prune_guard = 2e-3f;         // "prune_guard" (GridView)
     float refresh_margin = 1e-4f;      // "refresh_margin" (m) / "refresh_at" (iteration): NN-cache entries with less slack than
     int refresh_at = 6;                // that are searched again in that one launch, which searches anyway (IterInputs)

@@ -209,7 +209,24 @@ __device__ inline Near3 search_rows_group(const GridView& g, float px, float py,
             stack[nl * stride] = make_int2(cell[k].x, cell[k].y | (c << 24));
             ++nl;
         }
-        if (g.flat_rows) {
+        if (g.flat_rows == 2) {
+            // every surviving cell of the group scanned by its four lanes together, 16 candidates per round and cell: a
+            // round more than the flattened list when several small cells survive, a third of its instructions
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int n_of[4] = {quad_bcast<0>(nl), quad_bcast<1>(nl), quad_bcast<2>(nl), quad_bcast<3>(nl)};
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                for (int k = 0; k < n_of[l]; ++k) {  // group-uniform
+                    const int2 e = stack[k * stride + (l - sub)];  // lane l's column sits next to this lane's
+                    scan_strided4(g, e.x, e.y & 0xffffff, sub, px, py, pz, b, skip);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            nl = 0;
+        } else if (g.flat_rows) {
             // The surviving neighbour cells of the GROUP laid end to end (round 3): every lane's cells are announced in a
             // list the four lanes share (their four LDS columns, 28 slots), with the running candidate count in front of
             // each; the four lanes then walk candidates 0 .. T-1 together, four loads in flight each, finding the cell of

@@ -350,6 +350,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "lanes2": {"knn_lanes": 2}, "scan_gives_up": {"scan_poll_limit": 0},
                 "no_lead_solve": {"lead_solve": 0},  # every solve in a launch of its own (round 2's schedule)
                 "no_flat_rows": {"flat_rows": 0},    # neighbour cells walked lane by lane (round 2's schedule)
+                "flat_list": {"flat_rows": 1},       # surviving neighbour cells laid end to end (the first half of round 3)
                 "no_xcd_sectors": {"xcd_sectors": 0},  # consecutive queries in consecutive workgroups (no XCD sectors)
                 "no_lead_after_dense": {"lead_after_dense": 0},  # the dense launches keep their own solving launch
                 "no_lead_never_narrow": {"lead_solve": 0, "narrow_from": -1},
