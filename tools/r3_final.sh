@@ -1,11 +1,14 @@
 #!/bin/bash
-# round 3, end-of-session measurements on HEAD: GPU tests, smoke, the driver-style bench line (20 steps) and the 60-step
-# one, the two-rank run on the one GPU (gloo rendezvous), C4, kernel trace, PMC counters -> gpurun_out/$1
+# round 3, end-of-session measurements on HEAD: GPU tests, smoke, PMC traffic, the driver-style bench line (20 steps) and
+# the 60-step one, the two-rank run on the one GPU (gloo rendezvous), C4, kernel trace, PMC counters -> gpurun_out/$1
 set -u
 TAG=${1:-r3final}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log; tail -3 $OUT/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+# the PMC traffic of this build first: the bench lines below read it from profiles/pmc_search_kernel.json
+bash tools/pmc.sh k_iterate_compact > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_k_iterate_compact.json $OUT/ 2>/dev/null; tail -c 300 $OUT/pmc.log; echo
+[ -s gpurun_out/pmc_k_iterate_compact.json ] && cp gpurun_out/pmc_k_iterate_compact.json profiles/pmc_search_kernel.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_line_20.json 2> $OUT/bench_line_20.err; echo "bench20 rc=$?"
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err; echo "bench60 rc=$?"
 for f in $OUT/bench_line_20.json $OUT/bench_line.json; do python - "$f" <<'PY'
@@ -28,6 +31,5 @@ except Exception as e: print("FAILED", e)
 PY
 timeout 600 python bench.py --workload c4 --steps 6 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 rc=$?"; tail -c 700 $OUT/bench_c4.json; echo
 bash tools/gpu_trace.sh $TAG/trace | tail -20
-bash tools/pmc.sh k_iterate_compact > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_k_iterate_compact.json $OUT/ 2>/dev/null; tail -c 400 $OUT/pmc.log; echo
 bash tools/pmc_kernel.sh k_iterate_compact > $OUT/pmc_sq_iterate.txt 2>&1; cat $OUT/pmc_sq_iterate.txt
 bash tools/pmc_by_iter.sh $TAG > /dev/null 2>&1; head -30 $OUT/pmc_by_iter.txt | cut -c1-240
