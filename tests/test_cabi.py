@@ -63,3 +63,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(d, f)).read()
                 assert "icp_oracle" not in src and "import oracle" not in src, os.path.join(d, f)
+
+
+def test_documented_options_are_the_accepted_options():
+    """`icp_set_option`: every option name the header documents is one the library accepts, and every name the library
+    accepts (the chain of `k == "name"` comparisons in api.hip) is documented in the header — dev-only switches excepted."""
+    header = open(os.path.join(ROOT, "include", "icp_mi355x.h")).read()
+    start = header.index("MI355X-side tuning options by name")
+    block = header[start:header.index("*/", start)]
+    documented = set(re.findall(r'"([a-z_0-9]+)"', block))
+    api = open(os.path.join(ROOT, "pylidar-slam_amd", "csrc", "api.hip")).read()
+    body = api[api.index("int icp_set_option("):]
+    body = body[:body.index("\nint icp_set_cost(")]
+    accepted = set(re.findall(r'k == "([a-z_0-9]+)"', body))
+    assert documented, "no option documented?"
+    missing_in_library = documented - accepted
+    assert not missing_in_library, f"documented but not accepted: {sorted(missing_in_library)}"
+    undocumented = accepted - documented
+    assert not undocumented, f"accepted but not documented in include/icp_mi355x.h: {sorted(undocumented)}"
