@@ -2,6 +2,7 @@
 """Benchmark of the MI355X ICP odometry hot path on BASELINE.json's metric configuration.
 
     python bench.py --gpus 1 --steps 60 --warmup 5
+    python bench.py --gpus N ...                 (no launcher: re-executes itself under torch.distributed.run, N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -80,7 +81,11 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_POINT_ITER = 36  # 12 target xyz + 12 matched map xyz + 12 matched normal
 MIN_STEPS_FOR_HEADLINE = 50  # >= 50 timed frames
-PROFILE_EVERY = 9  # frames between two whose iteration kernels are bracketed by HIP events (coprime with the 14-frame period)
+# Live roofline timing: in EVERY timed frame ONE of the 20 iteration launches is bracketed by a HIP-event pair — launch
+# (frame number mod 20) — so a 20-step run sees every iteration index once and a 60-step run three times (library option
+# "profile_rotate").  Round 3 bracketed all 20 launches of every 9th frame: 3 frames of a 20-step run, each ~0.15 ms slower
+# for it, and a mean that depended on which frames of the 14-frame trajectory they were.
+PROFILE_EVERY = 1
 LOOP_PERIOD = 96
 SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
 
@@ -700,6 +705,21 @@ def pmc_traffic():
         return None, None
 
 
+NULL_KERNEL_US = 1.0  # run time of an empty kernel when no rocprofv3 summary is at hand (profiles/rocprof_iterate_kernel.json)
+
+
+def rocprof_figure():
+    """Average launch duration of the dominant kernel by `rocprofv3 --kernel-trace` (tools/rocprof_iterate_summary.py
+    over the trace of `bench.py --steps 30`, committed with the commit it was measured at), or None."""
+    path = os.path.join(ROOT, "profiles", "rocprof_iterate_kernel.json")
+    try:
+        rec = json.load(open(path))
+        rec["file"] = "profiles/rocprof_iterate_kernel.json"
+        return rec
+    except Exception:
+        return None
+
+
 def timed_region(extra, main_tr, steps, dist, dev):
     if dist is not None:
         dist.barrier()
@@ -721,14 +741,39 @@ def timed_region(extra, main_tr, steps, dist, dev):
     return res, elapsed
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with N ranks on
+    this node (127.0.0.1 rendezvous, a free port), pass the ranks' output through and return their exit code.  The ranks
+    need N visible GPUs under the nccl (= RCCL) backend; BENCH_DIST_BACKEND=gloo lets them share the devices there are
+    (a dry run of the N-rank code path on a 1-GPU box)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and ndev < args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} needs {args.gpus} visible GPUs (found {ndev}); "
+                                   "BENCH_DIST_BACKEND=gloo runs the ranks on the devices there are",
+                          "n_gpus": args.gpus}))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the in-library exchange need it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the product path has no CPU fallback"
     ndev = torch.cuda.device_count()
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU for a dry run
@@ -789,10 +834,14 @@ def main():
         # ~0.15 ms slower than an un-instrumented one (measured: 0.653 ms per step with --no-profile, 0.684 with every
         # 5th frame bracketed).  9 is coprime with the 14-frame period of the trajectory: every phase of it gets sampled
         main_tr.ctx.set_option("profile_every", PROFILE_EVERY)
+        main_tr.ctx.set_option("profile_rotate", 1)
         main_tr.ctx.profile_enable(int(os.environ.get("BENCH_PROF_MASK", "1")))  # 1: iteration kernel; 4: + normals
     res, elapsed = timed_region(extra, main_tr, args.steps, dist, dev)
     prof = main_tr.ctx.profile_read() if not args.no_profile else None
+    prof_iter = main_tr.ctx.profile_read_iterations(args.iters) if not args.no_profile else None
     main_tr.ctx.profile_enable(0)
+    main_tr.ctx.set_option("profile_rotate", 0)
+    event_floor_us = main_tr.ctx.profile_event_floor(200) if not args.no_profile else None
 
     # fewer than 50 timed steps (the driver's line has 20 = 13 ms): the same loop once more over 60 steps, so that the
     # figure does not rest on a 13 ms window (all ranks take part; instrumentation off)
@@ -892,7 +941,19 @@ def main():
         if through is not None:
             out["throughput"] = through
         if prof and prof["search_launches"] > 0:
-            avg_s = prof["search_ms"] * 1e-3 / prof["search_launches"]
+            # launch-weighted mean = mean over the iteration indices of the per-index means (every index weighs one launch
+            # per frame whatever the number of samples it got)
+            ms_i, n_i = prof_iter
+            per_iter_us = [float(ms_i[i] / n_i[i] * 1e3) if n_i[i] > 0 else None for i in range(args.iters)]
+            seen = [v for v in per_iter_us if v is not None]
+            raw_us = sum(seen) / len(seen)
+            # what an event pair adds: the pair around an EMPTY kernel measures `event_floor_us`, of which the empty kernel
+            # itself runs NULL_KERNEL_US by rocprofv3 (profiles/rocprof_iterate_kernel.json); the rest is the dispatch
+            # latency behind the barrier packet of the first event, which rocprofv3's kernel durations do not contain
+            rp = rocprof_figure()
+            null_us = (rp or {}).get("null_kernel_us", NULL_KERNEL_US)
+            net_us = max(raw_us - max(0.0, event_floor_us - null_us), 0.25 * raw_us)
+            avg_s = net_us * 1e-6
             n_local = main_tr.n_local if sharded else main_tr.n_pts
             achieved = BYTES_PER_POINT_ITER * n_local / avg_s
             traffic, source = pmc_traffic()
@@ -901,11 +962,25 @@ def main():
                                          "voxel-hash grid + point-to-plane rows + per-block partial normal equations)",
                                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
-                               "avg_launch_us": avg_s * 1e6, "launches": prof["search_launches"],
-                               "timed_frames": f"every {PROFILE_EVERY}th of the timed region",
+                               "avg_launch_us": net_us, "avg_launch_us_raw_events": raw_us,
+                               "event_floor_us": event_floor_us, "null_kernel_us": null_us,
+                               "avg_launch_us_by_iteration_raw": per_iter_us,
+                               "launches": prof["search_launches"],
+                               "timed_frames": "one iteration launch of every timed frame (launch = frame number mod "
+                                               f"{args.iters}), HIP events on the library's stream; avg_launch_us = mean "
+                                               "over the iteration indices of the raw event time - (event_floor_us - "
+                                               "null_kernel_us)",
                                "algorithmic_bytes_per_launch": BYTES_PER_POINT_ITER * n_local}
+            if rp is not None:  # the same kernel by rocprofv3 --kernel-trace (committed summary, with its commit)
+                out["roofline"]["rocprof_avg_launch_us"] = rp.get("avg_launch_us")
+                out["roofline"]["rocprof_frac"] = (BYTES_PER_POINT_ITER * n_local / (rp["avg_launch_us"] * 1e-6) / HBM_PEAK
+                                                   if rp.get("avg_launch_us") else None)
+                out["roofline"]["rocprof_source"] = {k: rp.get(k) for k in ("file", "head", "command", "by_shape_us")}
         if prof and prof.get("normals_ms", 0.0) > 0.0:
             out["normals_ms_per_step"] = prof["normals_ms"] / max(1, -(-args.steps // PROFILE_EVERY))
+        if world > 1:
+            out["rccl_ranks"] = world if dist.get_backend() == "nccl" else 0
+            out["dist_backend"] = dist.get_backend()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(main_tr, args)
         print(json.dumps(out))

@@ -127,16 +127,26 @@ int icp_synchronize(icp_ctx* ctx);
  *   "lead_solve" 0 | 1 (1)          launched / unpolled registrations: the 6x6 solve of iteration k runs in an extra workgroup
  *                                   at the head of the (late, 512-queries-per-block) launch k + 1, which publishes the pose to
  *                                   the workgroups of that launch through a mailbox, instead of a launch of its own; same bits
+ *   "lead_timeout_ms" t (50)        wall-clock bound of that poll: a workgroup that does not see the pose in time gives up and
+ *                                   the registration ends with ICP_ERR_HIP instead of hanging the GPU (the hand-off assumes the
+ *                                   lead workgroup — blockIdx 0 — is dispatched before the pollers fill the machine; raise the
+ *                                   bound, or set "lead_solve" 0, where a context shares its GPU with heavy foreign work)
+ *   "ball_search" 0 | 1 (1)         NN-cache misses of the fused kernel are first searched by ONE lane each: own cell, then the
+ *                                   cells across its nearer faces that a ball of the best distance reaches (99 % of the queries
+ *                                   of an ordinary frame); whatever does not fit goes to the 4-lane / whole-wave searches; same
+ *                                   bits.  With it the 512-query shape may serve the first iteration as well ("narrow_from" 0)
  *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last
  *                                   registration ran, plus one; icp_register_end enqueues more while the loop is still running
  *   "flat_rows" 0 | 1 | 2 (2)       how the 4-lane search reads the neighbour cells that survive the box test: 2 = cell by cell,
  *                                   the four lanes striding each cell together; 1 = laid end to end and dealt out candidate by
  *                                   candidate; 0 = every lane walks its own cells (round 2's schedule)
  *   "hoods" 0 | 1 (1)               neighbourhood lists: the points of every occupied cell's 27-neighbourhood copied into one
- *                                   contiguous run at each grid build (<= 27 x 16 B per map point, maps up to 2^22 points); the
+ *                                   contiguous run at each grid build (<= 27 x 16 B per map point, maps up to 2^22 points whose
+ *                                   normals will be estimated all at once, point-to-plane cost, 5 or 10 neighbours); the
  *                                   kNN normals stream ring 1 from it (0: they walk the 27 cells of the neighbour row)
  *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
  *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
+ *   "profile_rotate" 0 | 1 (0)      icp_profile_enable brackets one iteration launch per registration (see icp_profile_read_iterations)
  *   "profile_every" n (1)           icp_profile_enable times the kernels of every n-th registration only (an event pair
  *                                   costs ~2 us of stream time: 40 pairs per frame are 10 % of a 0.8 ms registration)
  * The library reads no environment variables. */
@@ -214,6 +224,12 @@ int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem); /* current map [M,3]
  * lazily estimated normal of every hit.  Outputs [n,3], [n,3], [n] (any may be NULL). */
 int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* neighbor_points_out,
                                 float* neighbor_normals_out, int32_t* neighbor_index_out, int out_mem);
+/* Test support for the search schedule (no reference counterpart; the reference recomputes every neighbour in every
+ * iteration, slam/odometry/icp_odometry.py:274-297): the ORIGINAL map index of the point each target of the last
+ * registration was matched with in its LAST iteration (-1: masked row), read back from the exact nearest-neighbour cache
+ * the fused iteration kernel keeps, and rows 0-2 of the pose that iteration ran with (pose_out, host memory, may be
+ * NULL).  Valid right after icp_register / icp_register_end, before the map changes; ICP_ERR_INVALID_ARGUMENT otherwise. */
+int icp_last_neighbors(icp_ctx* ctx, int32_t* neighbor_index_out, float pose_out[12], int out_mem);
 
 /* ---- projective local map: ProjectiveLocalMap (slam/odometry/local_map.py:91-240), the reference's "GPU" variant -----
  * compute_normal_map (slam/common/geometry.py:240-295): vertex map [3,H,W] -> normal map [3,H,W] (box-filter plane fit,
@@ -283,7 +299,13 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
 /* begin + every iteration enqueued + the result copied to pinned host memory behind the last iteration, without waiting:
  * work enqueued afterwards on the same context (icp_map_update with rel_pose = NULL: the pose-only branch of
  * ICPFrameToModel.__update_map, icp_odometry.py:379) overlaps the host's wait in icp_register_end, which then blocks on
- * the registration only.  With threshold_delta_pose > 0 the launches behind an early stop are device-side no-ops. */
+ * the registration only.  With threshold_delta_pose > 0 only a first chunk of iterations is on the stream when this
+ * returns ("chunked_launch": as many as the last registration ran, plus one; launches behind an early stop are
+ * device-side no-ops); icp_register_end enqueues more while the loop is still running.  Every entry point that changes
+ * what those held-back iterations would see — any icp_map_update / icp_map_set / icp_map_init / icp_map_update_vertex_map,
+ * icp_set_option / icp_set_cost / icp_set_alignment / icp_set_stream, icp_map_normals_owned / _install, icp_pmap_register,
+ * the next icp_register_launch — first enqueues ALL of them, so the stream order is the call order, as if every iteration
+ * had been enqueued here. */
 int icp_register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode, const float init_pose[16]);
 /* the same with the initial guess = the pose of the previous registration on this context, READ ON THE DEVICE: the
  * constant-velocity initialisation (`ConstantVelocityInitialization`, slam/initialization.py:103-119 — the last relative
@@ -337,6 +359,15 @@ int icp_map_normals_install(icp_ctx* ctx, const float* normals_by_index);
 int icp_profile_enable(icp_ctx* ctx, int enable);
 int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
                      double* normals_ms_out);
+/* the search kernel's time by ICP iteration index: ms_out / launches_out [cap] (index cap - 1 and beyond: not reported
+ * separately beyond 64).  With the option "profile_rotate" 1 only ONE iteration launch per registration is bracketed —
+ * iteration (number of the registration) mod max_num_alignments — so that every frame of a run can be sampled at the cost
+ * of two event records, and every iteration index is seen equally often. */
+int icp_profile_read_iterations(icp_ctx* ctx, double* ms_out, int64_t* launches_out, int32_t cap);
+/* what an event pair measures around an EMPTY kernel on the context's stream (median of `samples`, microseconds): the
+ * dispatch latency behind a barrier packet that every event-timed launch contains — bench.py reports it next to the
+ * raw event timing and subtracts it (plus the empty kernel's own run time) to compare with rocprofv3's durations. */
+int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out);
 
 #ifdef __cplusplus
 }

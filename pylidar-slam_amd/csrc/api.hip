@@ -39,9 +39,10 @@ void DeviceBuffer::release() {
     bytes = 0;
 }
 
-int prof_begin(icp_ctx* ctx, int kind) {
+int prof_begin(icp_ctx* ctx, int kind, int iter) {
     Profile& p = ctx->prof;
     if (!p.enabled || !p.sample_now || !((p.mask >> kind) & 1)) return -1;
+    if (kind == 0 && p.rotate && iter >= 0 && iter != p.rotate_index) return -1;
     const int ev = (int)p.pending.size();
     if (ev >= (int)p.pool.size()) {
         hipEvent_t a, b;
@@ -49,7 +50,7 @@ int prof_begin(icp_ctx* ctx, int kind) {
         p.pool.push_back({a, b});
     }
     (void)hipEventRecord(p.pool[ev].first, ctx->stream);
-    p.pending.push_back({kind, ev});
+    p.pending.push_back({kind, ev, iter});
     return ev;
 }
 
@@ -65,6 +66,11 @@ static void prof_collect(icp_ctx* ctx) {
         if (hipEventElapsedTime(&ms, p.pool[r.ev].first, p.pool[r.ev].second) == hipSuccess) {
             p.ms[r.kind] += ms;
             p.launches[r.kind] += 1;
+            if (r.kind == 0 && r.iter >= 0) {
+                const int slot = r.iter < Profile::ITER_SLOTS ? r.iter : Profile::ITER_SLOTS - 1;
+                p.ms_iter[slot] += ms;
+                p.launches_iter[slot] += 1;
+            }
         }
     }
     p.pending.clear();
@@ -79,6 +85,9 @@ __global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned 
     if (hist)
         for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // pose history, entry 0
 }
+
+// what an event pair costs: icp_profile_event_floor times this one bracketed like a real launch
+__global__ void k_event_floor() {}
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,10 +240,7 @@ static int continue_launch(icp_ctx* ctx, int count);
 // twice the scan, and for any scan while the map stays below ~10^6 points (a 6 000-point grid sample against 180 000
 // map points: 0.19 ms eager vs 0.45 ms for four lazy iterations; 200 000 points against 10^6: 2.8 vs 4.7 ms per frame of
 // twenty iterations).
-static bool wants_eager_normals(const icp_ctx* ctx, int64_t n) {
-    if (ctx->cost != ICP_COST_POINT_TO_PLANE) return false;
-    return ctx->map_m <= 2 * n || ctx->map_m <= (int64_t)ctx->eager_normals_limit;
-}
+// (wants_eager_normals: icp_internal.h — the grid build asks the same question before it builds the neighbourhood lists)
 static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first = 0, int count = -1);
 
 // ---- lifecycle ------------------------------------------------------------------------------------------------------
@@ -322,6 +328,10 @@ const char* icp_last_error(const icp_ctx* ctx) { return ctx ? ctx->error.c_str()
 int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     hipStream_t next = (hipStream_t)hip_stream;
     if (next != ctx->stream) {
         // work already enqueued on the previous stream (map builds, a registration in flight) must precede what follows
@@ -336,6 +346,10 @@ int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
 int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !name) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     const std::string k(name);
     const int iv = (int)value;
@@ -344,6 +358,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
     else if (k == "narrow_from") ctx->narrow_from = (int)iv;
     else if (k == "profile_every") ctx->prof.every = iv < 1 ? 1 : (int)iv;
+    else if (k == "profile_rotate") ctx->prof.rotate = iv != 0;
     else if (k == "wave_misses") ctx->wave_misses = iv < 0 ? 0 : (int)iv;
     else if (k == "wave_misses_dense") ctx->wave_misses_dense = iv < 0 ? 0 : (int)iv;
     else if (k == "frame_seed") { ctx->frame_seed = iv != 0; ctx->seed_n = 0; }
@@ -352,6 +367,8 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
+    else if (k == "ball_search") ctx->ball_search = value != 0.0 ? 1 : 0;
+    else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 0.01 ? value : 0.01;
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
     else if (k == "flat_rows") ctx->flat_rows = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
     else if (k == "xcd_sectors") ctx->xcd_sectors = value != 0.0 ? 1 : 0;
@@ -377,6 +394,10 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
 int icp_set_cost(icp_ctx* ctx, int32_t cost) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (cost != ICP_COST_POINT_TO_PLANE && cost != ICP_COST_POINT_TO_POINT)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "unknown alignment mode");
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
@@ -395,6 +416,10 @@ int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num
                       float threshold_delta_pose) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (scheme < 0 || scheme > ICP_SCHEME_CAUCHY || max_num_alignments < 1)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "bad alignment parameters");
     ctx->cfg.scheme = scheme;
@@ -588,6 +613,10 @@ int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_
 int icp_map_init(icp_ctx* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     ctx->map_m = 0;
     ctx->cloud_sizes.clear();
     ctx->grid_valid = false;
@@ -598,6 +627,10 @@ int icp_map_init(icp_ctx* ctx) {
 int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
     DeviceGuard device_guard(ctx);
     if (!ctx || m < 0 || (m > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     icp_map_init(ctx);  // set_map_pointcloud() calls init(): `_local_map_num_elements` stays empty (local_map.py:294)
     DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
     ICP_HIP(ctx, dst.reserve((size_t)(m > 0 ? m : 1) * 12));
@@ -695,7 +728,8 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
     if (!rel_pose && has_cloud && ctx->result_pending())
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL with a new cloud: collect the pending registration "
                                                    "(icp_register_end) first");
-    if (!rel_pose) {  // the pose it reads is the END of that registration: iterations a chunked launch holds back go first
+    {   // iterations a chunked launch holds back go first: the pose-only update reads the END of that registration, and
+        // ANY update rebuilds the grid the held-back iterations search (their NN cache and pose history belong to it)
         const int rc0 = continue_launch(ctx, -1);
         if (rc0) return rc0;
     }
@@ -729,6 +763,10 @@ int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const floa
                               int64_t* inserted_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !rel_pose || !vmap) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     const int npix = ctx->cfg.height * ctx->cfg.width;
     const void* in;
     int rc = import_buffer(ctx, vmap, (size_t)npix * 12, mem, ctx->stage_in, &in);
@@ -782,6 +820,31 @@ int icp_nearest_neighbor_search(icp_ctx* ctx, const float* xyz, int64_t n, int m
     if ((rc = export_finish(ctx, neighbor_points_out, pdev, (size_t)n * 12, out_mem))) return rc;
     if ((rc = export_finish(ctx, neighbor_normals_out, ndev, (size_t)n * 12, out_mem))) return rc;
     if ((rc = export_finish(ctx, neighbor_index_out, idev, (size_t)n * 4, out_mem))) return rc;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+int icp_last_neighbors(icp_ctx* ctx, int32_t* neighbor_index_out, float pose_out[12], int out_mem) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !neighbor_index_out) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration || ctx->result_pending())
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    // the cache must describe the targets of the last registration against the grid that is still current
+    if (ctx->cache_n <= 0 || ctx->cache_n != ctx->tgt_n || ctx->cache_gen != ctx->grid_gen || !ctx->grid_valid ||
+        ctx->iter_in_registration <= 0 || ctx->last_iterations <= 0 || !ctx->pose_hist)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "no fused registration against the current map to read neighbours from");
+    // the last iteration that ran: RegState.iter - 1 (a loop stopped early by its threshold enqueues no further search)
+    const int it = (ctx->last_iterations < ctx->iter_in_registration ? ctx->last_iterations : ctx->iter_in_registration) - 1;
+    if (it >= ctx->hist_cap) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "pose history too short");
+    const int64_t n = ctx->tgt_n;
+    void* idev;
+    int rc;
+    if ((rc = export_target(ctx, neighbor_index_out, (size_t)n * 4, out_mem, ctx->flags, &idev))) return rc;
+    if ((rc = launch_last_neighbors(ctx, it, (int*)idev))) return rc;
+    if ((rc = export_finish(ctx, neighbor_index_out, idev, (size_t)n * 4, out_mem))) return rc;
+    if (pose_out)
+        ICP_HIP(ctx, hipMemcpyAsync(pose_out, ctx->pose_hist + (size_t)it * 12, 12 * sizeof(float), hipMemcpyDeviceToHost,
+                                    ctx->stream));
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICP_OK;
 }
@@ -944,6 +1007,10 @@ int icp_pmap_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int ta
                       icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !result || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (ctx->pm_slots.empty()) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -1156,12 +1223,16 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     if ((rc = prepare_targets_and_state(ctx, n, init_pose, from_last))) return rc;
     ctx->have_device_pose = true;
     // event pairs around the kernels of every `every`-th registration only: a pair costs ~2 us of stream time
-    ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations++ % ctx->prof.every) == 0;
+    ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations % ctx->prof.every) == 0;
+    ctx->prof.rotate_index = (int)((ctx->prof.registrations / (ctx->prof.every > 1 ? ctx->prof.every : 1)) %
+                                   (ctx->cfg.max_num_alignments > 0 ? ctx->cfg.max_num_alignments : 1));
+    ctx->prof.registrations += 1;
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
     if (!ctx->normals_ready && wants_eager_normals(ctx, n) && (rc = launch_normals_all(ctx))) return rc;
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
+    ctx->cache_fresh = false;
     ctx->searches_in_registration = 0;
     return ICP_OK;
 }
@@ -1188,6 +1259,7 @@ int icp_iteration_accumulate(icp_ctx* ctx) {
         return launch_sum_partials(ctx, rows, quad);
     }
     if ((rc = launch_search(ctx))) return rc;
+    ctx->iter_in_registration += 1;  // (the fused launch counts itself)
     if (ctx->cost == ICP_COST_POINT_TO_POINT) return launch_reduce_p2p(ctx, false);
     if ((rc = launch_normals(ctx))) return rc;
     return launch_reduce(ctx);
@@ -1458,8 +1530,10 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
             if (!rc) rc = launch_sum_solve(ctx, rows, quad);
         } else if (ctx->cost == ICP_COST_POINT_TO_POINT) {
             (rc = launch_search(ctx)) || (rc = launch_reduce_p2p(ctx, true));
+            ctx->iter_in_registration += 1;  // (the fused launch counts itself)
         } else {
             (rc = launch_search(ctx)) || (rc = launch_normals(ctx)) || (rc = launch_reduce_solve(ctx));
+            ctx->iter_in_registration += 1;
         }
         if (rc) {
             ctx->in_registration = false;
@@ -1606,6 +1680,10 @@ int icp_exchange_destroy(icp_ctx* ctx) {
 int icp_map_normals_owned(icp_ctx* ctx, int32_t rank, int32_t world, float* normals_by_index) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !normals_by_index || world < 1 || rank < 0 || rank >= world) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     return launch_normals_owned(ctx, rank, world, normals_by_index);
@@ -1614,6 +1692,10 @@ int icp_map_normals_owned(icp_ctx* ctx, int32_t rank, int32_t world, float* norm
 int icp_map_normals_install(icp_ctx* ctx, const float* normals_by_index) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !normals_by_index) return ICP_ERR_INVALID_ARGUMENT;
+    {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     return launch_normals_install(ctx, normals_by_index);
@@ -1630,6 +1712,49 @@ int icp_profile_enable(icp_ctx* ctx, int enable) {
         ctx->prof.ms[k] = 0;
         ctx->prof.launches[k] = 0;
     }
+    for (int k = 0; k < Profile::ITER_SLOTS; ++k) {
+        ctx->prof.ms_iter[k] = 0;
+        ctx->prof.launches_iter[k] = 0;
+    }
+    ctx->prof.registrations = 0;
+    return ICP_OK;
+}
+
+int icp_profile_read_iterations(icp_ctx* ctx, double* ms_out, int64_t* launches_out, int32_t cap) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !ms_out || !launches_out || cap < 1) return ICP_ERR_INVALID_ARGUMENT;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int k = 0; k < cap; ++k) {
+        ms_out[k] = k < Profile::ITER_SLOTS ? ctx->prof.ms_iter[k] : 0.0;
+        launches_out[k] = k < Profile::ITER_SLOTS ? ctx->prof.launches_iter[k] : 0;
+    }
+    return ICP_OK;
+}
+
+int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !median_us_out || samples < 1 || samples > 4096) return ICP_ERR_INVALID_ARGUMENT;
+    hipEvent_t a, b;
+    ICP_HIP(ctx, hipEventCreate(&a));
+    ICP_HIP(ctx, hipEventCreate(&b));
+    std::vector<float> us;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < samples + 8; ++k) {
+        // a predecessor on the stream, as the bracketed launches of a registration have one
+        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream);
+        (void)hipEventRecord(a, ctx->stream);
+        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream);
+        (void)hipEventRecord(b, ctx->stream);
+        ICP_HIP(ctx, hipEventSynchronize(b));
+        float ms = 0.f;
+        if (k >= 8 && hipEventElapsedTime(&ms, a, b) == hipSuccess) us.push_back(ms * 1000.f);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (us.empty()) return fail(ctx, ICP_ERR_HIP, "event timing failed");
+    std::sort(us.begin(), us.end());
+    *median_us_out = us[us.size() / 2];
     return ICP_OK;
 }
 

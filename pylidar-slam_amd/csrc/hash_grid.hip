@@ -478,6 +478,9 @@ __device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, i
                                 float4* __restrict__ csorted, float4* __restrict__ normals, int* __restrict__ nflag,
                                 int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig) {
     if (i >= m) return;
+    // four +inf pads behind the last point: search_ball_lane reads cells in whole groups of four
+    if (i == 0)
+        for (int k = 0; k < SORTED_PAD; ++k) sorted[m + k] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
     const int slot = slot_of[i];
     const int pos = table[slot].start + rank_of[i];
     const int cpos = table[cslot_of[i]].start + crank_of[i];
@@ -598,7 +601,7 @@ int build_grid(icp_ctx* ctx) {
     }
     // the pending NN-cache -> seed conversion reads the OLD cell-sorted points: a launch of its own if they are about to be
     // reallocated, otherwise part of the clearing launch below
-    if (ctx->seed_job_n > 0 && ctx->sorted_pts.bytes < (size_t)m * sizeof(float4)) {
+    if (ctx->seed_job_n > 0 && ctx->sorted_pts.bytes < (size_t)(m + SORTED_PAD) * sizeof(float4)) {
         const int rc = run_seed_job(ctx);
         if (rc) return rc;
     }
@@ -607,7 +610,7 @@ int build_grid(icp_ctx* ctx) {
     ICP_HIP(ctx, ctx->csorted.reserve((size_t)m * sizeof(float4)));
     ICP_HIP(ctx, ctx->cslot_of.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->crank_of.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->sorted_pts.reserve((size_t)m * sizeof(float4)));
+    ICP_HIP(ctx, ctx->sorted_pts.reserve((size_t)(m + SORTED_PAD) * sizeof(float4)));
     ICP_HIP(ctx, ctx->normals.reserve((size_t)m * sizeof(float4)));
     ICP_HIP(ctx, ctx->nflag.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->slot_of.reserve((size_t)m * sizeof(int)));
@@ -656,7 +659,16 @@ int build_grid(icp_ctx* ctx) {
         }
     }
     // (the neighbourhood lists are allocated before the first launch of the build: their space counter is zeroed by it)
-    const bool with_hoods = ctx->hoods && m <= (1ll << 22);
+    // ... and only where something will read them: the eager estimation of point-to-plane normals with k = 5 or 10
+    // neighbours (k_normals_hood) — a point-to-point loop, a lazily estimated map or another k never does (432 B per map
+    // point and a launch per build otherwise); the list space of a map that stops needing it is given back
+    const int kn_hood = ctx->cfg.num_neighbors_normals + 1;
+    const bool with_hoods = ctx->hoods && m <= (1ll << 22) && (kn_hood == 11 || kn_hood == 6) &&
+                            wants_eager_normals(ctx, ctx->tgt_n > 0 ? ctx->tgt_n : m);
+    if (!with_hoods && ctx->hood.ptr) {
+        ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a launch of the previous build may still read them)
+        ctx->hood.release();
+    }
     const size_t hood_cap = (size_t)27 * (size_t)m;
     unsigned long long* hood_used = nullptr;
     if (with_hoods) {

@@ -49,6 +49,7 @@ struct GridView {
 };
 static constexpr float COARSE_FACTOR = 4.0f;
 static constexpr int COARSE_RINGS = 6;
+static constexpr int SORTED_PAD = 4;   // +inf entries behind the last cell-sorted point (search.hip::search_ball_lane reads groups of four)
 static constexpr int ROW_STRIDE = 28;  // 27 cells + 1 pad: rows are 224 B, 16-byte aligned
 
 __host__ __device__ inline unsigned long long pack_cell(int cx, int cy, int cz) {
@@ -223,10 +224,18 @@ struct Profile {
     long long registrations = 0;
     bool sample_now = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    struct Rec { int kind; int ev; };
+    struct Rec { int kind; int ev; int iter; };
     std::vector<Rec> pending;
     double ms[3] = {0, 0, 0};
     long long launches[3] = {0, 0, 0};
+    // "profile_rotate": of the fused iteration launches of a sampled registration only ONE is bracketed — iteration
+    // (number of the registration) mod max_num_alignments — so every frame can be sampled (two event records instead of
+    // forty: an event pair breaks the back-to-back dispatch around it) and every iteration index is seen equally often
+    int rotate = 0;
+    int rotate_index = 0;
+    static constexpr int ITER_SLOTS = 64;      // search-kernel time by iteration index (the last slot takes the rest)
+    double ms_iter[ITER_SLOTS] = {};
+    long long launches_iter[ITER_SLOTS] = {};
 };
 
 }  // namespace icp
@@ -275,7 +284,8 @@ struct icp_ctx {
     int tgt_mode = 0;
     icp::DeviceBuffer nn_pos;          // int[N]
     icp::DeviceBuffer nn_cache;        // int4[N]: (NN position | iteration << 24, bits(L), two more candidate positions or -1) — L = lower bound on the distance to every map point outside that set
-    int iter_in_registration = 0;
+    int iter_in_registration = 0;      // iterations of the registration in progress enqueued so far (= the device's RegState.iter while it runs)
+    bool cache_fresh = false;          // a fused launch of THIS registration has (re)written every NN-cache entry
     int cost = 0;                      // icp_cost of the registration loop (icp_set_cost)
     // tuning options (icp_set_option; none of them changes a result)
     int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
@@ -316,6 +326,8 @@ struct icp_ctx {
     bool hoods_valid = false;          // ... built for the current grid
     icp::DeviceBuffer hood;            // float4[<= 27 M] + the fill counter behind it
     int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks
+    int ball_search = 1;               // "ball_search": NN-cache misses of the fused kernel searched by one lane each first (search_ball_lane)
+    double lead_timeout_ms = 50.0;     // "lead_timeout_ms": how long a workgroup of a lead launch polls the pose mailbox before it gives up (-> ICP_ERR_HIP)
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
@@ -400,6 +412,7 @@ int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, qu
 int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
 int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager mode)
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
+int launch_last_neighbors(icp_ctx* ctx, int iteration, int* out_dev);  // NN cache -> matched map point per target (tests)
 // map-sharded normals: the owned share by original index (zeros elsewhere) / install the all-reduced array
 int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev);
 int launch_normals_install(icp_ctx* ctx, const float* by_index_dev);
@@ -463,9 +476,20 @@ int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double vox
                        float* points_dev, int* count_dev, int* count_host);
 
 // ---- profiling helpers (api.hip)
-int prof_begin(icp_ctx* ctx, int kind);
+int prof_begin(icp_ctx* ctx, int kind, int iter = -1);  // iter: index of the ICP iteration (search kernel)
 void prof_end(icp_ctx* ctx, int token);
 
 inline RegState* reg_state(icp_ctx* ctx) { return ctx->state.as<RegState>(); }
+
+// Normals of the whole map at once (one dense launch, then the fused iteration kernel) or lazily for the map points the
+// scan touches (local_map.py:397-422; three more launches per iteration, each a latency-bound chain when the scan is
+// small)?  Same values either way.  Eager costs ~1 us per 1000 map points; measured, it wins whenever the map is at most
+// twice the scan, and for any scan while the map stays below ~10^6 points (a 6 000-point grid sample against 180 000
+// map points: 0.19 ms eager vs 0.45 ms for four lazy iterations; 200 000 points against 10^6: 2.8 vs 4.7 ms per frame of
+// twenty iterations).  n = the number of targets (of the registration at hand, or of the last one as a stand-in).
+inline bool wants_eager_normals(const icp_ctx* ctx, int64_t n) {
+    if (ctx->cost != ICP_COST_POINT_TO_PLANE) return false;
+    return ctx->map_m <= 2 * n || ctx->map_m <= (int64_t)ctx->eager_normals_limit;
+}
 
 }  // namespace icp

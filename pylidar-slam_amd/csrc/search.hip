@@ -630,6 +630,188 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Ball search (round 4): ONE lane per query, no cooperation, no per-cell bookkeeping.
+//
+// Round 3's counters put the early iteration launches at 16.6 M VALU + 7.5 M SALU wave-instructions — 8 100 lane-
+// instructions per query for a 1-NN over ~50 candidates: box tests of 26 neighbours, LDS lists, group reductions, done by
+// four lanes each.  What a query actually needs, measured offline on the bench's frames (tools/ball_stats.py): its own
+// cell holds a point within 0.15 h of it (median; h = the cell edge), and a ball of that radius reaches 1 (50 %), 2 (33 %),
+// 4 (13 %) or 8 (4 %) cells — the own cell and the ones across its NEARER faces — with ~40 candidates in all; 99.4-99.9 %
+// of the queries of an ordinary frame fit that pattern.  So:
+//   1. own cell (one hashed probe; the 7 row entries of the cells across the nearer faces are requested with it);
+//   2. r = the best distance so far (own cell, seed); cells whose box is farther than r + prune_guard are pruned, their
+//      box distance bounds L; r + guard must stay inside the 2x2x2 block (else: the generic paths);
+//   3. the surviving cells, candidates four at a time.
+// Per candidate: the squared distance (6 instructions) and a sorted insertion into FOUR 32-bit keys by min / med3 (4):
+// key = distance bits with the low 8 bits replaced by the candidate's running number j (positive floats order like their
+// bits).  The keys name the candidate set the NN cache wants (three points + a bound on everybody else): everybody else
+// has a key >= K3, hence a distance >= K3 with its low bits cleared.  Exactness: the true nearest neighbour is one of
+// K0..K2 unless four candidates agree in the 15 leading mantissa bits (then: the generic paths); where K1 ties K0 in
+// those bits the tied points are compared exactly, (distance, original index) like everywhere else.
+// Cells are read in whole groups of four points — past the end of a cell into the next one of the array (real map points:
+// more candidates never hurt) or into the four +inf pads behind the last point — so no candidate is masked.
+// `stack` = this lane's column of an LDS array [7][stride] int2.  Returns false when the query does not fit the pattern.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr unsigned BALL_JMASK = 255u;
+static constexpr int BALL_MAX_CAND = 256;  // candidates (cells rounded up to groups of four) a key's j can number
+
+__device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {  // -> v_med3_u32
+    return max(min(a, b), min(max(a, b), c));
+}
+
+struct Top4 {
+    unsigned k0, k1, k2, k3;  // ascending
+    __device__ inline void insert(unsigned c) {
+        const unsigned n3 = umed3(k2, k3, c), n2 = umed3(k1, k2, c), n1 = umed3(k0, k1, c);
+        k0 = min(k0, c);
+        k1 = n1;
+        k2 = n2;
+        k3 = n3;
+    }
+};
+
+__device__ inline unsigned ball_key(const float4 q, float px, float py, float pz, int j) {
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    return (__float_as_uint(d2) & ~BALL_JMASK) | (unsigned)j;
+}
+
+__device__ inline bool search_ball_lane(const GridView& g, float px, float py, float pz, float seed_d2,
+                                        int2* __restrict__ stack, int stride, int& pos0, int& pos1, int& pos2,
+                                        float& L) {
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float h = g.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    // the nearer face of every axis: only a ball that reaches it leaves the cell on that side
+    const bool lx = fx < h - fx, ly = fy < h - fy, lz = fz < h - fz;
+    const float nx = lx ? fx : h - fx, ny = ly ? fy : h - fy, nz = lz ? fz : h - fz;
+    // every cell outside the 2x2x2 block on the nearer sides is at least that far
+    const float outer = h - fmaxf(nx, fmaxf(ny, nz));
+    const unsigned long long key = pack_cell(cx, cy, cz);
+    unsigned int slot = hash_cell(key) & g.mask;
+    const int o1 = lx ? -1 : 1, o2 = ly ? -3 : 3, o4 = lz ? -9 : 9;
+    GridEntry e = g.table[slot];
+    int2 rc[7];
+    {
+        const int2* __restrict__ r = g.rows + (size_t)slot * ROW_STRIDE + 13;
+#pragma unroll
+        for (int m = 1; m < 8; ++m) rc[m - 1] = r[((m & 1) ? o1 : 0) + ((m & 2) ? o2 : 0) + ((m & 4) ? o4 : 0)];
+    }
+    if (e.key != key && e.key != GRID_EMPTY) {
+        while (true) {
+            slot = (slot + 1) & g.mask;
+            e = g.table[slot];
+            if (e.key == key || e.key == GRID_EMPTY) break;
+        }
+        const int2* __restrict__ r = g.rows + (size_t)slot * ROW_STRIDE + 13;
+#pragma unroll
+        for (int m = 1; m < 8; ++m) rc[m - 1] = r[((m & 1) ? o1 : 0) + ((m & 2) ? o2 : 0) + ((m & 4) ? o4 : 0)];
+    }
+    if (e.key != key) return false;  // own cell empty
+    const int cum0 = (e.count + 3) & ~3;
+    if (cum0 > BALL_MAX_CAND) return false;
+    Top4 t;
+    t.k0 = t.k1 = t.k2 = t.k3 = ~0u;
+    {
+        const float4* __restrict__ q = g.pts + e.start;
+        for (int j = 0; j < cum0; j += 4) {
+            const float4 q0 = q[j], q1 = q[j + 1], q2 = q[j + 2], q3 = q[j + 3];
+            t.insert(ball_key(q0, px, py, pz, j));
+            t.insert(ball_key(q1, px, py, pz, j + 1));
+            t.insert(ball_key(q2, px, py, pz, j + 2));
+            t.insert(ball_key(q3, px, py, pz, j + 3));
+        }
+    }
+    // the pruning radius: the nearest so far is no farther than its key with the low bits set (a +inf / NaN key leaves
+    // the seed alone); the seed itself is a map point like any other and is met in its cell
+    const float r2 = fminf(seed_d2, __uint_as_float(t.k0 | BALL_JMASK));
+    const float R = sqrtf(r2) * 1.000001f + g.prune_guard;
+    if (!(R < outer)) return false;  // (also: nothing finite found)
+    const float R2 = R * R;
+    float Lb2 = outer * outer;
+    int ns = 0, total = cum0;
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+        const int2 c = rc[m - 1];
+        if (c.y > 0) {
+            const float gap2 = ((m & 1) ? nx * nx : 0.f) + ((m & 2) ? ny * ny : 0.f) + ((m & 4) ? nz * nz : 0.f);
+            if (gap2 > R2) {
+                Lb2 = fminf(Lb2, gap2);  // every point of a pruned cell is at least that far
+            } else {
+                stack[ns * stride] = make_int2(c.x - total, total);  // candidate j of this cell sits at position j + .x
+                total += (c.y + 3) & ~3;
+                ++ns;
+            }
+        }
+    }
+    if (total > BALL_MAX_CAND) return false;
+    {
+        int s = 0, off = 0, jnext = cum0;
+        for (int j = cum0; j < total; j += 4) {
+            if (j >= jnext) {  // (cells start at multiples of four: j meets every boundary)
+                off = stack[s * stride].x;
+                ++s;
+                jnext = s < ns ? stack[s * stride].y : total;
+            }
+            const float4* __restrict__ q = g.pts + (off + j);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            t.insert(ball_key(q0, px, py, pz, j));
+            t.insert(ball_key(q1, px, py, pz, j + 1));
+            t.insert(ball_key(q2, px, py, pz, j + 2));
+            t.insert(ball_key(q3, px, py, pz, j + 3));
+        }
+    }
+    // pads behind the last map point (+inf) and NaN distances are no candidates
+    if (t.k0 >= 0x7f800000u) return false;
+    if (t.k1 >= 0x7f800000u) t.k1 = ~0u;
+    if (t.k2 >= 0x7f800000u) t.k2 = ~0u;
+    if (t.k3 >= 0x7f800000u) t.k3 = ~0u;
+    if (t.k3 != ~0u && ((t.k3 ^ t.k0) & ~BALL_JMASK) == 0u) return false;  // four candidates within the key's resolution
+    const auto position = [&](unsigned k) -> int {
+        if (k == ~0u) return -1;
+        const int j = (int)(k & BALL_JMASK);
+        if (j < cum0) return e.start + j;
+        int s = 0;
+        if (ns > 4 && stack[4 * stride].y <= j) s = 4;
+        if (s + 2 < ns && stack[(s + 2) * stride].y <= j) s += 2;
+        if (s + 1 < ns && stack[(s + 1) * stride].y <= j) s += 1;
+        return stack[s * stride].x + j;
+    };
+    int p0 = position(t.k0), p1 = position(t.k1), p2 = position(t.k2);
+    if (t.k1 != ~0u && ((t.k1 ^ t.k0) & ~BALL_JMASK) == 0u) {
+        // K1 (and perhaps K2) ties K0 in the bits a key keeps: the exact (distance, original index) order decides
+        const float4 q0 = g.pts[p0], q1 = g.pts[p1];
+        Best b;
+        b.d2 = INFINITY;
+        b.idx = 0x7fffffff;
+        b.pos = -1;
+        b.second = INFINITY;
+        consider(q0, p0, px, py, pz, b);
+        consider(q1, p1, px, py, pz, b);
+        if (t.k2 != ~0u && ((t.k2 ^ t.k0) & ~BALL_JMASK) == 0u) consider(g.pts[p2], p2, px, py, pz, b);
+        if (b.pos == p1) {
+            p1 = p0;
+            p0 = b.pos;
+        } else if (b.pos == p2) {
+            p2 = p0;
+            p0 = b.pos;
+        }
+    }
+    // a point read twice (past the end of a cell into a cell that is scanned as well) names one candidate
+    if (p1 == p0) p1 = -1;
+    if (p2 == p0 || p2 == p1) p2 = -1;
+    float L2 = Lb2;
+    if (t.k3 != ~0u) L2 = fminf(L2, __uint_as_float(t.k3 & ~BALL_JMASK));
+    pos0 = p0;
+    pos1 = p1;
+    pos2 = p2;
+    L = sqrtf(L2);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Fused iteration kernel (every needed normal is ready): the search above + the point-to-plane row of each query +
 // the per-block partial normal equations, in one launch — no nn_pos round trip, no second pass over the targets.
 // (Measured and dropped in round 2: solving iteration k in the prologue of launch k + 1 — every workgroup redundantly,
@@ -717,6 +899,7 @@ struct IterInputs {
     int n, mode, max_rings, use_cache;
     int iter;                // index of this iteration within the registration (0, 1, ..)
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
+    int ball;                // option "ball_search": the misses go through search_ball_lane first (one lane each)
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
     // an L2 of its own — with consecutive queries in consecutive workgroups every L2 has to hold the rows and points of
     // the WHOLE map.  With swz_bpr_shift >= 0 the workgroups of one XCD take one azimuth sector (x elevation band) of the
@@ -1004,6 +1187,43 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             atomicAdd(&g.dbg[6], nmiss);
             atomicAdd(&g.dbg[8 + min(iter_now, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
         }
+    }
+    // ---- phase B0 (round 4): every miss by ONE lane (search_ball_lane); what does not fit its pattern (own cell empty, a
+    // ball that leaves the 2x2x2 block, more than 256 candidates, four candidates within a key's resolution) goes back on
+    // the list for the generic paths below
+    if (in.ball && nmiss > 0) {  // block-uniform
+        const int listed = nmiss;
+        const bool mine = (int)threadIdx.x < listed;
+        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 ms = make_int4(0, 0, 0, 0);
+        if (mine) {
+            mp = miss_p[threadIdx.x];
+            ms = miss_seed[threadIdx.x];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) nmiss = 0;
+        __syncthreads();
+        if (mine) {
+            int p0, p1, p2;
+            float L;
+            if (search_ball_lane(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), &cellstack[0][threadIdx.x], THREADS, p0, p1, p2,
+                                 L)) {
+                const int lq2 = __float_as_int(mp.w);
+                const float4 q = g.pts[p0];
+                const float4 nn = in.normals[p0];
+                in.nn_cache[q0 + lq2] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
+                float row[9];
+                point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) rowbuf[lq2][k] = row[k];
+                if (g.dbg) atomicAdd(&g.dbg[0], 1);
+            } else {
+                const int k = atomicAdd(&nmiss, 1);
+                miss_p[k] = mp;
+                miss_seed[k] = ms;
+            }
+        }
+        __syncthreads();
     }
     // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
     // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
@@ -2175,12 +2395,18 @@ unsigned next_box_generation(icp_ctx* ctx) {
 // time only
 static int fused_cache_mode(const icp_ctx* ctx) {
     // (positions share the cache word with the iteration tag: maps of 2^24 points and more search every iteration)
-    return (ctx->use_nn_cache && ctx->iter_in_registration > 0 && ctx->map_m < (1 << 24)) ? ctx->use_nn_cache : 0;
+    // entries carry the index of the iteration that searched them, and the pose history is kept by the same index — the
+    // count of ALL iterations of the registration, fused or not (the seam API may install normals mid-registration: the
+    // unfused iterations before that write no entries).  The cache is used once a fused launch of THIS registration has
+    // written every entry: the first one runs without it
+    return (ctx->use_nn_cache && ctx->cache_fresh && ctx->map_m < (1 << 24)) ? ctx->use_nn_cache : 0;
 }
 
 bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
+    // (without the NN cache — the first iteration of a registration — every query searches: one lane each with the ball
+    // search, which suits the 512-query shape; the 4-lane groups of the generic path want the 128-query shape)
     const int use_cache = fused_cache_mode(ctx);
-    return use_cache && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
+    return (use_cache || ctx->ball_search) && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
 }
 
 int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad) {
@@ -2197,14 +2423,14 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         }
     }
     ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int4)));
-    const int tok = prof_begin(ctx, 0);
+    const int tok = prof_begin(ctx, 0, ctx->iter_in_registration);
     IterInputs in;
     in.tgt = ctx->tgt4.as<float4>();
     in.normals = ctx->normals.as<float4>();
     in.nn_cache = ctx->nn_cache.as<int4>();
     in.pose_hist = ctx->pose_hist;
     // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
-    in.frame_seed = (ctx->iter_in_registration == 0 && ctx->frame_seed && ctx->seed_n == n && n > 0)
+    in.frame_seed = (!ctx->cache_fresh && ctx->frame_seed && ctx->seed_n == n && n > 0)
                         ? ctx->seed_orig.as<int>() : nullptr;
     // the classic launch writes parity 0 (what launch_sum_solve reads by default); lead launches alternate
     const int parity = lead_mode ? ctx->partials_parity : 0;
@@ -2221,7 +2447,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         lead.loss_hist = ctx->loss_hist;
         lead.dx_hist = ctx->dx_hist;
         lead.hist_cap = ctx->hist_cap;
-        lead.timeout_ticks = 5000000ll;  // 50 ms of the 100 MHz wall clock
+        lead.timeout_ticks = (long long)(ctx->lead_timeout_ms * 1.0e5);  // 100 MHz wall clock (option "lead_timeout_ms")
         ctx->partials_parity = parity ^ 1;
     }
     const int grid = blocks + (lead_mode ? lead.solve : 0);
@@ -2233,6 +2459,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // (the 128-query shape runs while most workgroups search: a wave per miss is a round of ~8 us under that load, the
     // 4-lane groups take up to 128 misses in 10-15 us — whole waves only for a handful)
     in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
+    in.ball = ctx->ball_search;
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;
     in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;
@@ -2268,6 +2495,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
     ctx->iter_in_registration += 1;
+    ctx->cache_fresh = true;
     ctx->cache_n = n;  // nn_cache now describes these targets against the current grid
     ctx->cache_m = ctx->map_m;
     ctx->cache_gen = ctx->grid_gen;
@@ -2324,6 +2552,45 @@ int launch_normals(icp_ctx* ctx) {
                            ctx->worklist.as<int>(), kn, ctx->normals.as<float4>(), ctx->nflag.as<int>());
     }
     prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// The map point (original index, -1: none) every target was matched with in fused iteration `iteration` of the last
+// registration, read back from the NN cache: the nearest member of the entry's candidate set under the pose that
+// iteration ran with (pose_hist) — what a cache hit of that launch used, and what its searches wrote.  Test support
+// (icp_last_neighbors): the benchmark-size parity test checks it against brute force.
+__global__ void k_last_neighbors(const float4* __restrict__ tgt, const int4* __restrict__ cache,
+                                 const float4* __restrict__ pts, const float* __restrict__ pose12, int n, int mode,
+                                 int m, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 t4 = tgt[i];
+    const int4 c = cache[i];
+    int best = -1;
+    if (target_valid(t4.x, t4.y, t4.z, mode) && c.x >= 0) {
+        float px, py, pz;
+        transform_point(pose12, t4.x, t4.y, t4.z, px, py, pz);
+        Best b;
+        b.d2 = INFINITY;
+        b.idx = 0x7fffffff;
+        b.pos = -1;
+        b.second = INFINITY;
+        const int p0 = c.x & CACHE_POS_MASK;
+        if (p0 < m) consider(pts[p0], p0, px, py, pz, b);
+        if (c.z >= 0 && c.z < m) consider(pts[c.z], c.z, px, py, pz, b);
+        if (c.w >= 0 && c.w < m) consider(pts[c.w], c.w, px, py, pz, b);
+        if (b.pos >= 0) best = b.idx;
+    }
+    out[i] = best;
+}
+
+int launch_last_neighbors(icp_ctx* ctx, int iteration, int* out_dev) {
+    const int n = (int)ctx->tgt_n;
+    if (n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_last_neighbors, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->tgt4.as<float4>(),
+                       ctx->nn_cache.as<int4>(), ctx->sorted_pts.as<float4>(), ctx->pose_hist + (size_t)iteration * 12, n,
+                       ctx->tgt_mode, (int)ctx->map_m, out_dev);
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }

@@ -92,6 +92,7 @@ EXPORTED_SYMBOLS = {
     "icp_map_num_clouds": (_INT, [_P]),
     "icp_map_get": (_INT, [_P, _P, _INT]),
     "icp_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, _P, _P, _INT]),
+    "icp_last_neighbors": (_INT, [_P, _P, _P, _INT]),
     "icp_compute_normal_map": (_INT, [_P, _P, _INT, _INT, _P, _INT]),
     "icp_compute_neighbors": (_INT, [_P, _P, _P, _P, _INT, _INT, _INT, _P, _P, _INT]),
     "icp_pmap_init": (_INT, [_P]),
@@ -115,6 +116,8 @@ EXPORTED_SYMBOLS = {
     "icp_normal_equations_ptr": (_P, [_P]),
     "icp_set_normal_equations_buffer": (_INT, [_P, _P]),
     "icp_profile_enable": (_INT, [_P, _INT]),
+    "icp_profile_read_iterations": (_INT, [_P, _P, _P, C.c_int32]),
+    "icp_profile_event_floor": (_INT, [_P, C.c_int32, C.POINTER(C.c_double)]),
     "icp_profile_read": (_INT, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
 }

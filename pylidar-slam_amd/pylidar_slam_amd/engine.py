@@ -340,6 +340,14 @@ class IcpContext:
                 ix.ctypes.data if ix is not None else None, MEM_HOST))
         return nb, nm, ix
 
+    def last_neighbors(self, n: int):
+        """(original map index per target, [3,4] pose) of the LAST iteration of the last registration, read back from the
+        library's exact nearest-neighbour cache (test support: `icp_last_neighbors`)."""
+        ix = np.empty(int(n), np.int32)  # n = the number of target rows of that registration
+        pose = np.empty(12, np.float32)
+        self._check(self._lib.icp_last_neighbors(self._h, ix.ctypes.data, pose.ctypes.data, MEM_HOST))
+        return ix, pose.reshape(3, 4)
+
     # ---- projective local map (SURVEY §8 row a19) --------------------------------------------------------------------
     def _planar(self, vmap: Array):
         """[3,H,W] float32 contiguous -> (pointer, mem, keep-alive)."""
@@ -649,3 +657,16 @@ class IcpContext:
         s, n, r, m = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
         self._check(self._lib.icp_profile_read(self._h, C.byref(s), C.byref(n), C.byref(r), C.byref(m)))
         return {"search_ms": s.value, "search_launches": int(n.value), "reduce_ms": r.value, "normals_ms": m.value}
+
+    def profile_read_iterations(self, cap: int = 64):
+        """(ms, launches) of the search kernel by ICP iteration index (`icp_profile_read_iterations`)."""
+        ms = np.zeros(cap, np.float64)
+        n = np.zeros(cap, np.int64)
+        self._check(self._lib.icp_profile_read_iterations(self._h, ms.ctypes.data, n.ctypes.data, int(cap)))
+        return ms, n
+
+    def profile_event_floor(self, samples: int = 200) -> float:
+        """Median time (us) an event pair measures around an empty kernel on this context's stream."""
+        v = C.c_double(0)
+        self._check(self._lib.icp_profile_event_floor(self._h, int(samples), C.byref(v)))
+        return float(v.value)

@@ -301,3 +301,29 @@ def test_in_library_exchange_world_size_2_on_one_gpu(torch_cuda, tmp_path):
     assert np.array_equal(r.pose, ref.pose) and np.array_equal(r.losses, ref.losses)
     solo.exchange_destroy()
     assert np.array_equal(solo.register(scan).pose, ref.pose)
+
+
+def test_bench_gpus_2_launches_its_own_ranks(torch_cuda):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start its ranks itself (it re-executes
+    under torch.distributed.run) and print ONE JSON line with n_gpus = 2 carrying the replicas headline and the
+    `sharded` / `c4` objects.  Here: two ranks on the one GPU over gloo (BENCH_DIST_BACKEND), the launcher path that the
+    driver's multi-GPU node takes with RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["max_pose_error_vs_ground_truth_m"] < 0.05
+    sh = d["sharded"]
+    for variant in ("library", "collective"):  # a failed exchange is REPORTED (and the collective still runs), never a hang
+        assert "value" in sh[variant] or "error" in sh[variant], sh
+    assert "value" in sh["collective"], sh
+    assert sh["collective"]["max_pose_error_vs_ground_truth_m"] < 0.05
+    assert "map_sharded_normals" in d["c4"], d["c4"]

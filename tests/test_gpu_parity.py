@@ -354,6 +354,11 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "no_xcd_sectors": {"xcd_sectors": 0},  # consecutive queries in consecutive workgroups (no XCD sectors)
                 "no_lead_after_dense": {"lead_after_dense": 0},  # the dense launches keep their own solving launch
                 "no_lead_never_narrow": {"lead_solve": 0, "narrow_from": -1},
+                "no_ball_search": {"ball_search": 0},  # every miss by the 4-lane / whole-wave searches (round 3's schedule)
+                "no_ball_never_narrow": {"ball_search": 0, "narrow_from": -1},
+                "narrow_always": {"narrow_from": 0},   # the 512-query shape from the first iteration on (ball search)
+                "narrow_always_nocache": {"narrow_from": 0, "nn_cache": 0},
+                "ball_no_guard": {"prune_guard": 0.0, "narrow_from": 0},
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -631,6 +636,95 @@ def test_c2_full_size_registration_vs_reference_and_oracle(torch_cuda, O):
         print(f"C2 {scheme} vs oracle: |dt| = {dt:.2e} m |dr| = {dr:.2e} rad, normals computed {res.normals_computed}")
         assert dt < 1e-4 and dr < 1e-4, (scheme, dt, dr)
         np.testing.assert_allclose(res.losses[-1], orc.traces[-1].loss[-1], rtol=1e-3)
+
+
+def _bench_workload():
+    """bench.py's headline workload (`make_workload(0, "pingpong")`): tracked scans the map has never seen, the map the
+    voxel-subsampled union of eight OTHER scans — restated here so that the test does not import the benchmark."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=64, width=2048, seed=1234, step=0.2, yaw_rate=0.005)
+    scans, poses = make_sequence(cfg, 16)
+    even = list(range(0, 16, 2))
+    model = make_fixed_map(cfg, [scans[f] for f in even], poses[even], ref_frame=0, num_points=100_000)
+    rel = np.linalg.inv(poses[1]) @ poses[0]
+    model = (model.astype(np.float64) @ rel[:3, :3].T + rel[:3, 3]).astype(np.float32)
+    return {f: scans[f] for f in (3, 5, 7)}, poses, model
+
+
+def test_schedule_options_at_benchmark_size(torch_cuda):
+    """the schedule options proven bit-identical AT THE BENCHMARK'S SIZE (131 072 x 100 000 x 20: 1024
+    workgroups in the 128-query shape — every slot of the chip — 257 in the lead launches, cells auto-tuned to 16 points,
+    the mailbox / pose history / look-back under real dispatch pressure), over three chained frames of the bench's own
+    workload (the second and third start from frame seeds and the constant-velocity guess); and the neighbour every
+    target had in the LAST iteration, read back through the NN cache (icp_last_neighbors), is the true nearest map point
+    (kd-tree on the host) for the whole scan — a cache that kept a second-nearest neighbour a few times per launch would
+    pass a 1e-4 pose test."""
+    from scipy.spatial import cKDTree
+    scans, poses, model = _bench_workload()
+    variants = {"default": {}, "nocache": {"nn_cache": 0}, "no_lead_solve": {"lead_solve": 0},
+                "never_narrow": {"narrow_from": -1}, "narrow_always": {"narrow_from": 0}, "no_hoods": {"hoods": 0},
+                "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
+                "round3": {"ball_search": 0, "narrow_from": 3}}
+    results = {}
+    for name, opts in variants.items():
+        ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0, scheme="geman_mcclure",
+                   sigma=0.3)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.map_set(model)
+        frames, init = [], None
+        for f in (3, 5):
+            ctx.register_launch(scans[f], init)
+            ctx.map_update(None, None)
+            r = ctx.register_end()
+            frames.append(r)
+            init = r.pose
+        r = ctx.register(scans[7], init)  # (no map update behind it: the cache still describes this registration)
+        frames.append(r)
+        ix, pose12 = ctx.last_neighbors(scans[7].shape[0])
+        _, nrm, _ = ctx.nearest_neighbor_search(scans[7][::13])
+        results[name] = (frames, ix, pose12, nrm, ctx.map_points())
+        ctx.close()
+    ref = results["default"]
+    problems = []
+    for name, (frames, ix, pose12, nrm, mp) in results.items():
+        for f, (r, rr) in enumerate(zip(frames, ref[0])):
+            assert r.iterations == 20
+            if not (np.array_equal(r.pose, rr.pose) and np.array_equal(r.losses, rr.losses) and np.array_equal(r.dx, rr.dx)):
+                first = int(np.argmax(r.losses != rr.losses)) if (r.losses != rr.losses).any() else -1
+                problems.append(f"{name}: frame {f} differs (first loss mismatch at iteration {first}, "
+                                f"max |dpose| {np.abs(r.pose - rr.pose).max():.1e})")
+        if not np.array_equal(pose12, ref[2]):
+            problems.append(f"{name}: pose of the last iteration differs")
+        if not np.array_equal(ix, ref[1]):  # (with the cache off every launch searches and writes its entries all the same)
+            problems.append(f"{name}: {int((ix != ref[1]).sum())} neighbours of the last iteration differ")
+        if not np.array_equal(nrm, ref[3]):
+            problems.append(f"{name}: normals differ")
+        if not np.array_equal(mp, ref[4]):
+            problems.append(f"{name}: map differs")
+    assert not problems, "\n".join(problems)
+    # ---- the neighbours of the last iteration against the kd-tree, every target.  The device transforms in float32:
+    # p = fma(z, T2, fma(y, T1, x * T0)) + T3 (search_device.h::transform_point), restated here (products of two floats
+    # are exact in float64)
+    frames, ix, pose12, _, mp = ref
+    t = pose12.astype(np.float32)
+    s7 = scans[7].astype(np.float32)
+    def row(k):
+        acc = (s7[:, 0] * t[k, 0]).astype(np.float32).astype(np.float64)
+        acc = (s7[:, 1].astype(np.float64) * np.float64(t[k, 1]) + acc).astype(np.float32).astype(np.float64)
+        acc = (s7[:, 2].astype(np.float64) * np.float64(t[k, 2]) + acc).astype(np.float32)
+        return (acc + t[k, 3]).astype(np.float32)
+    p = np.stack([row(0), row(1), row(2)], axis=1).astype(np.float64)
+    cur = mp.astype(np.float64)  # the map the last registration ran against (insertion order = original indices)
+    assert (ix >= 0).all() and ix.max() < cur.shape[0]
+    bd, bi = cKDTree(cur).query(p)
+    d_used = np.linalg.norm(p - cur[ix], axis=1)
+    same = (ix == bi).mean()
+    print(f"last-iteration neighbours: {same * 100:.4f} % equal to the kd-tree's, max excess distance "
+          f"{(d_used - bd).max():.2e} m")
+    assert same > 0.9995
+    # where the index differs the two candidates are equidistant to float32 resolution of the squared distance
+    np.testing.assert_allclose(d_used ** 2, bd ** 2, rtol=4e-6, atol=1e-12)
 
 
 def test_c2_full_size_properties(torch_cuda, O):

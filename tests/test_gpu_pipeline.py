@@ -387,3 +387,45 @@ def test_chunked_launch_equals_the_full_launch(torch_cuda, threshold):
         assert a.iterations == b.iterations and a.converged == b.converged
         assert np.array_equal(a.pose, b.pose) and np.array_equal(a.losses, b.losses) and np.array_equal(a.dx, b.dx)
     np.testing.assert_array_equal(runs[1][1], runs[0][1])
+
+
+def test_calls_between_a_chunked_launch_and_its_end_follow_the_whole_registration(torch_cuda):
+    """with a live stop threshold only the first chunk of iterations is on the stream when
+    `icp_register_launch` returns.  A map update with an EXPLICIT pose, an option change or a new alignment called before
+    `icp_register_end` must not reach the held-back iterations: the library enqueues them first, so the result equals the
+    un-chunked launch bit for bit (stream order = call order)."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 8)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    kw = dict(height=32, width=1024, max_num_alignments=20, threshold_delta_pose=1e-4, scheme="geman_mcclure", sigma=0.3)
+    dscans = [torch.from_numpy(s).cuda() for s in scans]
+    shift = np.eye(4, dtype=np.float32)
+    shift[:3, 3] = (0.3, -0.2, 0.05)
+    runs = {}
+    for chunked in (1, 0):
+        ctx = IcpContext(**kw)
+        ctx.set_option("chunked_launch", chunked)
+        ctx.map_set(model)
+        out = []
+        # frame 4 converges in a few iterations: the first chunk of frame 7's launch (a jump of three frames, identity
+        # guess) is far shorter than the iterations it needs
+        out.append(ctx.register(dscans[4]))
+        ctx.register_launch(dscans[7], None)
+        ctx.map_update(shift, None)            # explicit pose: rebuilds the grid the held-back iterations search
+        ctx.set_option("prune_guard", 0.004)   # an option of the search
+        out.append(ctx.register_end())
+        ctx.register_launch(dscans[5], None)
+        ctx.set_alignment("huber", 0.5, 20, 1e-4)  # must apply to the NEXT registration only
+        out.append(ctx.register_end())
+        out.append(ctx.register(dscans[6]))
+        runs[chunked] = (out, ctx.map_points())
+        ctx.close()
+    assert runs[1][0][1].iterations > runs[1][0][0].iterations + 1, [r.iterations for r in runs[1][0]]
+    for a, b in zip(runs[1][0], runs[0][0]):
+        assert a.iterations == b.iterations and a.converged == b.converged
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.losses, b.losses) and np.array_equal(a.dx, b.dx)
+    np.testing.assert_array_equal(runs[1][1], runs[0][1])
+

@@ -118,3 +118,23 @@ def test_distortion_filter_pass_through_rules():
     np.testing.assert_array_equal(d["sample_points"], out[d["sample_indices"]])
     with pytest.raises(AssertionError):
         g.filter({"input_data": np.zeros((5, 2), np.float32)})
+
+
+def test_bench_gpus_n_without_gpus_reports_instead_of_asking_for_a_launcher():
+    """`python bench.py --gpus N` starts its own ranks (self_launch); with fewer than N visible GPUs under the RCCL backend
+    it prints one JSON line that says so and exits 2 — it does not ask the caller for a launcher any more."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""  # no device on any box this test runs on
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and "needs 2 visible GPUs" in d["error"]
