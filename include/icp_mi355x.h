@@ -112,8 +112,9 @@ int icp_synchronize(icp_ctx* ctx);
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "wave_misses" n (24)            workgroups with up to n cache misses search each of them with a whole wave
  *   "wave_misses_dense" n (4)       the same threshold in the 128-queries-per-block launches of the early iterations
- *   "narrow_from" n (3; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each (few
- *                                   searches expected), instead of 128 with a 4-lane group each; same bits
+ *   "narrow_from" n (0; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each,
+ *                                   instead of 128 with a 4-lane group each; same bits (round 3: 3 — the one-lane ball
+ *                                   search of round 4 suits the 512-query shape from the first iteration on)
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (16), "search_stats" 0 | 1 | 2 (0)
@@ -121,7 +122,7 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
  *   "prune_guard" m (0.002)         searches scan neighbour cells whose box is within m metres of the best distance instead of
  *                                   pruning them (the gap of a pruned cell bounds the cache's L: a guard keeps L off the best)
- *   "refresh_at" n (6), "refresh_margin" m (1e-4)   in launch n, NN-cache entries with less slack than m are searched again
+ *   "refresh_at" n (2), "refresh_margin" m (2e-3)   in launch n, NN-cache entries with less slack than m are searched again
  *   "xcd_sectors" 0 | 1 (1)         the workgroups one XCD receives take one azimuth sector of the range image
  *   "lead_after_dense" 0 | 1 (1)    the first 512-query launch also solves the last 128-query one
  *   "lead_solve" 0 | 1 (1)          launched / unpolled registrations: the 6x6 solve of iteration k runs in an extra workgroup
@@ -135,15 +136,19 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   cells across its nearer faces that a ball of the best distance reaches (99 % of the queries
  *                                   of an ordinary frame); whatever does not fit goes to the 4-lane / whole-wave searches; same
  *                                   bits.  With it the 512-query shape may serve the first iteration as well ("narrow_from" 0)
+ *   "ball_max" n (256; <= 256)      ... if own cell + surviving cells hold at most n candidates: one lane walks them alone, and the
+ *                                   longest walk of a launch sets its duration (heavier queries: the cooperative searches)
  *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last
  *                                   registration ran, plus one; icp_register_end enqueues more while the loop is still running
  *   "flat_rows" 0 | 1 | 2 (2)       how the 4-lane search reads the neighbour cells that survive the box test: 2 = cell by cell,
  *                                   the four lanes striding each cell together; 1 = laid end to end and dealt out candidate by
  *                                   candidate; 0 = every lane walks its own cells (round 2's schedule)
- *   "hoods" 0 | 1 (1)               neighbourhood lists: the points of every occupied cell's 27-neighbourhood copied into one
+ *   "hoods" 0 | 1 | 2 (2)           neighbourhood lists: the points of every occupied cell's 27-neighbourhood copied into one
  *                                   contiguous run at each grid build (<= 27 x 16 B per map point, maps up to 2^22 points whose
  *                                   normals will be estimated all at once, point-to-plane cost, 5 or 10 neighbours); the
- *                                   kNN normals stream ring 1 from it (0: they walk the 27 cells of the neighbour row)
+ *                                   kNN normals stream ring 1 from it — 2: one lane per map point, sorted 32-bit keys, the
+ *                                   uncertified points finished by a launch of their own, one wave each; 1: four lanes per point
+ *                                   (round 3); 0: no lists, the 27 cells of the neighbour row are walked
  *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
  *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
  *   "profile_rotate" 0 | 1 (0)      icp_profile_enable brackets one iteration launch per registration (see icp_profile_read_iterations)

@@ -368,6 +368,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
     else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
     else if (k == "ball_search") ctx->ball_search = value != 0.0 ? 1 : 0;
+    else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);
     else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 0.01 ? value : 0.01;
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
     else if (k == "flat_rows") ctx->flat_rows = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
@@ -376,7 +377,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "refresh_margin") ctx->refresh_margin = value > 0.0 ? (float)value : 0.f;
     else if (k == "refresh_at") ctx->refresh_at = iv;
     else if (k == "prune_guard") ctx->prune_guard = value > 0.0 ? (float)value : 0.f;
-    else if (k == "hoods") ctx->hoods = value != 0.0 ? 1 : 0;
+    else if (k == "hoods") ctx->hoods = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 16.0;
     else if (k == "search_stats") {

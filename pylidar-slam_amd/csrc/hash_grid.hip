@@ -172,7 +172,10 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
     __shared__ float T[16];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
-        if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
+        if (hood_used) {
+            hood_used[0] = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
+            hood_used[2] = 0;  // the straggler queue of the one-lane kNN normals: length | exit ticket (search.hip)
+        }
     }
     const long long first = (long long)blockIdx.x * blockDim.x;
     const bool moves = first < move.m;  // block-uniform
@@ -548,7 +551,10 @@ __global__ __launch_bounds__(HOOD_THREADS) void k_hood_build(const int* __restri
         if (c >= o) incl += t;
     }
     const int tot = __shfl(incl, 31, 32);
-    if (c == 0) cell_tot[threadIdx.x >> 5] = tot;
+    // (a run occupies a whole number of groups of four entries, the tail filled with points at +inf: the one-lane kNN
+    // streams groups of four without masking a candidate)
+    const int tot4 = (tot + 3) & ~3;
+    if (c == 0) cell_tot[threadIdx.x >> 5] = tot4;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long sum = 0;
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(HOOD_THREADS) void k_hood_build(const int* __restri
     long long start = (long long)base_s;
     for (int k = 0; k < (int)(threadIdx.x >> 5); ++k) start += cell_tot[k];
     if (j >= ncells) return;
-    if (start + tot > capacity) {  // (cannot happen: the capacity is the 27 M bound)
+    if (start + tot4 > capacity) {  // (cannot happen: the capacity is the 27 M + 3 per cell bound)
         if (c == 0) rows[row + 27] = make_int2(0, 0);
         return;
     }
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(HOOD_THREADS) void k_hood_build(const int* __restri
         }
         const int seg_start = __shfl(e.x, seg & 31, 32), seg_excl = __shfl(excl, seg & 31, 32);
         if (i < tot) dst[i] = pts[seg_start + (i - seg_excl)];
+        else if (i < tot4) dst[i] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
     }
 }
 
@@ -669,11 +676,11 @@ int build_grid(icp_ctx* ctx) {
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a launch of the previous build may still read them)
         ctx->hood.release();
     }
-    const size_t hood_cap = (size_t)27 * (size_t)m;
+    const size_t hood_cap = (size_t)HOOD_PER_POINT * (size_t)m;  // 27 per point + the padding of every run to a multiple of four
     unsigned long long* hood_used = nullptr;
     if (with_hoods) {
         ICP_HIP(ctx, ctx->hood.reserve(hood_cap * sizeof(float4) + 64));
-        hood_used = (unsigned long long*)(ctx->hood.as<char>() + hood_cap * sizeof(float4));
+        hood_used = (unsigned long long*)(ctx->hood.as<char>() + hood_cap * sizeof(float4));  // 64 bytes of counters behind the lists
     }
     int* scan_ticket = ctx->scan_desc.as<int>();
     unsigned long long* desc = ctx->scan_desc.as<unsigned long long>() + 8;

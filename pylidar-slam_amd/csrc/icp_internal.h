@@ -49,6 +49,7 @@ struct GridView {
 };
 static constexpr float COARSE_FACTOR = 4.0f;
 static constexpr int COARSE_RINGS = 6;
+static constexpr int HOOD_PER_POINT = 30;  // neighbourhood-list entries reserved per map point (27 + padding of the runs); the counters follow
 static constexpr int SORTED_PAD = 4;   // +inf entries behind the last cell-sorted point (search.hip::search_ball_lane reads groups of four)
 static constexpr int ROW_STRIDE = 28;  // 27 cells + 1 pad: rows are 224 B, 16-byte aligned
 
@@ -292,7 +293,7 @@ struct icp_ctx {
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
-    int narrow_from = 3;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
+    int narrow_from = 0;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
     int wave_misses_dense = 4;         // "wave_misses_dense": the same threshold in the 128-query shape (early iterations)
     int wave_misses = 24;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
@@ -315,18 +316,19 @@ struct icp_ctx {
     long long eager_normals_limit = 1 << 20;  // "eager_normals_limit": maps up to that many points get all their normals at once whatever the scan size
     int flat_rows = 2;                 // "flat_rows" (GridView): 0 lane by lane, 1 flattened list, 2 cell by cell with four lanes
     float prune_guard = 2e-3f;         // "prune_guard" (GridView)
-    float refresh_margin = 1e-4f;      // "refresh_margin" (m) / "refresh_at" (iteration): NN-cache entries with less slack than
-    int refresh_at = 6;                // that are searched again in that one launch, which searches anyway (IterInputs)
+    float refresh_margin = 2e-3f;      // "refresh_margin" (m) / "refresh_at" (iteration): NN-cache entries with less slack than
+    int refresh_at = 2;                // that are searched again in that one launch, which searches anyway (IterInputs)
     int searches_in_registration = 0;  // k_search_rows launches of the registration in progress (unfused loops): from the
     long long nn_pos_n = -1;           // second on, nn_pos (of nn_pos_n targets against grid generation nn_pos_gen) seeds
     unsigned long long nn_pos_gen = 0; // the searches
     int lead_after_dense = 1;          // "lead_after_dense": the first narrow launch solves the last dense one (enqueue_iterations)
     int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
-    int hoods = 1;                     // "hoods": neighbourhood lists for the kNN normals
+    int hoods = 2;                     // "hoods": neighbourhood lists for the kNN normals (1: four lanes per point, 2: one lane per point + a straggler queue)
     bool hoods_valid = false;          // ... built for the current grid
     icp::DeviceBuffer hood;            // float4[<= 27 M] + the fill counter behind it
     int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks
     int ball_search = 1;               // "ball_search": NN-cache misses of the fused kernel searched by one lane each first (search_ball_lane)
+    int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)
     double lead_timeout_ms = 50.0;     // "lead_timeout_ms": how long a workgroup of a lead launch polls the pose mailbox before it gives up (-> ICP_ERR_HIP)
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs

@@ -654,6 +654,7 @@ __global__ __launch_bounds__(256) void k_search_rows(GridView g, const float4* _
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr unsigned BALL_JMASK = 255u;
 static constexpr int BALL_MAX_CAND = 256;  // candidates (cells rounded up to groups of four) a key's j can number
+static constexpr int BALL_W = 4;           // groups of four points a lane has in flight per trip of its scan
 
 __device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {  // -> v_med3_u32
     return max(min(a, b), min(max(a, b), c));
@@ -676,9 +677,33 @@ __device__ inline unsigned ball_key(const float4 q, float px, float py, float pz
     return (__float_as_uint(d2) & ~BALL_JMASK) | (unsigned)j;
 }
 
-__device__ inline bool search_ball_lane(const GridView& g, float px, float py, float pz, float seed_d2,
+// one trip of the scan: W groups of four consecutive points, all W * 4 loads in flight together (a lane's chain of
+// dependent round trips, not its instruction count, is what a one-lane search costs: the 4-wide loop of the first build
+// took 22 trips for the 64 candidates of the slowest lane of a wave); `a[g]` = the group's first point or the pads
+template <int W>
+__device__ inline void ball_trip(const float4* const (&a)[W], float px, float py, float pz, int j, Top4& t) {
+    float4 q[W][4];
+#pragma unroll
+    for (int g = 0; g < W; ++g) {
+        q[g][0] = a[g][0];
+        q[g][1] = a[g][1];
+        q[g][2] = a[g][2];
+        q[g][3] = a[g][3];
+    }
+#pragma unroll
+    for (int g = 0; g < W; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.insert(ball_key(q[g][i], px, py, pz, j + 4 * g + i));
+    }
+}
+
+// Returns true when the query is settled (pos0..2, L).  false: it goes to the generic paths; seed_pos >= 0 then names the
+// best point the own-cell scan found (closer than the caller's seed): their searches start from it.
+template <int W>
+__device__ inline bool search_ball_lane(const GridView& g, float px, float py, float pz, float seed_d2, int max_cand,
                                         int2* __restrict__ stack, int stride, int& pos0, int& pos1, int& pos2,
-                                        float& L) {
+                                        float& L, int& seed_pos) {
+    seed_pos = -1;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
     const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
@@ -711,64 +736,73 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
     }
     if (e.key != key) return false;  // own cell empty
     const int cum0 = (e.count + 3) & ~3;
-    if (cum0 > BALL_MAX_CAND) return false;
+    if (cum0 > max_cand) return false;
+    const float4* __restrict__ pad = g.pts + g.m;  // SORTED_PAD points at +inf
     Top4 t;
     t.k0 = t.k1 = t.k2 = t.k3 = ~0u;
     {
-        const float4* __restrict__ q = g.pts + e.start;
-        for (int j = 0; j < cum0; j += 4) {
-            const float4 q0 = q[j], q1 = q[j + 1], q2 = q[j + 2], q3 = q[j + 3];
-            t.insert(ball_key(q0, px, py, pz, j));
-            t.insert(ball_key(q1, px, py, pz, j + 1));
-            t.insert(ball_key(q2, px, py, pz, j + 2));
-            t.insert(ball_key(q3, px, py, pz, j + 3));
+        const float4* __restrict__ base = g.pts + e.start;
+        for (int j = 0; j < cum0; j += 4 * W) {
+            const float4* a[W];
+#pragma unroll
+            for (int gr = 0; gr < W; ++gr) a[gr] = (j + 4 * gr < cum0) ? base + (j + 4 * gr) : pad;
+            ball_trip<W>(a, px, py, pz, j, t);
         }
     }
-    // the pruning radius: the nearest so far is no farther than its key with the low bits set (a +inf / NaN key leaves
-    // the seed alone); the seed itself is a map point like any other and is met in its cell
+    if (t.k0 >= 0x7f800000u) return false;  // nothing finite in the own cell
+    // the pruning radius: the nearest so far is no farther than its key with the low bits set; the seed is a map point
+    // like any other and is met in its cell
     const float r2 = fminf(seed_d2, __uint_as_float(t.k0 | BALL_JMASK));
     const float R = sqrtf(r2) * 1.000001f + g.prune_guard;
-    if (!(R < outer)) return false;  // (also: nothing finite found)
+    const bool inside = R < outer;
     const float R2 = R * R;
     float Lb2 = outer * outer;
     int ns = 0, total = cum0;
+    if (inside) {
 #pragma unroll
-    for (int m = 1; m < 8; ++m) {
-        const int2 c = rc[m - 1];
-        if (c.y > 0) {
-            const float gap2 = ((m & 1) ? nx * nx : 0.f) + ((m & 2) ? ny * ny : 0.f) + ((m & 4) ? nz * nz : 0.f);
-            if (gap2 > R2) {
-                Lb2 = fminf(Lb2, gap2);  // every point of a pruned cell is at least that far
-            } else {
-                stack[ns * stride] = make_int2(c.x - total, total);  // candidate j of this cell sits at position j + .x
-                total += (c.y + 3) & ~3;
-                ++ns;
+        for (int m = 1; m < 8; ++m) {
+            const int2 c = rc[m - 1];
+            if (c.y > 0) {
+                const float gap2 = ((m & 1) ? nx * nx : 0.f) + ((m & 2) ? ny * ny : 0.f) + ((m & 4) ? nz * nz : 0.f);
+                if (gap2 > R2) {
+                    Lb2 = fminf(Lb2, gap2);  // every point of a pruned cell is at least that far
+                } else {
+                    stack[ns * stride] = make_int2(c.x - total, total);  // candidate j of this cell sits at position j + .x
+                    total += (c.y + 3) & ~3;
+                    ++ns;
+                }
             }
         }
     }
-    if (total > BALL_MAX_CAND) return false;
+    if (!inside || total > max_cand) {
+        // the generic paths take over, from the best point of the own cell if that beats the caller's seed
+        if (__uint_as_float(t.k0 & ~BALL_JMASK) < seed_d2) seed_pos = e.start + (int)(t.k0 & BALL_JMASK);
+        return false;
+    }
     {
         int s = 0, off = 0, jnext = cum0;
-        for (int j = cum0; j < total; j += 4) {
-            if (j >= jnext) {  // (cells start at multiples of four: j meets every boundary)
-                off = stack[s * stride].x;
-                ++s;
-                jnext = s < ns ? stack[s * stride].y : total;
+        for (int j = cum0; j < total; j += 4 * W) {
+            const float4* a[W];
+#pragma unroll
+            for (int gr = 0; gr < W; ++gr) {
+                const int jg = j + 4 * gr;
+                if (jg >= jnext && s < ns) {  // (cells start at multiples of four: a group never straddles two)
+                    off = stack[s * stride].x;
+                    ++s;
+                    jnext = s < ns ? stack[s * stride].y : total;
+                }
+                a[gr] = jg < total ? g.pts + (off + jg) : pad;
             }
-            const float4* __restrict__ q = g.pts + (off + j);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            t.insert(ball_key(q0, px, py, pz, j));
-            t.insert(ball_key(q1, px, py, pz, j + 1));
-            t.insert(ball_key(q2, px, py, pz, j + 2));
-            t.insert(ball_key(q3, px, py, pz, j + 3));
+            ball_trip<W>(a, px, py, pz, j, t);
         }
     }
     // pads behind the last map point (+inf) and NaN distances are no candidates
-    if (t.k0 >= 0x7f800000u) return false;
     if (t.k1 >= 0x7f800000u) t.k1 = ~0u;
     if (t.k2 >= 0x7f800000u) t.k2 = ~0u;
     if (t.k3 >= 0x7f800000u) t.k3 = ~0u;
-    if (t.k3 != ~0u && ((t.k3 ^ t.k0) & ~BALL_JMASK) == 0u) return false;  // four candidates within the key's resolution
+    if (t.k3 != ~0u && ((t.k3 ^ t.k0) & ~BALL_JMASK) == 0u) {  // four candidates within the key's resolution
+        return false;
+    }
     const auto position = [&](unsigned k) -> int {
         if (k == ~0u) return -1;
         const int j = (int)(k & BALL_JMASK);
@@ -827,9 +861,10 @@ static constexpr int IT_QUERIES = IT_THREADS / 4;
 
 // per-block partial normal equations from the 9-float rows of the block's queries: for every 128 queries 4 x 30 threads,
 // element e of quarter `qtr` of them, f64, fixed order (bit-reproducible).  The canonical order of the whole sum
-// (gauss_newton.hip::sum_partials_block): 128 queries -> base row r = (p0 + p1) + (p2 + p3); four consecutive base rows
-// -> super-row (r0 + r1) + (r2 + r3); super-rows in the strided 8-accumulator pattern.  A block of 128 queries (Q = 128)
-// writes its base row, a block of 512 queries its super-row: a quarter of the rows for the summing kernel, same bits.
+// (solve_device.h::sum_partials_vt): 128 queries -> base row r = (p0 + p1) + (p2 + p3); base rows s, s + S, s + 2S, s + 3S
+// (S = a quarter of the base rows) -> super-row (r0 + r1) + (r2 + r3); super-rows in the strided 8-accumulator pattern.  A
+// block of 128 queries (Q = 128) writes its base row, a block of 512 queries — four 128-query chunks S base rows apart —
+// its super-row: a quarter of the rows for the summing kernel, same bits.
 template <int Q>
 __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
                                          int block) {
@@ -900,6 +935,8 @@ struct IterInputs {
     int iter;                // index of this iteration within the registration (0, 1, ..)
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
     int ball;                // option "ball_search": the misses go through search_ball_lane first (one lane each)
+    int ball_max;            // option "ball_max": ... those with up to that many candidates (cells rounded up to fours)
+    int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
     // an L2 of its own — with consecutive queries in consecutive workgroups every L2 has to hold the rows and points of
     // the WHOLE map.  With swz_bpr_shift >= 0 the workgroups of one XCD take one azimuth sector (x elevation band) of the
@@ -1019,11 +1056,19 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     const long long t_entry = g.stamps ? wall_clock64() : 0;
     const int vb = logical_block(in, (int)blockIdx.x, lead_blocks);  // which queries, which partial row
-    const int q0 = vb * Q;
+    // which query a local slot stands for: the 128-query shape takes consecutive queries (one BASE row of the canonical sum,
+    // solve_device.h); the 512-query shape takes FOUR base rows a quarter of the scan apart — base rows vb, vb + S, vb + 2S,
+    // vb + 3S, exactly the four that form super-row vb — so a workgroup mixes four regions of the scan (the rings near the
+    // floor hit dense map cells, the upper rings sparse ones: with 512 consecutive queries per workgroup the slowest
+    // workgroup of an early launch searched for 30 us against a mean of 14, and the launch lasts as long as it does)
+    const auto query_of = [&](int slot) -> int {
+        if (Q == IT_QUERIES || in.chunk_stride <= 0) return vb * Q + slot;
+        return (vb + (slot / IT_QUERIES) * in.chunk_stride) * IT_QUERIES + (slot % IT_QUERIES);
+    };
     // ---- phase A, first half: everything that does not depend on the pose is requested now — target, cache entry and,
     // behind it, the cached neighbour and its normal (or the frame seed and its map point): in a lead launch these loads
     // are in flight while the lead workgroup solves
-    const int lq = threadIdx.x, qi = q0 + lq;
+    const int lq = threadIdx.x, qi = query_of(lq);
     bool valid = false;
     float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq, cq2 = cq, cn2 = cq,
            cq3 = cq, cn3 = cq;
@@ -1191,7 +1236,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // ---- phase B0 (round 4): every miss by ONE lane (search_ball_lane); what does not fit its pattern (own cell empty, a
     // ball that leaves the 2x2x2 block, more than 256 candidates, four candidates within a key's resolution) goes back on
     // the list for the generic paths below
-    if (in.ball && nmiss > 0) {  // block-uniform
+    // (a workgroup with a handful of misses gives each a whole wave instead — phase B1: three round trips against the ~ten
+    // of a lane on its own, and in the late launches the slowest search IS the launch)
+    if (in.ball && nmiss > in.wave_misses) {  // block-uniform
         const int listed = nmiss;
         const bool mine = (int)threadIdx.x < listed;
         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1204,20 +1251,26 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         if (threadIdx.x == 0) nmiss = 0;
         __syncthreads();
         if (mine) {
-            int p0, p1, p2;
+            int p0, p1, p2, sp;
             float L;
-            if (search_ball_lane(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), &cellstack[0][threadIdx.x], THREADS, p0, p1, p2,
-                                 L)) {
+            // (the 128-query shape is built for 64 registers: it keeps one group of four in flight)
+            if (search_ball_lane<(Q == THREADS ? BALL_W : 1)>(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), in.ball_max,
+                                         &cellstack[0][threadIdx.x], THREADS, p0, p1, p2, L, sp)) {
                 const int lq2 = __float_as_int(mp.w);
                 const float4 q = g.pts[p0];
                 const float4 nn = in.normals[p0];
-                in.nn_cache[q0 + lq2] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
+                in.nn_cache[query_of(lq2)] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
                 float row[9];
                 point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) rowbuf[lq2][k] = row[k];
                 if (g.dbg) atomicAdd(&g.dbg[0], 1);
             } else {
+                if (sp >= 0) {  // a better seed than the one it came with: the nearest point of its own cell (exact distance)
+                    const float4 q = g.pts[sp];
+                    const float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
+                    ms = make_int4(__float_as_int(fmaf(dz, dz, fmaf(dy, dy, dx * dx))), __float_as_int(q.w), sp, 0);
+                }
                 const int k = atomicAdd(&nmiss, 1);
                 miss_p[k] = mp;
                 miss_seed[k] = ms;
@@ -1241,7 +1294,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 const int lq = __float_as_int(mp.w);
                 // the runner-up and the third ride along: L then bounds everything but the set
                 const bool pair = r2.pos >= 0 && b.pos >= 0, triple = pair && r3.pos >= 0;
-                in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now),
+                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now),
                                                  __float_as_int(sqrtf(triple ? r3.second : (pair ? r2.second : b.second)) *
                                                                 0.999999f),
                                                  pair ? r2.pos : -1, triple ? r3.pos : -1);
@@ -1281,7 +1334,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             const Best& b = near.b;
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[q0 + lq] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
+                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
                                                  near.pos1, near.pos2);
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
@@ -2080,6 +2133,160 @@ __device__ inline int bucket_owner(float x, float y, float z, int world) {
     return (int)(hash_cell(key) % (unsigned)world);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The eager estimation through the neighbourhood lists with ONE lane per map point (round 4; "hoods" 2).
+// Round 3's k_normals_hood gives a point four lanes and walks its list three times (distances -> T, members, covariance)
+// with two butterfly merges in between: ~2 600 VALU instructions per wave of 16 points.  Here a lane streams the whole list
+// of its point once, sixteen entries in flight, into KN + 1 sorted 32-bit keys (distance bits, the low 11 bits replaced by
+// the entry's number; min + med3 per slot — the device of search_ball_lane).  The keys name the KN nearest entries
+// exactly whenever key KN differs from key KN - 1 in the bits above the number (every other entry then lies a whole
+// truncation step farther than all KN), and ring 1 certifies them when the KN-th distance — bounded by its key with the
+// low bits set — is within h + edge.  The covariance sums are order-independent (CovSums), so the members need no order.
+// Anything else (an uncertified KN-th neighbour: ~0.2 % of a LiDAR map; two entries within 2^-12 of each other at the
+// KN-th place; lists beyond 2 048 entries) is appended to a chip-wide queue that k_normals_queue finishes, one wave per
+// point, exactly like the continuation of k_normals_hood — in a launch of its own, so that no workgroup waits for the
+// stragglers of a sparse region while the rest of the chip idles.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr unsigned HOOD_JMASK = 2047u;
+static constexpr int NRM1_THREADS = 128;
+static constexpr int NRMQ_THREADS = 256;
+static constexpr int NRMQ_BLOCKS = 256;
+
+template <int N>
+struct TopKeys {
+    unsigned k[N];  // ascending
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < N; ++i) k[i] = ~0u;
+    }
+    __device__ inline void insert(unsigned c) {
+#pragma unroll
+        for (int i = N - 1; i > 0; --i) k[i] = umed3(k[i - 1], k[i], c);  // (the old k[i - 1]: going down)
+        k[0] = min(k[0], c);
+    }
+};
+
+template <int KN>
+__device__ inline bool cov_hood_lane(const GridView& g, int s, float* __restrict__ cov) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    const float h = g.h;
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const int2 hh = g.rows[(size_t)g.row_of_pos[s] * ROW_STRIDE + 27];
+    const int n = hh.y, n4 = (n + 3) & ~3;  // (runs are padded to whole groups of four with points at +inf)
+    if (n < KN || n4 > (int)HOOD_JMASK + 1) return false;
+    const float4* __restrict__ H = g.hood + hh.x;
+    const float4* __restrict__ pad = g.pts + g.m;
+    TopKeys<KN + 1> t;
+    t.init();
+    for (int j = 0; j < n4; j += 16) {
+        float4 q[4][4];
+#pragma unroll
+        for (int gr = 0; gr < 4; ++gr) {
+            const float4* __restrict__ a = (j + 4 * gr < n4) ? H + (j + 4 * gr) : pad;
+            q[gr][0] = a[0];
+            q[gr][1] = a[1];
+            q[gr][2] = a[2];
+            q[gr][3] = a[3];
+        }
+#pragma unroll
+        for (int gr = 0; gr < 4; ++gr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dx = q[gr][i].x - px, dy = q[gr][i].y - py, dz = q[gr][i].z - pz;
+                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                t.insert((__float_as_uint(d2) & ~HOOD_JMASK) | (unsigned)(j + 4 * gr + i));
+            }
+        }
+    }
+    if (t.k[KN - 1] >= 0x7f800000u) return false;  // fewer than KN finite distances
+    // ring 1 certifies the KN-th neighbour ...
+    const float bound = h + edge;
+    if (!(__uint_as_float(t.k[KN - 1] | HOOD_JMASK) <= bound * bound * 0.999999f)) return false;
+    // ... and the keys name the KN nearest when everybody else is a whole truncation step farther
+    if ((t.k[KN] & ~HOOD_JMASK) == (t.k[KN - 1] & ~HOOD_JMASK)) return false;
+    CovSums cs;
+    cs.zero();
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {  // (the nearest — the point itself or a twin at distance 0 — adds nothing: :407)
+        const float4 q = H[t.k[i] & HOOD_JMASK];
+        cs.add(q.x - px, q.y - py, q.z - pz);
+    }
+    cs.store(KN - 1, cov);
+    return true;
+}
+
+template <int KN, bool OWNED>
+__global__ __launch_bounds__(NRM1_THREADS) void k_normals_hood1(GridView g, int rank, int world, float4* __restrict__ out,
+                                                                int* __restrict__ nflag, int* __restrict__ queue,
+                                                                int* __restrict__ queue_n) {
+    const int s = blockIdx.x * NRM1_THREADS + threadIdx.x;
+    if (s >= g.m) return;
+    if (OWNED) {
+        const float4 P = g.pts[s];
+        if (bucket_owner(P.x, P.y, P.z, world) != rank) return;
+    }
+    float cov[6];
+    if (!cov_hood_lane<KN>(g, s, cov)) {
+        queue[atomicAdd(queue_n, 1)] = s;
+        return;
+    }
+    float nx, ny, nz;
+    smallest_eigenvector(cov[0], cov[1], cov[2], cov[3], cov[4], cov[5], nx, ny, nz);
+    if (OWNED) {
+        out[__float_as_int(g.pts[s].w)] = make_float4(nx, ny, nz, 1.f);
+    } else {
+        out[s] = make_float4(nx, ny, nz, 1.f);
+        nflag[s] = 1;
+    }
+}
+
+// the queue of k_normals_hood1: one wave per point — the merged (distance, index) list of ring 1 rebuilt from the point's
+// neighbourhood list, then finish_cov_wave (fine ring 2, coarse level, exhaustive), the eigen-solve by lane 0.  The last
+// workgroup to leave resets the queue for the next launch.
+template <int KN, bool OWNED>
+__global__ __launch_bounds__(NRMQ_THREADS) void k_normals_queue(GridView g, int max_rings, float4* __restrict__ out,
+                                                                int* __restrict__ nflag, const int* __restrict__ queue,
+                                                                int* __restrict__ queue_n, int* __restrict__ ticket) {
+    __shared__ int wl[NRMQ_THREADS / 64][128];
+    __shared__ float covs[NRMQ_THREADS / 64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = *queue_n;
+    for (int k = blockIdx.x * (NRMQ_THREADS / 64) + wave; k < n; k += gridDim.x * (NRMQ_THREADS / 64)) {  // wave-uniform
+        const int ps = queue[k];
+        const float4 P = g.pts[ps];
+        const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
+        TopK<KN> t, m;
+        t.init();
+        for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
+        merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
+        finish_cov_wave<KN>(g, ps, lane, max_rings, m, covs[wave], wl[wave]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            float nx, ny, nz;
+            const float* c = covs[wave];
+            smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
+            if (OWNED) {
+                out[__float_as_int(P.w)] = make_float4(nx, ny, nz, 1.f);
+            } else {
+                out[ps] = make_float4(nx, ny, nz, 1.f);
+                nflag[ps] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+        *queue_n = 0;
+        *ticket = 0;
+    }
+}
+
 template <int KN, int NL>
 __global__ __launch_bounds__(NRM_THREADS) void k_normals_owned(GridView g, int max_rings, int rank, int world,
                                                                float4* __restrict__ by_index) {
@@ -2211,6 +2418,12 @@ __global__ void k_gather_neighbors(GridView g, const int* __restrict__ nn_pos, c
     if (idx_out) idx_out[i] = __float_as_int(q.w);
 }
 
+// the straggler queue of k_normals_hood1: its length and the exit ticket of k_normals_queue live behind the list-space
+// counter of the neighbourhood lists (zeroed by the first launch of every grid build: hash_grid.hip::k_grid_clear)
+static int* hood_queue_counter(icp_ctx* ctx) {
+    return (int*)(ctx->hood.as<char>() + (size_t)HOOD_PER_POINT * (size_t)ctx->map_m * sizeof(float4) + 16);
+}
+
 static GridView make_view(icp_ctx* ctx) {
     GridView g;
     g.table = ctx->table.as<GridEntry>();
@@ -2309,7 +2522,23 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (NL == 4 && g.hood && (kn == 11 || kn == 6)) {  // through the neighbourhood lists
+    if (NL == 4 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {  // one lane per point + the queue of the stragglers
+        int* qn = hood_queue_counter(ctx);
+        const int b1 = (int)((ctx->map_m + NRM1_THREADS - 1) / NRM1_THREADS);
+        if (kn == 11) {
+            hipLaunchKernelGGL((k_normals_hood1<11, false>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, 0, 1, nrm, nf,
+                               ctx->worklist.as<int>(), qn);
+            hipLaunchKernelGGL((k_normals_queue<11, false>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
+                               nrm, nf, ctx->worklist.as<int>(), qn, qn + 1);
+        } else {
+            hipLaunchKernelGGL((k_normals_hood1<6, false>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, 0, 1, nrm, nf,
+                               ctx->worklist.as<int>(), qn);
+            hipLaunchKernelGGL((k_normals_queue<6, false>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
+                               nrm, nf, ctx->worklist.as<int>(), qn, qn + 1);
+        }
+        return;
+    }
+    if (NL == 4 && g.hood && (kn == 11 || kn == 6)) {  // through the neighbourhood lists, four lanes per point (round 3)
         if (kn == 11)
             hipLaunchKernelGGL((k_normals_hood<11, false>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, 0, 1,
                                nrm, nf);
@@ -2356,7 +2585,21 @@ int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev)
     const int rings = knn_fine_rings(ctx);
     float4* out = (float4*)by_index_dev;
     const int tok = prof_begin(ctx, 2);
-    if (g.hood && kn == 11)
+    if (g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {
+        int* qn = hood_queue_counter(ctx);
+        const int b1 = (int)((m + NRM1_THREADS - 1) / NRM1_THREADS);
+        if (kn == 11) {
+            hipLaunchKernelGGL((k_normals_hood1<11, true>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, rank, world, out,
+                               (int*)nullptr, ctx->worklist.as<int>(), qn);
+            hipLaunchKernelGGL((k_normals_queue<11, true>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
+                               out, (int*)nullptr, ctx->worklist.as<int>(), qn, qn + 1);
+        } else {
+            hipLaunchKernelGGL((k_normals_hood1<6, true>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, rank, world, out,
+                               (int*)nullptr, ctx->worklist.as<int>(), qn);
+            hipLaunchKernelGGL((k_normals_queue<6, true>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
+                               out, (int*)nullptr, ctx->worklist.as<int>(), qn, qn + 1);
+        }
+    } else if (g.hood && kn == 11)
         hipLaunchKernelGGL((k_normals_hood<11, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank,
                            world, out, (int*)nullptr);
     else if (g.hood && kn == 6)
@@ -2459,7 +2702,9 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // (the 128-query shape runs while most workgroups search: a wave per miss is a round of ~8 us under that load, the
     // 4-lane groups take up to 128 misses in 10-15 us — whole waves only for a handful)
     in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
+    in.chunk_stride = narrow ? blocks : 0;  // (S = ceil(base rows / 4) = the number of 512-query workgroups)
     in.ball = ctx->ball_search;
+    in.ball_max = ctx->ball_max < BALL_MAX_CAND ? ctx->ball_max : BALL_MAX_CAND;
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;
     in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;
@@ -2468,7 +2713,12 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         // row has fewer than 8 blocks); any other target array: eight contiguous runs of workgroups
         const int W = ctx->cfg.width, H = ctx->cfg.height;
         int row_blocks = 1, rows = blocks;
-        if ((int64_t)H * W == n && W % per_block == 0) {
+        if (narrow && (int64_t)H * W == n && W % IT_QUERIES == 0 && H % 4 == 0) {
+            // (a 512-query workgroup = the same 128 columns of four image rows H / 4 apart: logical workgroup = that segment
+            // of the first of them)
+            row_blocks = W / IT_QUERIES;
+            rows = H / 4;
+        } else if (!narrow && (int64_t)H * W == n && W % per_block == 0) {
             row_blocks = W / per_block;
             rows = H;
         }

@@ -261,18 +261,21 @@ __device__ inline void solve_and_update(RegState* __restrict__ st, const double*
 // Fixed-order sum of the partial rows -> out[NEQ].  The order of the additions depends only on the geometry, never on
 // timing, and is defined for 1024 VIRTUAL threads (32 row groups x 32 columns): a workgroup of THREADS threads plays
 // 1024 / THREADS of them each, so the 1024-thread summing kernel and the 512-thread lead workgroup of the fused iteration
-// launch form the same bits.  Canonical order: four consecutive BASE rows form a super-row (r0 + r1) + (r2 + r3) (rows past
-// the end count as 0.0); the super-rows are added in the strided 8-accumulator pattern below.  `quad` = 1: `partials`
+// launch form the same bits.  Canonical order: with B base rows (128 queries each) and S = ceil(B / 4), super-row s =
+// (r[s] + r[s + S]) + (r[s + 2S] + r[s + 3S]) — four base rows a QUARTER OF THE SCAN apart (rows past the end count as
+// 0.0; round 3 grouped four consecutive ones: the 512-query workgroup that forms a super-row then searched 512 consecutive
+// queries, and the one in the densest region of the map set the duration of the launch); the super-rows are added in the
+// strided 8-accumulator pattern below.  `quad` = 1: `partials`
 // holds base rows (grouped here); 0: the producer already wrote super-rows (the 512-queries-per-block shape of the fused
 // iteration kernel: a quarter of the bytes for this single workgroup to load).  `lds` = 32 x NEQ doubles of scratch.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ inline double load_super_row(const double* __restrict__ partials, int nrows, int quad, int sr, int col) {
     if (!quad) return partials[(size_t)sr * NEQ + col];
-    const int b = 4 * sr;
-    const double r0 = partials[(size_t)b * NEQ + col];
-    const double r1 = b + 1 < nrows ? partials[(size_t)(b + 1) * NEQ + col] : 0.0;
-    const double r2 = b + 2 < nrows ? partials[(size_t)(b + 2) * NEQ + col] : 0.0;
-    const double r3 = b + 3 < nrows ? partials[(size_t)(b + 3) * NEQ + col] : 0.0;
+    const int S = (nrows + 3) / 4;  // super-row sr = base rows sr, sr + S, sr + 2S, sr + 3S
+    const double r0 = partials[(size_t)sr * NEQ + col];
+    const double r1 = sr + S < nrows ? partials[(size_t)(sr + S) * NEQ + col] : 0.0;
+    const double r2 = sr + 2 * S < nrows ? partials[(size_t)(sr + 2 * S) * NEQ + col] : 0.0;
+    const double r3 = sr + 3 * S < nrows ? partials[(size_t)(sr + 3 * S) * NEQ + col] : 0.0;
     return (r0 + r1) + (r2 + r3);
 }
 

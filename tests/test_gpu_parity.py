@@ -493,6 +493,21 @@ def test_knn_normals_on_stress_clouds(torch_cuda, O, neighbors):
         _, eager, ix = ctx.nearest_neighbor_search(cloud, with_index=True)
         np.testing.assert_array_equal(eager, whole[ix, :3], err_msg=f"{name} eager")
         ctx.close()
+        # the eager kernels of the earlier rounds behind their options: four lanes per point over the neighbourhood lists
+        # (hoods 1), the row walk (hoods 0) — the default (hoods 2) is one lane per point + a queue of the stragglers
+        for hoods in (1, 0):
+            ctx = _ctx(num_neighbors_normals=neighbors, max_num_alignments=1, threshold_delta_pose=0.0)
+            ctx.set_option("hoods", hoods)
+            ctx.map_set(cloud)
+            owned = ctx.map_normals_owned(0, 1).cpu().numpy()
+            np.testing.assert_array_equal(owned, whole, err_msg=f"{name} owned, hoods {hoods}")
+            try:
+                ctx.register(cloud)
+            except RuntimeError:
+                pass
+            _, eager, ix = ctx.nearest_neighbor_search(cloud, with_index=True)
+            np.testing.assert_array_equal(eager, whole[ix, :3], err_msg=f"{name} eager, hoods {hoods}")
+            ctx.close()
 
 
 def test_grid_build_with_more_scan_tiles_than_resident_workgroups(torch_cuda, O):
@@ -663,6 +678,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
     scans, poses, model = _bench_workload()
     variants = {"default": {}, "nocache": {"nn_cache": 0}, "no_lead_solve": {"lead_solve": 0},
                 "never_narrow": {"narrow_from": -1}, "narrow_always": {"narrow_from": 0}, "no_hoods": {"hoods": 0},
+                "hoods_4_lanes": {"hoods": 1}, "narrow_from_3": {"narrow_from": 3}, "ball_max_64": {"ball_max": 64},
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
                 "round3": {"ball_search": 0, "narrow_from": 3}}
     results = {}
