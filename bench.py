@@ -462,6 +462,9 @@ def odometry_loop_leg(args, device_index, frames=36):
                GridSample(GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted")),
                ToTensor(ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}, dtype="float32"), device=dev)]
     init = ConstantVelocityInitialization()
+    for opt in args.option:  # (developer A/B runs)
+        name, value = opt.split("=", 1)
+        odo.ctx.set_option(name, float(value))
 
     def one_pass():
         odo.init()

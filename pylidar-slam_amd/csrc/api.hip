@@ -1687,6 +1687,7 @@ int icp_map_normals_owned(icp_ctx* ctx, int32_t rank, int32_t world, float* norm
     }
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    ctx->sharded_normals = true;  // (the grid builds from now on keep the neighbourhood lists for it)
     return launch_normals_owned(ctx, rank, world, normals_by_index);
 }
 

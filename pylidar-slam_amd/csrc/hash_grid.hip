@@ -172,10 +172,7 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
     __shared__ float T[16];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
-        if (hood_used) {
-            hood_used[0] = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
-            hood_used[2] = 0;  // the straggler queue of the one-lane kNN normals: length | exit ticket (search.hip)
-        }
+        if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
     }
     const long long first = (long long)blockIdx.x * blockDim.x;
     const bool moves = first < move.m;  // block-uniform
@@ -667,11 +664,12 @@ int build_grid(icp_ctx* ctx) {
     }
     // (the neighbourhood lists are allocated before the first launch of the build: their space counter is zeroed by it)
     // ... and only where something will read them: the eager estimation of point-to-plane normals with k = 5 or 10
-    // neighbours (k_normals_hood) — a point-to-point loop, a lazily estimated map or another k never does (432 B per map
-    // point and a launch per build otherwise); the list space of a map that stops needing it is given back
+    // neighbours (k_normals_hood2 / k_normals_hood), by the library's own schedule or map-sharded through
+    // icp_map_normals_owned — a point-to-point loop, a lazily estimated map or another k never does (480 B per map point
+    // and a launch per build otherwise); the list space of a map that stops needing it is given back
     const int kn_hood = ctx->cfg.num_neighbors_normals + 1;
     const bool with_hoods = ctx->hoods && m <= (1ll << 22) && (kn_hood == 11 || kn_hood == 6) &&
-                            wants_eager_normals(ctx, ctx->tgt_n > 0 ? ctx->tgt_n : m);
+                            (wants_eager_normals(ctx, ctx->tgt_n > 0 ? ctx->tgt_n : m) || ctx->sharded_normals);
     if (!with_hoods && ctx->hood.ptr) {
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a launch of the previous build may still read them)
         ctx->hood.release();

@@ -325,7 +325,8 @@ struct icp_ctx {
     int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
     int hoods = 2;                     // "hoods": neighbourhood lists for the kNN normals (1: four lanes per point, 2: one lane per point + a straggler queue)
     bool hoods_valid = false;          // ... built for the current grid
-    icp::DeviceBuffer hood;            // float4[<= 27 M] + the fill counter behind it
+    bool sharded_normals = false;      // icp_map_normals_owned has been used on this context (the lists serve it too)
+    icp::DeviceBuffer hood;            // float4[<= 30 M] + the fill counter behind it
     int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks
     int ball_search = 1;               // "ball_search": NN-cache misses of the fused kernel searched by one lane each first (search_ball_lane)
     int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)

@@ -2134,23 +2134,25 @@ __device__ inline int bucket_owner(float x, float y, float z, int world) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The eager estimation through the neighbourhood lists with ONE lane per map point (round 4; "hoods" 2).
-// Round 3's k_normals_hood gives a point four lanes and walks its list three times (distances -> T, members, covariance)
-// with two butterfly merges in between: ~2 600 VALU instructions per wave of 16 points.  Here a lane streams the whole list
-// of its point once, sixteen entries in flight, into KN + 1 sorted 32-bit keys (distance bits, the low 11 bits replaced by
-// the entry's number; min + med3 per slot — the device of search_ball_lane).  The keys name the KN nearest entries
-// exactly whenever key KN differs from key KN - 1 in the bits above the number (every other entry then lies a whole
-// truncation step farther than all KN), and ring 1 certifies them when the KN-th distance — bounded by its key with the
-// low bits set — is within h + edge.  The covariance sums are order-independent (CovSums), so the members need no order.
+// The eager estimation through the neighbourhood lists with TWO lanes per map point and ONE pass over the list (round 4;
+// "hoods" 2).  Round 3's k_normals_hood gives a point four lanes and walks its list three times (distances -> T, members,
+// covariance) with two butterfly merges in between: ~2 600 VALU instructions per wave of 16 points.  Here the two lanes of
+// a point stream alternate groups of four entries, sixteen entries in flight each, into KN + 1 sorted 32-bit keys
+// (distance bits, the low 11 bits replaced by the entry's number; min + med3 per slot — the device of search_ball_lane);
+// one butterfly step (element-wise min of one list with the other reversed = the KN + 1 smallest of both) merges them.
+// The keys name the KN nearest entries exactly whenever key KN differs from key KN - 1 in the bits above the number (every
+// other entry then lies a whole truncation step farther than all KN), and ring 1 certifies them when the KN-th distance —
+// bounded by its key with the low bits set — is within h + edge.  The covariance sums are order-independent (CovSums), so
+// the members need no order and the two lanes split them.  (One lane per point was built first: 43 us — 1 563 waves on
+// 1 024 SIMDs, each a chain of eight list trips, the Jacobi solve behind it.)
 // Anything else (an uncertified KN-th neighbour: ~0.2 % of a LiDAR map; two entries within 2^-12 of each other at the
-// KN-th place; lists beyond 2 048 entries) is appended to a chip-wide queue that k_normals_queue finishes, one wave per
-// point, exactly like the continuation of k_normals_hood — in a launch of its own, so that no workgroup waits for the
-// stragglers of a sparse region while the rest of the chip idles.
+// KN-th place; lists beyond 2 048 entries) is finished by a whole wave of the workgroup (finish_cov_wave, as before).
+// (Tried and dropped: the stragglers in a chip-wide queue — a launch of its own behind the main one: +31 us, a chain of
+// dependent probes per point whoever runs it; drained inside the launch by the waves that are done with ring 1: a shared
+// head counter serialises a thousand waves on one address, 7 ms.)
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr unsigned HOOD_JMASK = 2047u;
-static constexpr int NRM1_THREADS = 128;
-static constexpr int NRMQ_THREADS = 256;
-static constexpr int NRMQ_BLOCKS = 256;
+static constexpr int NRM2_THREADS = 128;  // 64 map points x 2 lanes
 
 template <int N>
 struct TopKeys {
@@ -2166,8 +2168,9 @@ struct TopKeys {
     }
 };
 
+// the two lanes of a point (sub = 0 / 1, neighbours in a DPP quad); true: lane 0 has written the covariance
 template <int KN>
-__device__ inline bool cov_hood_lane(const GridView& g, int s, float* __restrict__ cov) {
+__device__ inline bool cov_hood_pair(const GridView& g, int s, int sub, float* __restrict__ cov) {
     const float4 P = g.pts[s];
     const float px = P.x, py = P.y, pz = P.z;
     const float h = g.h;
@@ -2178,16 +2181,18 @@ __device__ inline bool cov_hood_lane(const GridView& g, int s, float* __restrict
     const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
     const int2 hh = g.rows[(size_t)g.row_of_pos[s] * ROW_STRIDE + 27];
     const int n = hh.y, n4 = (n + 3) & ~3;  // (runs are padded to whole groups of four with points at +inf)
-    if (n < KN || n4 > (int)HOOD_JMASK + 1) return false;
+    if (n < KN || n4 > (int)HOOD_JMASK + 1) return false;  // pair-uniform
     const float4* __restrict__ H = g.hood + hh.x;
     const float4* __restrict__ pad = g.pts + g.m;
     TopKeys<KN + 1> t;
     t.init();
-    for (int j = 0; j < n4; j += 16) {
+    for (int j = 0; j < n4; j += 32) {  // pair-uniform trip count: the DPP exchange below needs both lanes
         float4 q[4][4];
+        int first[4];
 #pragma unroll
         for (int gr = 0; gr < 4; ++gr) {
-            const float4* __restrict__ a = (j + 4 * gr < n4) ? H + (j + 4 * gr) : pad;
+            first[gr] = j + 8 * gr + 4 * sub;
+            const float4* __restrict__ a = first[gr] < n4 ? H + first[gr] : pad;
             q[gr][0] = a[0];
             q[gr][1] = a[1];
             q[gr][2] = a[2];
@@ -2199,78 +2204,94 @@ __device__ inline bool cov_hood_lane(const GridView& g, int s, float* __restrict
             for (int i = 0; i < 4; ++i) {
                 const float dx = q[gr][i].x - px, dy = q[gr][i].y - py, dz = q[gr][i].z - pz;
                 const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                t.insert((__float_as_uint(d2) & ~HOOD_JMASK) | (unsigned)(j + 4 * gr + i));
+                t.insert((__float_as_uint(d2) & ~HOOD_JMASK) | (unsigned)((first[gr] + i) & (int)HOOD_JMASK));
             }
         }
     }
-    if (t.k[KN - 1] >= 0x7f800000u) return false;  // fewer than KN finite distances
+    // the KN + 1 smallest of both lanes' lists, sorted again (identical in the two lanes)
+    TopKeys<KN + 1> m;
+    m.init();
+#pragma unroll
+    for (int i = 0; i <= KN; ++i) m.insert(min(t.k[i], (unsigned)quad_xor<1>((int)t.k[KN - i])));
+    if (m.k[KN - 1] >= 0x7f800000u) return false;  // fewer than KN finite distances
     // ring 1 certifies the KN-th neighbour ...
     const float bound = h + edge;
-    if (!(__uint_as_float(t.k[KN - 1] | HOOD_JMASK) <= bound * bound * 0.999999f)) return false;
+    if (!(__uint_as_float(m.k[KN - 1] | HOOD_JMASK) <= bound * bound * 0.999999f)) return false;
     // ... and the keys name the KN nearest when everybody else is a whole truncation step farther
-    if ((t.k[KN] & ~HOOD_JMASK) == (t.k[KN - 1] & ~HOOD_JMASK)) return false;
+    if ((m.k[KN] & ~HOOD_JMASK) == (m.k[KN - 1] & ~HOOD_JMASK)) return false;
     CovSums cs;
     cs.zero();
 #pragma unroll
     for (int i = 0; i < KN; ++i) {  // (the nearest — the point itself or a twin at distance 0 — adds nothing: :407)
-        const float4 q = H[t.k[i] & HOOD_JMASK];
-        cs.add(q.x - px, q.y - py, q.z - pz);
+        if ((i & 1) == sub) {
+            const float4 q = H[m.k[i] & HOOD_JMASK];
+            cs.add(q.x - px, q.y - py, q.z - pz);
+        }
     }
-    cs.store(KN - 1, cov);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cs.c[k] += quad_xor<1>(cs.c[k]);  // (exact sums of multiples of 2^-40: any order)
+    if (sub == 0) cs.store(KN - 1, cov);
     return true;
 }
 
 template <int KN, bool OWNED>
-__global__ __launch_bounds__(NRM1_THREADS) void k_normals_hood1(GridView g, int rank, int world, float4* __restrict__ out,
-                                                                int* __restrict__ nflag, int* __restrict__ queue,
-                                                                int* __restrict__ queue_n) {
-    const int s = blockIdx.x * NRM1_THREADS + threadIdx.x;
-    if (s >= g.m) return;
-    if (OWNED) {
+__global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int max_rings, int rank, int world,
+                                                                float4* __restrict__ out, int* __restrict__ nflag) {
+    constexpr int PTS = NRM2_THREADS / 2;
+    __shared__ float covs[PTS][7];
+    __shared__ int settled[PTS];
+    __shared__ int pend_s[PTS];
+    __shared__ int npend;
+    __shared__ int wl[NRM2_THREADS / 64][128];
+    __shared__ float wcov[NRM2_THREADS / 64][8];
+    if (threadIdx.x == 0) npend = 0;
+    __syncthreads();
+    const int lq = threadIdx.x >> 1, sub = threadIdx.x & 1;
+    const int s = blockIdx.x * PTS + lq;
+    bool mine = s < g.m;
+    if (OWNED && mine) {
         const float4 P = g.pts[s];
-        if (bucket_owner(P.x, P.y, P.z, world) != rank) return;
+        mine = bucket_owner(P.x, P.y, P.z, world) == rank;  // pair-uniform
     }
-    float cov[6];
-    if (!cov_hood_lane<KN>(g, s, cov)) {
-        queue[atomicAdd(queue_n, 1)] = s;
-        return;
+    bool ok = false;
+    if (mine) ok = cov_hood_pair<KN>(g, s, sub, covs[lq]);
+    if (sub == 0) {
+        settled[lq] = (mine && ok) ? 1 : 0;
+        if (mine && !ok) pend_s[atomicAdd(&npend, 1)] = s;
     }
-    float nx, ny, nz;
-    smallest_eigenvector(cov[0], cov[1], cov[2], cov[3], cov[4], cov[5], nx, ny, nz);
-    if (OWNED) {
-        out[__float_as_int(g.pts[s].w)] = make_float4(nx, ny, nz, 1.f);
-    } else {
-        out[s] = make_float4(nx, ny, nz, 1.f);
-        nflag[s] = 1;
+    __syncthreads();
+    if (threadIdx.x < PTS && settled[threadIdx.x]) {  // the eigen-solves on a dense wave
+        const int s2 = blockIdx.x * PTS + threadIdx.x;
+        float nx, ny, nz;
+        const float* c = covs[threadIdx.x];
+        smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
+        if (OWNED) {
+            out[__float_as_int(g.pts[s2].w)] = make_float4(nx, ny, nz, 1.f);
+        } else {
+            out[s2] = make_float4(nx, ny, nz, 1.f);
+            nflag[s2] = 1;
+        }
     }
-}
-
-// the queue of k_normals_hood1: one wave per point — the merged (distance, index) list of ring 1 rebuilt from the point's
-// neighbourhood list, then finish_cov_wave (fine ring 2, coarse level, exhaustive), the eigen-solve by lane 0.  The last
-// workgroup to leave resets the queue for the next launch.
-template <int KN, bool OWNED>
-__global__ __launch_bounds__(NRMQ_THREADS) void k_normals_queue(GridView g, int max_rings, float4* __restrict__ out,
-                                                                int* __restrict__ nflag, const int* __restrict__ queue,
-                                                                int* __restrict__ queue_n, int* __restrict__ ticket) {
-    __shared__ int wl[NRMQ_THREADS / 64][128];
-    __shared__ float covs[NRMQ_THREADS / 64][8];
+    // ---- the stragglers of this workgroup, a wave per point
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = *queue_n;
-    for (int k = blockIdx.x * (NRMQ_THREADS / 64) + wave; k < n; k += gridDim.x * (NRMQ_THREADS / 64)) {  // wave-uniform
-        const int ps = queue[k];
+#ifdef ICP_DEV_SKIP_STRAGGLERS  // (timing experiments only: wrong normals)
+    if (npend >= 0) return;
+#endif
+    for (int k = wave; k < npend; k += NRM2_THREADS / 64) {  // wave-uniform
+        const int ps = pend_s[k];
         const float4 P = g.pts[ps];
         const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
         TopK<KN> t, m;
         t.init();
         for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
         merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
-        finish_cov_wave<KN>(g, ps, lane, max_rings, m, covs[wave], wl[wave]);
+        finish_cov_wave<KN>(g, ps, lane, max_rings, m, wcov[wave], wl[wave]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane == 0) {
             float nx, ny, nz;
-            const float* c = covs[wave];
+            const float* c = wcov[wave];
             smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
             if (OWNED) {
                 out[__float_as_int(P.w)] = make_float4(nx, ny, nz, 1.f);
@@ -2279,11 +2300,8 @@ __global__ __launch_bounds__(NRMQ_THREADS) void k_normals_queue(GridView g, int 
                 nflag[ps] = 1;
             }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
-        *queue_n = 0;
-        *ticket = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the next point overwrites the wave's scratch)
     }
 }
 
@@ -2418,12 +2436,6 @@ __global__ void k_gather_neighbors(GridView g, const int* __restrict__ nn_pos, c
     if (idx_out) idx_out[i] = __float_as_int(q.w);
 }
 
-// the straggler queue of k_normals_hood1: its length and the exit ticket of k_normals_queue live behind the list-space
-// counter of the neighbourhood lists (zeroed by the first launch of every grid build: hash_grid.hip::k_grid_clear)
-static int* hood_queue_counter(icp_ctx* ctx) {
-    return (int*)(ctx->hood.as<char>() + (size_t)HOOD_PER_POINT * (size_t)ctx->map_m * sizeof(float4) + 16);
-}
-
 static GridView make_view(icp_ctx* ctx) {
     GridView g;
     g.table = ctx->table.as<GridEntry>();
@@ -2522,20 +2534,14 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     const int rings = knn_fine_rings(ctx);
     float4* nrm = ctx->normals.as<float4>();
     int* nf = ctx->nflag.as<int>();
-    if (NL == 4 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {  // one lane per point + the queue of the stragglers
-        int* qn = hood_queue_counter(ctx);
-        const int b1 = (int)((ctx->map_m + NRM1_THREADS - 1) / NRM1_THREADS);
-        if (kn == 11) {
-            hipLaunchKernelGGL((k_normals_hood1<11, false>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, 0, 1, nrm, nf,
-                               ctx->worklist.as<int>(), qn);
-            hipLaunchKernelGGL((k_normals_queue<11, false>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
-                               nrm, nf, ctx->worklist.as<int>(), qn, qn + 1);
-        } else {
-            hipLaunchKernelGGL((k_normals_hood1<6, false>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, 0, 1, nrm, nf,
-                               ctx->worklist.as<int>(), qn);
-            hipLaunchKernelGGL((k_normals_queue<6, false>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
-                               nrm, nf, ctx->worklist.as<int>(), qn, qn + 1);
-        }
+    if (NL == 4 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {  // two lanes per point, one pass over the list
+        const int b2 = (int)((ctx->map_m + NRM2_THREADS / 2 - 1) / (NRM2_THREADS / 2));
+        if (kn == 11)
+            hipLaunchKernelGGL((k_normals_hood2<11, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+                               nf);
+        else
+            hipLaunchKernelGGL((k_normals_hood2<6, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+                               nf);
         return;
     }
     if (NL == 4 && g.hood && (kn == 11 || kn == 6)) {  // through the neighbourhood lists, four lanes per point (round 3)
@@ -2586,19 +2592,13 @@ int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev)
     float4* out = (float4*)by_index_dev;
     const int tok = prof_begin(ctx, 2);
     if (g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {
-        int* qn = hood_queue_counter(ctx);
-        const int b1 = (int)((m + NRM1_THREADS - 1) / NRM1_THREADS);
-        if (kn == 11) {
-            hipLaunchKernelGGL((k_normals_hood1<11, true>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, rank, world, out,
-                               (int*)nullptr, ctx->worklist.as<int>(), qn);
-            hipLaunchKernelGGL((k_normals_queue<11, true>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
-                               out, (int*)nullptr, ctx->worklist.as<int>(), qn, qn + 1);
-        } else {
-            hipLaunchKernelGGL((k_normals_hood1<6, true>), dim3(b1), dim3(NRM1_THREADS), 0, ctx->stream, g, rank, world, out,
-                               (int*)nullptr, ctx->worklist.as<int>(), qn);
-            hipLaunchKernelGGL((k_normals_queue<6, true>), dim3(NRMQ_BLOCKS), dim3(NRMQ_THREADS), 0, ctx->stream, g, rings,
-                               out, (int*)nullptr, ctx->worklist.as<int>(), qn, qn + 1);
-        }
+        const int b2 = (int)((m + NRM2_THREADS / 2 - 1) / (NRM2_THREADS / 2));
+        if (kn == 11)
+            hipLaunchKernelGGL((k_normals_hood2<11, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, rank, world,
+                               out, (int*)nullptr);
+        else
+            hipLaunchKernelGGL((k_normals_hood2<6, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, rank, world,
+                               out, (int*)nullptr);
     } else if (g.hood && kn == 11)
         hipLaunchKernelGGL((k_normals_hood<11, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank,
                            world, out, (int*)nullptr);

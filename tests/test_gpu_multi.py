@@ -79,7 +79,7 @@ def test_c4_size_map_sharded_registration_vs_oracle(torch_cuda, O):
     """BASELINE.json configs[3] on one GPU: a 128-beam 200k-point scan against a 1M-point map.  The map is > 2x the scan,
     so below `eager_normals_limit` normals are estimated lazily for the map points the scan touches (unfused iterations); with the
     map-sharded estimation (here two simulated ranks) the normals are all there and the fused kernel runs.  Both within
-    1e-4 m / 1e-4 rad of the oracle."""
+    1e-4 m / 1e-4 rad of the oracle over the benchmark's 20 iterations, every iteration's loss within 1e-3."""
     torch = torch_cuda
     from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
     cfg = SceneConfig(height=128, width=1563, up_fov=22.5, down_fov=-22.5, step=0.2, yaw_rate=0.005)
@@ -87,7 +87,7 @@ def test_c4_size_map_sharded_registration_vs_oracle(torch_cuda, O):
     model = make_fixed_map(cfg, scans[:20], poses[:20], ref_frame=19, num_points=1_000_000, voxel=0.1)
     scan = scans[20]
     assert scan.shape[0] == 128 * 1563 and model.shape[0] == 1_000_000
-    iters = 5
+    iters = 20  # (the benchmark's iteration count: VERDICT r3 item 3; five in round 3)
     kw = dict(height=128, width=1563, up_fov=22.5, down_fov=-22.5, max_num_alignments=iters, threshold_delta_pose=0.0,
               scheme="geman_mcclure", sigma=0.3)
     dmodel, dscan = torch.from_numpy(model).cuda(), torch.from_numpy(scan).cuda()

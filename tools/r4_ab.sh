@@ -5,7 +5,7 @@ TAG=${1:-r4x}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 run() {
   local extra=""; for o in ${2//,/ }; do extra="$extra --option $o"; done
-  timeout 300 python bench.py --steps 84 --warmup 6 --no-cpu-baseline --loop-steps 0 --no-profile --plugin-steps 0 --odometry-loop 0 $extra > $OUT/b_$1.json 2> $OUT/b_$1.err
+  timeout 120 python bench.py --steps 84 --warmup 6 --no-cpu-baseline --loop-steps 0 --no-profile --plugin-steps 0 --odometry-loop 0 $extra > $OUT/b_$1.json 2> $OUT/b_$1.err
   python - $OUT/b_$1.json "$1 $2" <<'PY'
 import json,sys
 try:
