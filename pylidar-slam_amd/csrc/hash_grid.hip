@@ -609,7 +609,11 @@ int build_grid(icp_ctx* ctx) {
         const int rc = run_seed_job(ctx);
         if (rc) return rc;
     }
-    const unsigned int tsize = next_pow2((unsigned int)(2 * m));
+    // table slots: the next power of two above 1.25 M (round 3: above 2 M).  A map fills at most one slot per point, so
+    // the load stays below 0.8 whatever the cloud (linear probing: a handful of probes even there); a LiDAR map with its
+    // ~16 points per cell fills 5 % — and the clearing launch, the one-launch scan and the sparse row array all walk or
+    // reserve the WHOLE table every build (8 MB cleared and scanned for 6 000 cells at the headline sizes)
+    const unsigned int tsize = next_pow2((unsigned int)(m + m / 4));
     ICP_HIP(ctx, ctx->table.reserve((size_t)2 * tsize * sizeof(GridEntry)));  // fine level, then the coarse level
     ICP_HIP(ctx, ctx->csorted.reserve((size_t)m * sizeof(float4)));
     ICP_HIP(ctx, ctx->cslot_of.reserve((size_t)m * sizeof(int)));
