@@ -839,6 +839,14 @@ def main():
     res, elapsed = timed_region(extra, main_tr, args.steps, dist, dev)
     prof = main_tr.ctx.profile_read() if not args.no_profile else None
     prof_iter = main_tr.ctx.profile_read_iterations(args.iters) if not args.no_profile else None
+    # a short run (the driver's 20 steps) sees every iteration index ONCE — one sample each, some of them on the two
+    # turn-around frames of the trajectory: 100 more frames of the same loop with the same sampling (outside the timed
+    # region; all ranks take part), reported next to the timed region's own figure as `avg_launch_us_long`
+    prof_iter_long = None
+    if not args.no_profile and args.steps < MIN_STEPS_FOR_HEADLINE and not extra:
+        main_tr.run(100)
+        prof_iter_long = main_tr.ctx.profile_read_iterations(args.iters)
+        del main_tr.step_ms[args.steps:]
     main_tr.ctx.profile_enable(0)
     main_tr.ctx.set_option("profile_rotate", 0)
     event_floor_us = main_tr.ctx.profile_event_floor(200) if not args.no_profile else None
@@ -954,6 +962,11 @@ def main():
             # rocprofv3's 16.7 and 18.3 raw)
             rp = rocprof_figure()
             net_us = raw_us
+            long_us = None
+            if prof_iter_long is not None:  # (cumulative: the timed region's samples + the 100 extra frames')
+                ms_l, n_l = prof_iter_long
+                seen_l = [float(ms_l[i] / n_l[i] * 1e3) for i in range(args.iters) if n_l[i] > 0]
+                long_us = sum(seen_l) / len(seen_l)
             avg_s = net_us * 1e-6
             n_local = main_tr.n_local if sharded else main_tr.n_pts
             achieved = BYTES_PER_POINT_ITER * n_local / avg_s
@@ -963,7 +976,9 @@ def main():
                                          "voxel-hash grid + point-to-plane rows + per-block partial normal equations)",
                                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
-                               "avg_launch_us": net_us, "event_floor_us": event_floor_us,
+                               "avg_launch_us": net_us, "avg_launch_us_long": long_us,
+                               "frac_long": (BYTES_PER_POINT_ITER * n_local / (long_us * 1e-6) / HBM_PEAK) if long_us else None,
+                               "event_floor_us": event_floor_us,
                                "avg_launch_us_by_iteration_raw": per_iter_us,
                                "launches": prof["search_launches"],
                                "timed_frames": "one iteration launch of every timed frame (launch = frame number mod "
