@@ -136,6 +136,10 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   cells across its nearer faces that a ball of the best distance reaches (99 % of the queries
  *                                   of an ordinary frame); whatever does not fit goes to the 4-lane / whole-wave searches; same
  *                                   bits.  With it the 512-query shape may serve the first iteration as well ("narrow_from" 0)
+ *   "ball_lanes" 1 | 2 | 8 (8)      ... by 2 neighbouring lanes each where the workgroup has at most 256 misses, by 8 where it has
+ *                                   at most 64 (the groups of four points of a cell alternate between the lanes, one butterfly
+ *                                   merge of their sorted keys at the end); 1: one lane always, and workgroups with up to
+ *                                   "wave_misses" misses go straight to the whole-wave search
  *   "ball_max" n (256; <= 256)      ... if own cell + surviving cells hold at most n candidates: one lane walks them alone, and the
  *                                   longest walk of a launch sets its duration (heavier queries: the cooperative searches)
  *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last

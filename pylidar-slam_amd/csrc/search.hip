@@ -9,6 +9,8 @@
 // the query inside its cell.  Cells whose box is farther than the current best are skipped without a table probe.
 // Queries that exhaust `max_rings` fall back to an exhaustive scan, so the result is the exact NN for every input.
 // Distance ties are broken on the smaller original map index (the kd-tree's tie order is unspecified).
+#include <type_traits>
+
 #include "gn_device.h"
 #include "icp_internal.h"
 #include "search_device.h"
@@ -681,7 +683,7 @@ __device__ inline unsigned ball_key(const float4 q, float px, float py, float pz
 // dependent round trips, not its instruction count, is what a one-lane search costs: the 4-wide loop of the first build
 // took 22 trips for the 64 candidates of the slowest lane of a wave); `a[g]` = the group's first point or the pads
 template <int W>
-__device__ inline void ball_trip(const float4* const (&a)[W], float px, float py, float pz, int j, Top4& t) {
+__device__ inline void ball_trip(const float4* const (&a)[W], const int (&tag)[W], float px, float py, float pz, Top4& t) {
     float4 q[W][4];
 #pragma unroll
     for (int g = 0; g < W; ++g) {
@@ -693,15 +695,38 @@ __device__ inline void ball_trip(const float4* const (&a)[W], float px, float py
 #pragma unroll
     for (int g = 0; g < W; ++g) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t.insert(ball_key(q[g][i], px, py, pz, j + 4 * g + i));
+        for (int i = 0; i < 4; ++i) t.insert(ball_key(q[g][i], px, py, pz, tag[g] + i));
     }
+}
+
+// exchange inside a group of LPQ lanes (the lanes of one query): lane ^ X — DPP inside a quad, the LDS crossbar beyond
+template <int X>
+__device__ inline unsigned ball_xchg(unsigned v) {
+    if constexpr (X <= 2) return (unsigned)quad_xor<X>((int)v);
+    else return (unsigned)__shfl_xor((int)v, X, 64);
+}
+// the four smallest keys of this lane's and its partner's lists, sorted again (identical in the two lanes: element-wise
+// minimum of one sorted list with the other reversed = the smallest four of the union)
+template <int X>
+__device__ inline void ball_merge(Top4& t) {
+    const unsigned b0 = ball_xchg<X>(t.k0), b1 = ball_xchg<X>(t.k1), b2 = ball_xchg<X>(t.k2), b3 = ball_xchg<X>(t.k3);
+    const unsigned a0 = min(t.k0, b3), a1 = min(t.k1, b2), a2 = min(t.k2, b1), a3 = min(t.k3, b0);
+    t.k0 = t.k1 = t.k2 = t.k3 = ~0u;
+    t.insert(a0);
+    t.insert(a1);
+    t.insert(a2);
+    t.insert(a3);
 }
 
 // Returns true when the query is settled (pos0..2, L).  false: it goes to the generic paths; seed_pos >= 0 then names the
 // best point the own-cell scan found (closer than the caller's seed): their searches start from it.
-template <int W>
+// LPQ = lanes per query (1, 2, 4 or 8 neighbouring lanes; `sub` = this lane's place among them): the groups of four points
+// of every cell alternate between the lanes, each keeps its own four keys, one butterfly merge at the end — a workgroup
+// with few misses (iterations 1-6) gives each of them more lanes and a chain of dependent trips that much shorter.  All
+// lanes of a group return the same.
+template <int W, int LPQ>
 __device__ inline bool search_ball_lane(const GridView& g, float px, float py, float pz, float seed_d2, int max_cand,
-                                        int2* __restrict__ stack, int stride, int& pos0, int& pos1, int& pos2,
+                                        int2* __restrict__ stack, int stride, int sub, int& pos0, int& pos1, int& pos2,
                                         float& L, int& seed_pos) {
     seed_pos = -1;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
@@ -742,17 +767,25 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
     t.k0 = t.k1 = t.k2 = t.k3 = ~0u;
     {
         const float4* __restrict__ base = g.pts + e.start;
-        for (int j = 0; j < cum0; j += 4 * W) {
+        for (int j = 0; j < cum0; j += 4 * W * LPQ) {
             const float4* a[W];
+            int tag[W];
 #pragma unroll
-            for (int gr = 0; gr < W; ++gr) a[gr] = (j + 4 * gr < cum0) ? base + (j + 4 * gr) : pad;
-            ball_trip<W>(a, px, py, pz, j, t);
+            for (int gr = 0; gr < W; ++gr) {
+                tag[gr] = j + 4 * (gr * LPQ + sub);
+                a[gr] = tag[gr] < cum0 ? base + tag[gr] : pad;
+            }
+            ball_trip<W>(a, tag, px, py, pz, t);
         }
     }
-    if (t.k0 >= 0x7f800000u) return false;  // nothing finite in the own cell
+    unsigned kbest = t.k0;  // the best of the own cell over the lanes of the query
+    if constexpr (LPQ >= 2) kbest = min(kbest, ball_xchg<1>(kbest));
+    if constexpr (LPQ >= 4) kbest = min(kbest, ball_xchg<2>(kbest));
+    if constexpr (LPQ >= 8) kbest = min(kbest, ball_xchg<4>(kbest));
+    if (kbest >= 0x7f800000u) return false;  // nothing finite in the own cell
     // the pruning radius: the nearest so far is no farther than its key with the low bits set; the seed is a map point
     // like any other and is met in its cell
-    const float r2 = fminf(seed_d2, __uint_as_float(t.k0 | BALL_JMASK));
+    const float r2 = fminf(seed_d2, __uint_as_float(kbest | BALL_JMASK));
     const float R = sqrtf(r2) * 1.000001f + g.prune_guard;
     const bool inside = R < outer;
     const float R2 = R * R;
@@ -776,26 +809,31 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
     }
     if (!inside || total > max_cand) {
         // the generic paths take over, from the best point of the own cell if that beats the caller's seed
-        if (__uint_as_float(t.k0 & ~BALL_JMASK) < seed_d2) seed_pos = e.start + (int)(t.k0 & BALL_JMASK);
+        if (__uint_as_float(kbest & ~BALL_JMASK) < seed_d2) seed_pos = e.start + (int)(kbest & BALL_JMASK);
         return false;
     }
     {
         int s = 0, off = 0, jnext = cum0;
-        for (int j = cum0; j < total; j += 4 * W) {
+        for (int j = cum0; j < total; j += 4 * W * LPQ) {
             const float4* a[W];
+            int tag[W];
 #pragma unroll
             for (int gr = 0; gr < W; ++gr) {
-                const int jg = j + 4 * gr;
-                if (jg >= jnext && s < ns) {  // (cells start at multiples of four: a group never straddles two)
+                const int jg = j + 4 * (gr * LPQ + sub);
+                while (jg >= jnext && s < ns) {  // (cells start at multiples of four: a group never straddles two)
                     off = stack[s * stride].x;
                     ++s;
                     jnext = s < ns ? stack[s * stride].y : total;
                 }
+                tag[gr] = jg;
                 a[gr] = jg < total ? g.pts + (off + jg) : pad;
             }
-            ball_trip<W>(a, px, py, pz, j, t);
+            ball_trip<W>(a, tag, px, py, pz, t);
         }
     }
+    if constexpr (LPQ >= 2) ball_merge<1>(t);
+    if constexpr (LPQ >= 4) ball_merge<2>(t);
+    if constexpr (LPQ >= 8) ball_merge<4>(t);
     // pads behind the last map point (+inf) and NaN distances are no candidates
     if (t.k1 >= 0x7f800000u) t.k1 = ~0u;
     if (t.k2 >= 0x7f800000u) t.k2 = ~0u;
@@ -936,6 +974,7 @@ struct IterInputs {
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
     int ball;                // option "ball_search": the misses go through search_ball_lane first (one lane each)
     int ball_max;            // option "ball_max": ... those with up to that many candidates (cells rounded up to fours)
+    int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
     // an L2 of its own — with consecutive queries in consecutive workgroups every L2 has to hold the rows and points of
@@ -1233,19 +1272,27 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             atomicAdd(&g.dbg[8 + min(iter_now, 21) / 3], nmiss);  // misses by iteration: 0-2, 3-5, .., 18-20
         }
     }
-    // ---- phase B0 (round 4): every miss by ONE lane (search_ball_lane); what does not fit its pattern (own cell empty, a
-    // ball that leaves the 2x2x2 block, more than 256 candidates, four candidates within a key's resolution) goes back on
-    // the list for the generic paths below
-    // (a workgroup with a handful of misses gives each a whole wave instead — phase B1: three round trips against the ~ten
-    // of a lane on its own, and in the late launches the slowest search IS the launch)
-    if (in.ball && nmiss > in.wave_misses) {  // block-uniform
+    // ---- phase B0 (round 4): every miss by ONE lane — or, where the workgroup has few of them, by 2 or 8 neighbouring
+    // lanes (search_ball_lane); what does not fit its pattern (own cell empty, a ball that leaves the 2x2x2 block, more than
+    // 256 candidates, four candidates within a key's resolution) goes back on the list for the generic paths below
+    const int ball_lpq = !in.ball ? 0
+                         : (in.ball_lanes >= 8 && nmiss * 8 <= THREADS)   ? 8
+                         : (in.ball_lanes >= 4 && nmiss * 4 <= THREADS)   ? 4
+                         : (in.ball_lanes >= 2 && nmiss * 2 <= THREADS)   ? 2
+                         : (in.ball_lanes >= 2 || nmiss > in.wave_misses) ? 1
+                                                                          : 0;  // ("ball_lanes" 1: a handful of misses -> B1)
+    const auto ball_phase = [&](auto lpq_c) {
+        constexpr int LPQ = decltype(lpq_c)::value;
+        // (the 128-query shape is built for 64 registers: one group of four in flight; more lanes per query, fewer groups each)
+        constexpr int W = Q != THREADS ? 1 : (LPQ == 1 ? BALL_W : (LPQ == 2 ? 2 : 1));
         const int listed = nmiss;
-        const bool mine = (int)threadIdx.x < listed;
+        const int m = (int)threadIdx.x / LPQ, sub = (int)threadIdx.x % LPQ;
+        const bool mine = m < listed;  // (uniform over the LPQ lanes of a query)
         float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
         int4 ms = make_int4(0, 0, 0, 0);
         if (mine) {
-            mp = miss_p[threadIdx.x];
-            ms = miss_seed[threadIdx.x];
+            mp = miss_p[m];
+            ms = miss_seed[m];
         }
         __syncthreads();
         if (threadIdx.x == 0) nmiss = 0;
@@ -1253,30 +1300,38 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         if (mine) {
             int p0, p1, p2, sp;
             float L;
-            // (the 128-query shape is built for 64 registers: it keeps one group of four in flight)
-            if (search_ball_lane<(Q == THREADS ? BALL_W : 1)>(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), in.ball_max,
-                                         &cellstack[0][threadIdx.x], THREADS, p0, p1, p2, L, sp)) {
-                const int lq2 = __float_as_int(mp.w);
-                const float4 q = g.pts[p0];
-                const float4 nn = in.normals[p0];
-                in.nn_cache[query_of(lq2)] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
-                float row[9];
-                point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+            const bool ok = search_ball_lane<W, LPQ>(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), in.ball_max,
+                                                     &cellstack[0][threadIdx.x], THREADS, sub, p0, p1, p2, L, sp);
+            if (sub == 0) {
+                if (ok) {
+                    const int lq2 = __float_as_int(mp.w);
+                    const float4 q = g.pts[p0];
+                    const float4 nn = in.normals[p0];
+                    in.nn_cache[query_of(lq2)] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
+                    float row[9];
+                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) rowbuf[lq2][k] = row[k];
-                if (g.dbg) atomicAdd(&g.dbg[0], 1);
-            } else {
-                if (sp >= 0) {  // a better seed than the one it came with: the nearest point of its own cell (exact distance)
-                    const float4 q = g.pts[sp];
-                    const float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
-                    ms = make_int4(__float_as_int(fmaf(dz, dz, fmaf(dy, dy, dx * dx))), __float_as_int(q.w), sp, 0);
+                    for (int k = 0; k < 9; ++k) rowbuf[lq2][k] = row[k];
+                    if (g.dbg) atomicAdd(&g.dbg[0], 1);
+                } else {
+                    if (sp >= 0) {  // a better seed than the one it came with: the nearest point of its own cell (exact distance)
+                        const float4 q = g.pts[sp];
+                        const float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
+                        ms = make_int4(__float_as_int(fmaf(dz, dz, fmaf(dy, dy, dx * dx))), __float_as_int(q.w), sp, 0);
+                    }
+                    const int k = atomicAdd(&nmiss, 1);
+                    miss_p[k] = mp;
+                    miss_seed[k] = ms;
                 }
-                const int k = atomicAdd(&nmiss, 1);
-                miss_p[k] = mp;
-                miss_seed[k] = ms;
             }
         }
         __syncthreads();
+    };
+    if (nmiss > 0) {  // block-uniform
+        if (ball_lpq == 8) ball_phase(std::integral_constant<int, 8>{});
+        else if (ball_lpq == 4) ball_phase(std::integral_constant<int, 4>{});
+        else if (ball_lpq == 2) ball_phase(std::integral_constant<int, 2>{});
+        else if (ball_lpq == 1) ball_phase(std::integral_constant<int, 1>{});
     }
     // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
     // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
@@ -2704,6 +2759,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
     in.chunk_stride = narrow ? blocks : 0;  // (S = ceil(base rows / 4) = the number of 512-query workgroups)
     in.ball = ctx->ball_search;
+    in.ball_lanes = ctx->ball_lanes;
     in.ball_max = ctx->ball_max < BALL_MAX_CAND ? ctx->ball_max : BALL_MAX_CAND;
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;
