@@ -140,6 +140,9 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   at most 64 (the groups of four points of a cell alternate between the lanes, one butterfly
  *                                   merge of their sorted keys at the end); 1: one lane always, and workgroups with up to
  *                                   "wave_misses" misses go straight to the whole-wave search
+ *   "wide_until" n (3)              the launches of ICP iterations below n run 1024 threads per 512 queries (two lanes for every
+ *                                   miss even when all 512 search: the slowest wave of a launch is a lane walking the candidates
+ *                                   of a dense cell alone); same bits
  *   "ball_max" n (256; <= 256)      ... if own cell + surviving cells hold at most n candidates: one lane walks them alone, and the
  *                                   longest walk of a launch sets its duration (heavier queries: the cooperative searches)
  *   "chunked_launch" 0 | 1 (1)      icp_register_launch with threshold_delta_pose > 0 enqueues as many iterations as the last

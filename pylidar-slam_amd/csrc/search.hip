@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     const auto ball_phase = [&](auto lpq_c) {
         constexpr int LPQ = decltype(lpq_c)::value;
         // (the 128-query shape is built for 64 registers: one group of four in flight; more lanes per query, fewer groups each)
-        constexpr int W = Q != THREADS ? 1 : (LPQ == 1 ? BALL_W : (LPQ == 2 ? 2 : 1));
+        constexpr int W = Q == IT_QUERIES ? 1 : (LPQ == 1 ? BALL_W : (LPQ == 2 ? 2 : 1));
         const int listed = nmiss;
         const int m = (int)threadIdx.x / LPQ, sub = (int)threadIdx.x % LPQ;
         const bool mine = m < listed;  // (uniform over the LPQ lanes of a query)
@@ -2789,7 +2789,13 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
             in.swz_row_blocks = row_blocks;
         }
     }
-    if (narrow)
+    // the first launches of a registration (most queries search) with 1024 threads per workgroup: twice the lanes for the
+    // same 512 queries, so every miss gets two (the slowest WAVE sets these launches: a lane that walks 200 candidates of a
+    // dense cell alone); same super-rows, same bits
+    if (narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search)
+        hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS>), dim3(grid), dim3(2 * IT_THREADS), 0,
+                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (narrow)
         hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else if (ctx->iterate_dense)

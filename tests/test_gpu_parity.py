@@ -360,6 +360,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "narrow_always_nocache": {"narrow_from": 0, "nn_cache": 0},
                 "ball_no_guard": {"prune_guard": 0.0, "narrow_from": 0},
                 "ball_one_lane": {"ball_lanes": 1}, "ball_two_lanes": {"ball_lanes": 2},
+                "never_wide": {"wide_until": 0}, "always_wide": {"wide_until": 99},
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -680,6 +681,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
     variants = {"default": {}, "nocache": {"nn_cache": 0}, "no_lead_solve": {"lead_solve": 0},
                 "never_narrow": {"narrow_from": -1}, "narrow_always": {"narrow_from": 0}, "no_hoods": {"hoods": 0},
                 "hoods_4_lanes": {"hoods": 1}, "narrow_from_3": {"narrow_from": 3}, "ball_max_64": {"ball_max": 64}, "ball_one_lane": {"ball_lanes": 1}, "ball_two_lanes": {"ball_lanes": 2},
+                "never_wide": {"wide_until": 0}, "always_wide": {"wide_until": 99},
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
                 "round3": {"ball_search": 0, "narrow_from": 3}}
     results = {}
