@@ -376,9 +376,11 @@ int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launch
  * iteration (number of the registration) mod max_num_alignments — so that every frame of a run can be sampled at the cost
  * of two event records, and every iteration index is seen equally often. */
 int icp_profile_read_iterations(icp_ctx* ctx, double* ms_out, int64_t* launches_out, int32_t cap);
-/* what an event pair measures around an EMPTY kernel on the context's stream (median of `samples`, microseconds): the
- * dispatch latency behind a barrier packet that every event-timed launch contains — bench.py reports it next to the
- * raw event timing and subtracts it (plus the empty kernel's own run time) to compare with rocprofv3's durations. */
+/* what an event pair ADDS to the launch it brackets, on the context's stream (median of `samples`, microseconds): the
+ * pair is put around a kernel that spins for exactly 20 us of the device's wall clock, with a busy predecessor and a
+ * successor like a launch inside a registration has them; the result is the measured time minus those 20 us — the dispatch
+ * latency behind the barrier packet of the first event, which back-to-back launches do not pay and rocprofv3's kernel
+ * durations do not contain.  bench.py subtracts it from its live event timing of the dominant kernel. */
 int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out);
 
 #ifdef __cplusplus

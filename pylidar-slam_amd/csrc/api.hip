@@ -86,8 +86,13 @@ __global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned 
         for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // pose history, entry 0
 }
 
-// what an event pair costs: icp_profile_event_floor times this one bracketed like a real launch
-__global__ void k_event_floor() {}
+// what an event pair adds: icp_profile_event_floor brackets this kernel like a real launch — it spins for `ticks` of the
+// 100 MHz wall clock (ticks = 0: returns at once), so its run time is known from the inside
+__global__ void k_event_floor(long long ticks) {
+    if (ticks <= 0 || threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+}
 
 __global__ void k_flag_not_nan(const float* __restrict__ xyz, long long n, int skip_null, int* __restrict__ flags) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1745,14 +1750,16 @@ int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out
     std::vector<float> us;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < samples + 8; ++k) {
-        // a predecessor on the stream, as the bracketed launches of a registration have one
-        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream);
+        // a busy predecessor and a successor on the stream, as the bracketed launch of a registration has them; the kernel
+        // in the bracket spins for 20 us of the device's wall clock: what the pair measures beyond that is what it adds
+        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream, 1000ll);
         (void)hipEventRecord(a, ctx->stream);
-        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream);
+        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream, 2000ll);
         (void)hipEventRecord(b, ctx->stream);
+        hipLaunchKernelGGL(k_event_floor, dim3(1), dim3(64), 0, ctx->stream, 1000ll);
         ICP_HIP(ctx, hipEventSynchronize(b));
         float ms = 0.f;
-        if (k >= 8 && hipEventElapsedTime(&ms, a, b) == hipSuccess) us.push_back(ms * 1000.f);
+        if (k >= 8 && hipEventElapsedTime(&ms, a, b) == hipSuccess) us.push_back(ms * 1000.f - 20.0f);
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """rocprofv3 --kernel-trace CSV of a bench.py run -> profiles/rocprof_iterate_kernel.json: the average launch duration
 of the dominant kernel (k_iterate_compact, launch-weighted over its shapes), by shape and by iteration index within a
-frame, the run time of the empty calibration kernel (k_event_floor) — the figures bench.py prints next to its live
+frame, the duration rocprofv3 sees for the 20 us spin kernel of the event calibration (k_event_floor) — the figures bench.py prints next to its live
 HIP-event timing as `roofline.rocprof_*`.
 
 usage: tools/rocprof_iterate_summary.py <dir with *kernel_trace.csv> <out.json> [commit] [command]"""
@@ -31,16 +31,17 @@ def main():
     iters = 20
     frames = [d[i:i + iters] for i in range(0, len(d) - len(d) % iters, iters)]
     per_iter = [statistics.mean(fr[i] for fr in frames) for i in range(iters)] if frames else []
-    null = [dur(r) for r in rows if "k_event_floor" in r["Kernel_Name"]]
+    # the calibration kernel of icp_profile_event_floor: the bracketed launches spin for 20 us of the device clock
+    null = [dur(r) for r in rows if "k_event_floor" in r["Kernel_Name"] and dur(r) >= 15.0]
     rec = {"kernel": "k_iterate_compact", "head": head, "command": command, "launches": len(d),
            "avg_launch_us": statistics.mean(d) if d else None,
            "by_shape_us": {k: {"launches": len(v), "avg": statistics.mean(v), "min": min(v), "max": max(v)}
                            for k, v in by_shape.items()},
            "by_iteration_us": per_iter,
-           "null_kernel_us": statistics.median(null) if null else None,
+           "spin_kernel_us": statistics.median(null) if null else None,
            "source": "rocprofv3 --kernel-trace (End_Timestamp - Start_Timestamp per dispatch)"}
-    if rec["null_kernel_us"] is None:
-        rec.pop("null_kernel_us")
+    if rec["spin_kernel_us"] is None:
+        rec.pop("spin_kernel_us")
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
