@@ -838,7 +838,9 @@ int icp_last_neighbors(icp_ctx* ctx, int32_t* neighbor_index_out, float pose_out
     if (ctx->in_registration || ctx->result_pending())
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
     // the cache must describe the targets of the last registration against the grid that is still current
-    if (ctx->cache_n <= 0 || ctx->cache_n != ctx->tgt_n || ctx->cache_gen != ctx->grid_gen || !ctx->grid_valid ||
+    // (`cache_fresh`: a fused launch of the LAST registration wrote the entries — an unfused registration leaves the cache of
+    // an earlier one behind)
+    if (!ctx->cache_fresh || ctx->cache_n <= 0 || ctx->cache_n != ctx->tgt_n || ctx->cache_gen != ctx->grid_gen || !ctx->grid_valid ||
         ctx->iter_in_registration <= 0 || ctx->last_iterations <= 0 || !ctx->pose_hist)
         return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "no fused registration against the current map to read neighbours from");
     // the last iteration that ran: RegState.iter - 1 (a loop stopped early by its threshold enqueues no further search)

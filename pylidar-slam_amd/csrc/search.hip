@@ -2329,9 +2329,6 @@ __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int 
     }
     // ---- the stragglers of this workgroup, a wave per point
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifdef ICP_DEV_SKIP_STRAGGLERS  // (timing experiments only: wrong normals)
-    if (npend >= 0) return;
-#endif
     for (int k = wave; k < npend; k += NRM2_THREADS / 64) {  // wave-uniform
         const int ps = pend_s[k];
         const float4 P = g.pts[ps];

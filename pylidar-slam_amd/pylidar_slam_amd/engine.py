@@ -666,7 +666,8 @@ class IcpContext:
         return ms, n
 
     def profile_event_floor(self, samples: int = 200) -> float:
-        """Median time (us) an event pair measures around an empty kernel on this context's stream."""
+        """What an event pair adds (us, median) to the launch it brackets on this context's stream: measured around a kernel
+        that spins for exactly 20 us, minus those 20 us (`icp_profile_event_floor`)."""
         v = C.c_double(0)
         self._check(self._lib.icp_profile_event_floor(self._h, int(samples), C.byref(v)))
         return float(v.value)
