@@ -110,7 +110,7 @@ int icp_synchronize(icp_ctx* ctx);
  *   "nn_cache" 0 | 1 | 2 (2)        exact nearest-neighbour cache across ICP iterations (2: a missed entry seeds the search)
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
- *   "wave_misses" n (24)            workgroups with up to n cache misses search each of them with a whole wave
+ *   "wave_misses" n (48)            workgroups with up to n cache misses search each of them with a whole wave
  *   "wave_misses_dense" n (4)       the same threshold in the 128-queries-per-block launches of the early iterations
  *   "narrow_from" n (0; -1: never)  from ICP iteration n on the fused kernel takes 512 queries per block, one lane each,
  *                                   instead of 128 with a 4-lane group each; same bits (round 3: 3 — the one-lane ball

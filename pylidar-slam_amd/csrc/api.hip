@@ -1421,6 +1421,17 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                                     "and published after %.2f more\n",
                             it, (q[0] - first) * 0.01, (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01);
                 }
+                if (it < 4 && getenv("ICP_STATS_BLOCKS")) {  // dev: the search phase of every workgroup, by logical block
+                    fprintf(stderr, "[icp blocks] it %d:", it);
+                    for (int i = 0; i < nb; ++i) {
+                        const long long* q = t + 4 * i;
+                        if (q[0] == 0) continue;
+                        fprintf(stderr, " %d:%lld:%lld:%lld:%d:%d:%d:%d", i, ((q[1] & MASK) - (q[0] & MASK)),
+                                ((q[2] & MASK) - (q[1] & MASK)), ((q[3] & MASK) - (q[2] & MASK)), (int)(q[1] >> 48),
+                                (int)(q[2] >> 48), (int)(q[3] >> 48), (int)(q[0] >> 48));
+                    }
+                    fprintf(stderr, "\n");
+                }
                 fprintf(stderr, "[icp phases] it %2d: start skew %.2f, span %.2f us; A mean %.2f max %.2f; B mean %.2f max %.2f (that block: %d misses), blocks with B > 2 us: %d, > 5 us: %d; misses %d in %d blocks; reduce mean %.2f max %.2f\n",
                         it, (last_start - first) * 0.01, (last_end - first) * 0.01, a / seen, amax, b / seen, bmax, bmax_miss,
                         b_over2, b_over5, total_miss, with_miss, r / seen, rmax);

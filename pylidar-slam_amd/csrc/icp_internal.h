@@ -295,7 +295,7 @@ struct icp_ctx {
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
     int narrow_from = 0;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
     int wave_misses_dense = 4;         // "wave_misses_dense": the same threshold in the 128-query shape (early iterations)
-    int wave_misses = 24;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
+    int wave_misses = 48;              // "wave_misses": blocks with up to that many NN-cache misses search them a wave each
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
     int search_stats = 0;              // "search_stats": count which path resolved each query (dev)

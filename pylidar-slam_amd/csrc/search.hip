@@ -1333,6 +1333,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         else if (ball_lpq == 2) ball_phase(std::integral_constant<int, 2>{});
         else if (ball_lpq == 1) ball_phase(std::integral_constant<int, 1>{});
     }
+    if (stamps && !dbg_global && threadIdx.x == 0) {  // dev ("search_stats" 2): what the ball search left, and when
+        dbg_s[12] = nmiss;
+        dbg_s[13] = (int)(wall_clock64() - (stamps[1] & ((1ll << 48) - 1)));
+    }
     // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
     // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
     if (nmiss > 0 && nmiss <= in.wave_misses) {  // block-uniform
@@ -1407,6 +1411,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+    if (stamps && !dbg_global && threadIdx.x == 0) {  // (top bits of stamps 3 / 0: queries left to B1 / B2, ticks of B0)
+        stamps[3] |= (long long)min(dbg_s[12], 65535) << 48;
+        stamps[0] |= (long long)min(dbg_s[13], 65535) << 48;
+    }
     if (dbg_global) {  // dev: counters to the context's totals; per workgroup: beyond ring 1 | own cell empty | coarse level
         if (threadIdx.x < 16 && dbg_s[threadIdx.x]) atomicAdd(&dbg_global[threadIdx.x], dbg_s[threadIdx.x]);
         if (stamps && threadIdx.x == 0) {
