@@ -410,6 +410,192 @@ __device__ inline Near3 search_rows_group(const GridView& g, float px, float py,
     return out;
 }
 
+// ---- the generic exact search with W = 16 lanes per query (round 4, item 48) -------------------------------------
+// For the queries the ball search hands back when a workgroup has a few dozen of them: own cell empty, a ball that leaves
+// its 2x2x2 block, more candidates than `ball_max`.  A 4-lane group takes them one dependent round trip after the other
+// (seven lookups per lane and chunk, a round of loads per cell: 12-35 us per query, and the launch lasts as long as the
+// workgroup that has them); here a lane looks up at most seven cells AT ONCE (keys first, then the ranges: two round trips
+// for a whole ring 2 at W = 16), the cells found are laid end to end in the group's LDS columns and their points taken
+// 4 W per round.  Same minimum, same tie-break, same bound on every other point as the 4-lane search.
+template <int W>
+__device__ __forceinline__ void group_min_w(Best& b) {
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        const float d2 = __shfl_xor(b.d2, o, W);
+        const int idx = __shfl_xor(b.idx, o, W);
+        const int pos = __shfl_xor(b.pos, o, W);
+        float sec = fminf(b.second, __shfl_xor(b.second, o, W));
+        if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
+        if (better(d2, idx, b.d2, b.idx)) {
+            b.d2 = d2;
+            b.idx = idx;
+            b.pos = pos;
+        }
+        b.second = sec;
+    }
+}
+
+// seven cells of one lane looked up together: first-slot keys (one round trip), then the ranges of those that matched (a
+// second); a collision walks on alone.  found[k] = (start, count), (0, 0) where there is no such cell or bit k of `want` is
+// clear.  (found[k] itself holds the key while it is in flight: no registers beside the list.)
+template <typename KeyOf>
+__device__ __forceinline__ void grid_lookup7(const GridView& g, int want, KeyOf key_of, int2 (&found)[7]) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        found[k] = make_int2(0, 0);
+        if (want >> k & 1) {
+            const unsigned long long v = g.table[hash_cell(key_of(k)) & g.mask].key;
+            found[k] = make_int2((int)(unsigned int)(v & 0xffffffffull), (int)(unsigned int)(v >> 32));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        if (!(want >> k & 1)) continue;
+        const unsigned long long key = key_of(k);
+        unsigned int slot = hash_cell(key) & g.mask;
+        unsigned long long got = ((unsigned long long)(unsigned int)found[k].y << 32) | (unsigned int)found[k].x;
+        while (got != key && got != GRID_EMPTY) {
+            slot = (slot + 1) & g.mask;
+            got = g.table[slot].key;
+        }
+        found[k] = got == key ? *reinterpret_cast<const int2*>(&g.table[slot].start) : make_int2(0, 0);
+    }
+}
+
+// the cells in found[] (count > 0) of the W lanes of a group, laid end to end in the group's 7 x W LDS entries
+// (`col0` = column of the group's lane 0, rows `stride` apart) and walked together, 4 W candidates per round
+template <int W>
+__device__ __forceinline__ void walk_found_w(const GridView& lv, const int2 (&found)[7], int2* __restrict__ col0, int stride, int sub,
+                                    float px, float py, float pz, Best& b) {
+    int nl = 0, tl = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (found[k].y > 0) {
+            ++nl;
+            tl += found[k].y;
+        }
+    int cincl = nl, tincl = tl;  // inclusive prefix sums over the lanes of the group
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        const int cn = __shfl_up(cincl, o, W), tn = __shfl_up(tincl, o, W);
+        if (sub >= o) {
+            cincl += cn;
+            tincl += tn;
+        }
+    }
+    const int C = __shfl(cincl, W - 1, W), T = __shfl(tincl, W - 1, W);  // group-uniform
+    if (T == 0) return;
+    {
+        int e = cincl - nl, cum = tincl - tl;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (found[k].y > 0) {
+                col0[(e / W) * stride + (e % W)] = make_int2(found[k].x - cum, cum);  // candidate j of this cell: j + .x
+                cum += found[k].y;
+                ++e;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j0 = 0; j0 < T; j0 += 4 * W) {  // group-uniform
+        int pos[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = min(j0 + W * m + sub, T - 1);  // (a clamped tail re-reads the last candidate: harmless)
+            int e = 0;
+#pragma unroll
+            for (int s2 = 64; s2 > 0; s2 >>= 1) {  // (C <= 7 W <= 112)
+                const int t = e + s2;
+                if (t < C && col0[(t / W) * stride + (t % W)].y <= j) e = t;
+            }
+            pos[m] = j + col0[(e / W) * stride + (e % W)].x;
+        }
+        const float4 q0 = lv.pts[pos[0]], q1 = lv.pts[pos[1]], q2 = lv.pts[pos[2]], q3 = lv.pts[pos[3]];
+        consider(q0, pos[0], px, py, pz, b);
+        consider(q1, pos[1], px, py, pz, b);
+        consider(q2, pos[2], px, py, pz, b);
+        consider(q3, pos[3], px, py, pz, b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the next chunk overwrites the list)
+}
+
+// rings r_begin .. r_end of ONE level: the whole cube of radius r_begin first, then shell after shell; true as soon as the
+// best (shared by the group after every ring) is provably exact on this level
+template <int W>
+__device__ __forceinline__ bool far_rings_w(const GridView& lv, float px, float py, float pz, int sub, int r_begin, int r_end, Best& b,
+                                   int2* __restrict__ col0, int stride) {
+    const int cx = cell_coord(px, lv.inv_h), cy = cell_coord(py, lv.inv_h), cz = cell_coord(pz, lv.inv_h);
+    const float h = lv.h;
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    for (int r = r_begin; r <= r_end; ++r) {
+        const int side = 2 * r + 1, total = side * side * side;
+        for (int c0 = 0; c0 < total; c0 += 7 * W) {  // group-uniform
+            int want = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int c = c0 + sub + W * k;
+                if (c >= total) continue;
+                const int ox = c % side - r, oy = (c / side) % side - r, oz = c / (side * side) - r;
+                const int m = max(max(ox < 0 ? -ox : ox, oy < 0 ? -oy : oy), oz < 0 ? -oz : oz);
+                if (m < r && r > r_begin) continue;  // interior: visited by the previous rings
+                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+                if (gap2 > b.d2) {
+                    b.second = fminf(b.second, gap2);  // every point of a pruned cell is at least that far
+                    continue;
+                }
+                want |= 1 << k;
+            }
+            int2 found[7];
+            grid_lookup7(lv, want, [&](int k) {
+                const int c = c0 + sub + W * k;
+                return pack_cell(cx + c % side - r, cy + (c / side) % side - r, cz + c / (side * side) - r);
+            }, found);
+            walk_found_w<W>(lv, found, col0, stride, sub, px, py, pz, b);
+        }
+        group_min_w<W>(b);
+        const float bound = (float)r * h + edge;
+        if (b.d2 <= bound * bound * 0.999999f) {
+            b.second = fminf(b.second, bound * bound * 0.999999f);  // nothing outside the visited block is closer
+            return true;
+        }
+    }
+    return false;
+}
+
+// one query by its W lanes: fine rings 1 .. max_rings, the coarse level, the exhaustive scan.  The result is the same in
+// every lane of the group: nearest point (distance, original index, position) and, in .second, a lower bound on the
+// squared distance of every other map point.  `seed_*`: a map point already known (the cached neighbour), lane 0's.
+template <int W>
+__device__ __forceinline__ Best search_far_w(const GridView& g, float px, float py, float pz, int sub, int max_rings,
+                                    int2* __restrict__ col0, int stride, float seed_d2, int seed_idx, int seed_pos) {
+    Best b;
+    b.d2 = sub == 0 ? seed_d2 : INFINITY;
+    b.idx = sub == 0 ? seed_idx : 0x7fffffff;
+    b.pos = sub == 0 ? seed_pos : -1;
+    b.second = INFINITY;
+    if (far_rings_w<W>(g, px, py, pz, sub, 1, max(max_rings, 1), b, col0, stride)) return b;
+    if (g.ctable) {
+        // candidates of the coarse level carry positions of ITS point array: the winner is identified by its original index
+        const bool ok = far_rings_w<W>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b, col0, stride);
+        if (b.idx != 0x7fffffff) b.pos = g.pos_of_orig[b.idx];
+        if (ok) return b;
+    }
+    // farther than COARSE_RINGS coarse cells from every map point: every point is seen, .second = the second nearest
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    b.second = INFINITY;
+    for (int k = sub; k < g.m; k += W) consider(g.pts[k], k, px, py, pz, b);
+    group_min_w<W>(b);
+    return b;
+}
+
 __device__ inline void wave_min64(Best& b) {
 #pragma unroll
     for (int o = 1; o <= 32; o <<= 1) {
@@ -974,6 +1160,8 @@ struct IterInputs {
     int wave_misses;         // up to that many cache misses in a block: a whole wave per miss (0: never)
     int ball;                // option "ball_search": the misses go through search_ball_lane first (one lane each)
     int ball_max;            // option "ball_max": ... those with up to that many candidates (cells rounded up to fours)
+    int far_lanes;           // option "far_lanes": lanes of a handed-back query in phase BF (0: no such phase, 16)
+    int far_max;             // option "far_max": the most handed-back queries of a workgroup phase BF takes
     int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
@@ -1336,6 +1524,34 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     if (stamps && !dbg_global && threadIdx.x == 0) {  // dev ("search_stats" 2): what the ball search left, and when
         dbg_s[12] = nmiss;
         dbg_s[13] = (int)(wall_clock64() - (stamps[1] & ((1ll << 48) - 1)));
+    }
+    // ---- phase BF (round 4, item 48): a few dozen queries left — too many for a wave each, too few to fill the workgroup
+    // four lanes each: 16 lanes per query, THREADS / 16 queries at a time (search_far_w); nothing is left behind
+    if (Q != IT_QUERIES && in.far_lanes >= 16 && nmiss > THREADS / 64 && nmiss <= in.far_max) {  // block-uniform
+        constexpr int W = 16;
+        const int listed = nmiss, sub = (int)threadIdx.x % W;
+        __syncthreads();
+        if (threadIdx.x == 0) nmiss = 0;
+        for (int m = (int)threadIdx.x / W; m < listed; m += THREADS / W) {  // group-uniform
+            const float4 mp = miss_p[m];
+            const int4 ms = miss_seed[m];
+            const Best b = search_far_w<W>(g, mp.x, mp.y, mp.z, sub, in.max_rings, &cellstack[0][threadIdx.x - sub], THREADS,
+                                           __int_as_float(ms.x), ms.y, ms.z);
+            if (sub == 0) {
+                const int lq = __float_as_int(mp.w);
+                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
+                                                      -1, -1);
+                if (b.pos >= 0) {
+                    const float4 q = g.pts[b.pos];
+                    const float4 nn = in.normals[b.pos];
+                    float row[9];
+                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                }
+            }
+        }
+        __syncthreads();
     }
     // ---- phase B1: few misses (the late iterations): a whole wave per miss — the latency of the slowest search is the
     // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
@@ -2765,6 +2981,8 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.chunk_stride = narrow ? blocks : 0;  // (S = ceil(base rows / 4) = the number of 512-query workgroups)
     in.ball = ctx->ball_search;
     in.ball_lanes = ctx->ball_lanes;
+    in.far_lanes = ctx->far_lanes;
+    in.far_max = min(ctx->far_max, IT_THREADS);
     in.ball_max = ctx->ball_max < BALL_MAX_CAND ? ctx->ball_max : BALL_MAX_CAND;
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;

@@ -361,6 +361,9 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "ball_no_guard": {"prune_guard": 0.0, "narrow_from": 0},
                 "ball_one_lane": {"ball_lanes": 1}, "ball_two_lanes": {"ball_lanes": 2},
                 "never_wide": {"wide_until": 0}, "always_wide": {"wide_until": 99},
+                # what the ball search hands back: 4 lanes / a wave each (far_lanes 0), 16 lanes however many, ... and a small ball cap
+                "no_far_lanes": {"far_lanes": 0}, "far_lanes_two_passes": {"far_max": 512},
+                "far_lanes_small_balls": {"far_max": 512, "ball_max": 16},
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -682,6 +685,8 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
                 "never_narrow": {"narrow_from": -1}, "narrow_always": {"narrow_from": 0}, "no_hoods": {"hoods": 0},
                 "hoods_4_lanes": {"hoods": 1}, "narrow_from_3": {"narrow_from": 3}, "ball_max_64": {"ball_max": 64}, "ball_one_lane": {"ball_lanes": 1}, "ball_two_lanes": {"ball_lanes": 2},
                 "never_wide": {"wide_until": 0}, "always_wide": {"wide_until": 99},
+                "no_far_lanes": {"far_lanes": 0}, "far_lanes_many": {"far_max": 512},
+                "far_lanes_small_balls": {"far_max": 512, "ball_max": 32},
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
                 "round3": {"ball_search": 0, "narrow_from": 3}}
     results = {}
