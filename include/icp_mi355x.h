@@ -141,11 +141,12 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   merge of their sorted keys at the end); 1: one lane always, and workgroups with up to
  *                                   "wave_misses" misses go straight to the whole-wave search
  *   "far_lanes" 0 | 16 (16)         what the ball search hands back (own cell empty, a ball that leaves its block, more than
- *                                   "ball_max" candidates) where a workgroup has more of them than it has waves and at most
+ *                                   "ball_max" candidates) where a workgroup has more than "far_min" of them and at most
  *                                   "far_max": every such query searched by 16 lanes, THREADS / 16 queries at a time — seven
  *                                   cell lookups per lane in flight together, the points of the cells found 64 per round;
  *                                   0: the whole-wave / 4-lane searches take them; same bits
  *   "far_max" n (128)               see "far_lanes"
+ *   "far_min" n (16)                see "far_lanes": more than n handed-back queries (up to n: a whole wave each)
  *   "wide_until" n (3)              the launches of ICP iterations below n run 1024 threads per 512 queries (two lanes for every
  *                                   miss even when all 512 search: the slowest wave of a launch is a lane walking the candidates
  *                                   of a dense cell alone); same bits

@@ -375,6 +375,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "ball_search") ctx->ball_search = value != 0.0 ? 1 : 0;
     else if (k == "wide_until") ctx->wide_until = iv < 0 ? 0 : (int)iv;
     else if (k == "far_lanes") ctx->far_lanes = iv >= 16 ? 16 : 0;
+    else if (k == "far_min") ctx->far_min = iv < 0 ? 0 : (int)iv;
     else if (k == "far_max") ctx->far_max = iv < 0 ? 0 : (iv > 512 ? 512 : (int)iv);
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);

@@ -331,6 +331,7 @@ struct icp_ctx {
     int ball_search = 1;               // "ball_search": NN-cache misses of the fused kernel searched by one lane each first (search_ball_lane)
     int wide_until = 3;                // "wide_until": fused launches of iterations below that run with 1024 threads per 512 queries
     int far_lanes = 16;                // "far_lanes": 16 lanes for a query the ball search hands back, where a workgroup has a few dozen (0 | 16)
+    int far_min = 16;                  // "far_min": ... more than that many (fewer: a wave each)
     int far_max = 128;                 // "far_max": ... up to that many of them (THREADS / 16 at a time)
     int ball_lanes = 8;                // "ball_lanes": a miss of a workgroup with few of them gets 2 or 8 lanes of the ball search (IterInputs)
     int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)

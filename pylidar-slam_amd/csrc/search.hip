@@ -1162,6 +1162,7 @@ struct IterInputs {
     int ball_max;            // option "ball_max": ... those with up to that many candidates (cells rounded up to fours)
     int far_lanes;           // option "far_lanes": lanes of a handed-back query in phase BF (0: no such phase, 16)
     int far_max;             // option "far_max": the most handed-back queries of a workgroup phase BF takes
+    int far_min;             // option "far_min": ... and it takes more than that many (fewer: a wave each, phase B1)
     int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
@@ -1527,7 +1528,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     // ---- phase BF (round 4, item 48): a few dozen queries left — too many for a wave each, too few to fill the workgroup
     // four lanes each: 16 lanes per query, THREADS / 16 queries at a time (search_far_w); nothing is left behind
-    if (Q != IT_QUERIES && in.far_lanes >= 16 && nmiss > THREADS / 64 && nmiss <= in.far_max) {  // block-uniform
+    if (Q != IT_QUERIES && in.far_lanes >= 16 && nmiss > in.far_min && nmiss <= in.far_max) {  // block-uniform
         constexpr int W = 16;
         const int listed = nmiss, sub = (int)threadIdx.x % W;
         __syncthreads();
@@ -2983,6 +2984,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     in.ball_lanes = ctx->ball_lanes;
     in.far_lanes = ctx->far_lanes;
     in.far_max = min(ctx->far_max, IT_THREADS);
+    in.far_min = ctx->far_min;
     in.ball_max = ctx->ball_max < BALL_MAX_CAND ? ctx->ball_max : BALL_MAX_CAND;
     in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
     in.swz_bpr_shift = -1;

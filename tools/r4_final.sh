@@ -36,3 +36,5 @@ PY
 timeout 600 python bench.py --workload c4 --steps 6 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 rc=$?"; tail -c 500 $OUT/bench_c4.json; echo
 bash tools/r4_legs_prof.sh $TAG/legs > $OUT/legs.txt 2>&1; head -60 $OUT/legs.txt
 bash tools/pmc_by_iter.sh $TAG > /dev/null 2>&1; head -30 $OUT/pmc_by_iter.txt | cut -c1-200
+# the early launches workgroup by workgroup: phase stamps + what the ball search leaves
+ICP_STATS_BLOCKS=1 timeout 100 python bench.py --steps 14 --warmup 6 --no-cpu-baseline --loop-steps 0 --no-profile --plugin-steps 0 --odometry-loop 0 --throughput-leg 0 --option search_stats=2 > $OUT/blocks.json 2> $OUT/blocks.err; grep -c "icp blocks" $OUT/blocks.err
