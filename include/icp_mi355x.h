@@ -233,6 +233,15 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem);        /* s
  * rel_pose = NULL: an insertion / eviction must not follow a registration whose status the host has not seen. */
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
                    int64_t* inserted_out);
+/* The same update in two steps, for a caller that knows BEFORE a registration which cloud it will insert after it
+ * (ICPFrameToModel.do_process_next_frame inserts the frame it has just registered, icp_odometry.py:229-231,360-376):
+ * icp_map_stage_cloud flags and compacts the valid rows (row_mode as above) into the context and sends their count to the
+ * host without waiting for it; icp_map_update_staged then performs update() :302-362 with those rows — same map, same
+ * *inserted_out — and has nothing to wait for when anything that synchronises (icp_register_end) ran in between: one host
+ * round trip per frame less than icp_map_update with a cloud.  A staged cloud is consumed by the first
+ * icp_map_update_staged and replaced by the next icp_map_stage_cloud; rel_pose = NULL as for icp_map_update. */
+int icp_map_stage_cloud(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int row_mode);
+int icp_map_update_staged(icp_ctx* ctx, const float rel_pose[16], int64_t* inserted_out);
 /* update(new_vertex_map=...) :320-324 — appends the pixels of a [3,H,W] vertex map with norm > 0.01 */
 int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,
                               int64_t* inserted_out);

@@ -319,6 +319,9 @@ void icp_destroy(icp_ctx* ctx) {
         if (r.event) (void)hipEventDestroy(r.event);
     }
     if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
+    ctx->staged_xyz.release();
+    if (ctx->staged_count_host) (void)hipHostFree(ctx->staged_count_host);
+    if (ctx->staged_event) (void)hipEventDestroy(ctx->staged_event);
     exchange_release(ctx);
     ctx->x_seq.release();
     for (auto& e : ctx->prof.pool) {
@@ -658,8 +661,10 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
 }
 
 // shared tail of the two update flavours: `new_dev` [n,3] device rows with flags, or nothing
+// `known_count` >= 0: `new_dev` holds exactly that many valid rows, already in order (a staged cloud) — copied, not compacted,
+// and nothing is read back
 static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
-                           int64_t n, bool has_cloud, int64_t* inserted_out) {
+                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count = -1) {
     int rc = ensure_state(ctx);
     if (rc) return rc;
     ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
@@ -670,7 +675,11 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         DeviceBuffer& dst = ctx->map_xyz[ctx->map_cur];
         ICP_HIP(ctx, dst.reserve((size_t)(n > 0 ? n : 1) * 12));
         int* count_dev = ctx->counter.as<int>();
-        if (has_cloud) {
+        if (has_cloud && known_count >= 0) {
+            if (known_count > 0)
+                ICP_HIP(ctx, hipMemcpyAsync(dst.ptr, new_dev, (size_t)known_count * 12, hipMemcpyDeviceToDevice, ctx->stream));
+            inserted = known_count;
+        } else if (has_cloud) {
             if ((rc = compact_rows(ctx, new_dev, flags_dev, n, 3, dst.as<float>(), count_dev))) return rc;
             int c = 0;
             ICP_HIP(ctx, hipMemcpyAsync(&c, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -702,7 +711,13 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
             if (rel_pose) memcpy(job.rel.m, rel_pose, sizeof(job.rel.m));
             job.st = rel_pose ? (const RegState*)nullptr : (const RegState*)reg_state(ctx);
         }
-        if (has_cloud) {
+        if (has_cloud && known_count >= 0) {
+            if (known_count > 0)
+                ICP_HIP(ctx, hipMemcpyAsync(dst.as<float>() + 3 * keep, new_dev, (size_t)known_count * 12,
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+            inserted = known_count;
+            ctx->cloud_sizes.push_back(inserted);
+        } else if (has_cloud) {
             int* count_dev = ctx->counter.as<int>();
             if ((rc = compact_rows(ctx, new_dev, flags_dev, n, 3, dst.as<float>() + 3 * keep, count_dev))) return rc;
             int c = 0;
@@ -755,6 +770,54 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
                                ctx->flags.as<int>());
     }
     return map_update_impl(ctx, rel_pose, (const float*)in, ctx->flags.as<int>(), n, has_cloud, inserted_out);
+}
+
+int icp_map_stage_cloud(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int row_mode) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    ctx->staged_rows = -1;
+    if (!ctx->staged_count_host) ICP_HIP(ctx, hipHostMalloc((void**)&ctx->staged_count_host, sizeof(int), hipHostMallocDefault));
+    if (!ctx->staged_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->staged_event, hipEventDisableTiming));
+    *ctx->staged_count_host = 0;
+    if (n > 0) {
+        const void* in = nullptr;
+        if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in))) return rc;
+        ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
+        ICP_HIP(ctx, ctx->staged_xyz.reserve((size_t)n * 12));
+        hipLaunchKernelGGL(k_flag_not_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)in,
+                           (long long)n, row_mode == ICP_TARGETS_SKIP_NULL ? 1 : 0, ctx->flags.as<int>());
+        int* count_dev = ctx->counter.as<int>();
+        if ((rc = compact_rows(ctx, (const float*)in, ctx->flags.as<int>(), n, 3, ctx->staged_xyz.as<float>(), count_dev)))
+            return rc;
+        // (the flags, the scan space and the counter are the context's scratch: whatever is enqueued next may reuse them —
+        // behind this copy, in stream order)
+        ICP_HIP(ctx, hipMemcpyAsync(ctx->staged_count_host, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
+    }
+    ICP_HIP(ctx, hipEventRecord(ctx->staged_event, ctx->stream));
+    ctx->staged_rows = n;
+    return ICP_OK;
+}
+
+int icp_map_update_staged(icp_ctx* ctx, const float rel_pose[16], int64_t* inserted_out) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->staged_rows < 0) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "no staged cloud (icp_map_stage_cloud)");
+    if (!rel_pose && !ctx->have_device_pose)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL needs a previous registration on this context");
+    if (!rel_pose && ctx->result_pending())
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL with a new cloud: collect the pending registration "
+                                                   "(icp_register_end) first");
+    {   // (as icp_map_update: iterations a chunked launch holds back go first)
+        const int rc0 = continue_launch(ctx, -1);
+        if (rc0) return rc0;
+    }
+    ICP_HIP(ctx, hipEventSynchronize(ctx->staged_event));  // long past when a registration was collected in between
+    const int64_t count = *ctx->staged_count_host;
+    ctx->staged_rows = -1;  // consumed
+    return map_update_impl(ctx, rel_pose, ctx->staged_xyz.as<float>(), nullptr, count, true, inserted_out, count);
 }
 
 int icp_compact_targets(icp_ctx* ctx, const float* xyz, int64_t n, int target_mode, float* out, int64_t cap) {

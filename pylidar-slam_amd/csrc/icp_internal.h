@@ -300,6 +300,12 @@ struct icp_ctx {
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
     int search_stats = 0;              // "search_stats": count which path resolved each query (dev)
     icp::DeviceBuffer dbg_counts;
+    // a cloud staged for the next map update (icp_map_stage_cloud): its valid rows, in order; their count travels to the host
+    // behind the compaction, beside whatever is enqueued after it — the update then needs no synchronisation of its own
+    icp::DeviceBuffer staged_xyz;
+    int* staged_count_host = nullptr;  // pinned
+    hipEvent_t staged_event = nullptr;
+    int64_t staged_rows = -1;          // rows handed to the staging call (-1: nothing staged)
     icp::DeviceBuffer tgt4;            // float4[N]: the targets the kernels read
     // what nn_cache currently describes: `cache_n` targets against the grid of generation `cache_gen` (map of cache_m points)
     int64_t cache_n = 0, cache_m = 0;

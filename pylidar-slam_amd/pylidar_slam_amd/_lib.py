@@ -87,6 +87,8 @@ EXPORTED_SYMBOLS = {
     "icp_map_init": (_INT, [_P]),
     "icp_map_set": (_INT, [_P, _P, _I64, _INT]),
     "icp_map_update": (_INT, [_P, _P, _P, _I64, _INT, _INT, C.POINTER(_I64)]),
+    "icp_map_stage_cloud": (_INT, [_P, _P, _I64, _INT, _INT]),
+    "icp_map_update_staged": (_INT, [_P, _P, C.POINTER(_I64)]),
     "icp_map_update_vertex_map": (_INT, [_P, _P, _P, _INT, C.POINTER(_I64)]),
     "icp_map_size": (_I64, [_P]),
     "icp_map_num_clouds": (_INT, [_P]),

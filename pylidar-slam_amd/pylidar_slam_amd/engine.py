@@ -301,6 +301,22 @@ class IcpContext:
                                              TARGETS_SKIP_NULL if skip_null else TARGETS_ALL, C.byref(ins)))
         return int(ins.value)
 
+    def map_stage_cloud(self, new_points: Array, skip_null: bool = False) -> None:
+        """Prepares the cloud a later `map_update_staged` inserts (icp_map_stage_cloud): its valid rows are compacted on the
+        device and their count is sent to the host without waiting — called before a registration, the update after it
+        needs no host round trip of its own."""
+        self._bind(new_points)
+        p, mem, keep = _ptr_mem(new_points)
+        n = int(keep.shape[0])
+        self._check(self._lib.icp_map_stage_cloud(self._h, p if n else None, n, mem,
+                                                  TARGETS_SKIP_NULL if skip_null else TARGETS_ALL))
+
+    def map_update_staged(self, rel_pose) -> int:
+        ins = C.c_int64(0)
+        self._check(self._lib.icp_map_update_staged(self._h, _pose16(rel_pose) if rel_pose is not None else None,
+                                                    C.byref(ins)))
+        return int(ins.value)
+
     def map_update_vertex_map(self, rel_pose, vmap: Array) -> int:
         self._bind(vmap)
         p, mem, keep = _ptr_mem(vmap)

@@ -426,7 +426,9 @@ class HashGridLocalMap:
             relative_pose = relative_pose[0].cpu().numpy()
         rel = np.asarray(relative_pose, dtype=np.float32)
         assert_debug(rel.shape == (4, 4))
-        if new_pc_data is not None:
+        if kwargs.get("staged", False):  # the cloud handed to stage() before the registration
+            self._last_count = self.ctx.map_update_staged(rel)
+        elif new_pc_data is not None:
             pc = new_pc_data.reshape(-1, 3)
             self._last_count = self.ctx.map_update(rel, pc, skip_null=bool(kwargs.get("skip_null", False)))
         elif new_vertex_map is not None:
@@ -435,6 +437,12 @@ class HashGridLocalMap:
             self._last_count = self.ctx.map_update_vertex_map(rel, vm[0])
         else:
             self.ctx.map_update(rel, None)
+
+    def stage(self, new_pc_data, skip_null: bool = False):
+        """The cloud the next `update(..., staged=True)` inserts, handed over before the registration it follows: its rows
+        are compacted and counted on the device while the host goes on (icp_map_stage_cloud) — same map as
+        `update(pose, new_pc_data=...)`, one host synchronisation per frame less."""
+        self.ctx.map_stage_cloud(new_pc_data.reshape(-1, 3), skip_null=skip_null)
 
     def nearest_neighbor_search(self, target_points, with_normals: bool = True, with_new_target_points: bool = True,
                                 **kwargs) -> NeighborhoodResult:  # :372-395
@@ -749,6 +757,7 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self._tgt_vmap = None
         self._tgt_pc = None
         self._host_rows = None
+        self._staged = False
         if isinstance(data, np.ndarray):
             assert_debug(data.ndim == 2 and data.shape[1] == 3, f"expected [N, 3], got {data.shape}")
             self._sample_pointcloud = True  # sticky (:330)
@@ -822,6 +831,11 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             params, pose, _ = self.register_new_frame(targets, initial_estimate, skip_null=skip_null)
             tgt_np_pc = self._rows_to_host(rows_ready) if want_rows else data_dict["distorted"]
         else:
+            # the frame goes into the map right after its registration (:229-231): its valid rows are compacted and counted
+            # NOW, in front of the registration, so that the update finds the count on the host (one synchronisation less)
+            self._staged = hasattr(self.local_map, "stage") and self._tgt_pc.is_cuda
+            if self._staged:
+                self.local_map.stage(self._tgt_pc, skip_null=self._pc_is_pixels)
             self.ctx.register_launch(targets, initial_estimate, skip_null=skip_null)
             tgt_np_pc = self._rows_to_host(rows_ready) if want_rows else data_dict["distorted"]  # GPU busy meanwhile
             res = self.ctx.register_end()  # raises before the map is touched (:286)
@@ -922,7 +936,10 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
                 self._delta_since_map_update = np.eye(4, dtype=np.float32)
                 return
             # vertex-map input: `_tgt_pc` = the non-null pixels (:342-344) -> null rows are dropped inside the library
-            self.local_map.update(new_rpose, new_pc_data=self._tgt_pc, skip_null=self._pc_is_pixels)
+            if getattr(self, "_staged", False):
+                self.local_map.update(new_rpose, staged=True)
+            else:
+                self.local_map.update(new_rpose, new_pc_data=self._tgt_pc, skip_null=self._pc_is_pixels)
             self._delta_since_map_update = np.eye(4, dtype=np.float32)
         else:
             self.local_map.update(new_rpose)

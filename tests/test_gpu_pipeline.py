@@ -429,3 +429,57 @@ def test_calls_between_a_chunked_launch_and_its_end_follow_the_whole_registratio
         assert np.array_equal(a.pose, b.pose) and np.array_equal(a.losses, b.losses) and np.array_equal(a.dx, b.dx)
     np.testing.assert_array_equal(runs[1][1], runs[0][1])
 
+
+
+@pytest.mark.gpu
+def test_staged_map_update_equals_the_direct_update(torch_cuda):
+    """`icp_map_stage_cloud` before a registration + `icp_map_update_staged` after it = `icp_map_update` with the cloud
+    (update() of local_map.py:302-362: rows with a NaN dropped, null rows too under skip_null, order kept, the oldest
+    cloud evicted beyond the window) — same counts, same map, same registration afterwards, on device and host input; a
+    staged cloud is consumed once; staging replaces what was staged."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, _ = make_sequence(cfg, 6)
+    rng = np.random.default_rng(5)
+    clouds = []
+    for s in scans:
+        c = s.copy()
+        c[rng.integers(0, len(c), 200)] = np.nan      # rows with a NaN
+        c[rng.integers(0, len(c), 300)] = 0.0         # null rows
+        clouds.append(c)
+    shift = np.eye(4, dtype=np.float32)
+    shift[:3, 3] = (0.2, -0.1, 0.02)
+    kw = dict(height=32, width=1024, max_num_alignments=8, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3,
+              local_map_size=3)
+    runs = {}
+    for staged in (False, True):
+        for on_device in (True, False):
+            ctx = IcpContext(**kw)
+            ctx.map_init()
+            counts, results = [], []
+            for i, c in enumerate(clouds):
+                rows = torch.from_numpy(c).cuda() if on_device else c
+                skip_null = i % 2 == 0
+                if staged:
+                    ctx.map_stage_cloud(rows, skip_null=skip_null)
+                    if i == 2:  # staging again replaces the staged cloud
+                        ctx.map_stage_cloud(rows, skip_null=skip_null)
+                if i > 0:
+                    results.append(ctx.register(torch.from_numpy(scans[i]).cuda()))
+                counts.append(ctx.map_update_staged(shift) if staged else ctx.map_update(shift, rows, skip_null=skip_null))
+            if staged:
+                with pytest.raises(AssertionError):  # (ICP_ERR_INVALID_ARGUMENT)
+                    ctx.map_update_staged(shift)  # consumed
+            runs[(staged, on_device)] = (counts, ctx.map_points(), ctx.map_num_clouds(), results)
+            ctx.close()
+    ref = runs[(False, True)]
+    assert ref[2] == 3 and len(ref[1]) == sum(ref[0][-3:])
+    for key, (counts, pts, nclouds, results) in runs.items():
+        assert counts == ref[0], key
+        assert nclouds == ref[2], key
+        np.testing.assert_array_equal(pts, ref[1], err_msg=str(key))
+        for a, b in zip(results, ref[3]):
+            np.testing.assert_array_equal(a.pose, b.pose, err_msg=str(key))
+            np.testing.assert_array_equal(a.losses, b.losses, err_msg=str(key))
