@@ -837,7 +837,10 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         else:
             # the frame goes into the map right after its registration (:229-231): its valid rows are compacted and counted
             # NOW, in front of the registration, so that the update finds the count on the host (one synchronisation less)
-            self._staged = hasattr(self.local_map, "stage") and self._tgt_pc.is_cuda and \
+            # (rows in host memory would make the staging call wait for their upload: no round trip saved — except under
+            # the CPU stand-in of tests/, which exercises this flow without a GPU)
+            self._staged = hasattr(self.local_map, "stage") and \
+                (self._tgt_pc.is_cuda or self.device.type != "cuda") and \
                 int(self._tgt_pc.shape[0]) <= int(_get(self.config, "stage_insert_max_rows", 32768))
             if self._staged:
                 self.local_map.stage(self._tgt_pc, skip_null=self._pc_is_pixels)

@@ -66,6 +66,20 @@ class OracleContext:
         self.lm.update(np.asarray(rel_pose, np.float32), pts)
         return 0 if pts is None else int(pts.shape[0])
 
+    # the two-step update around a registration (icp_map_stage_cloud / icp_map_update_staged): the staged rows are kept —
+    # a copy: the caller may reuse its buffer — until an update consumes them or the next staging replaces them
+    def map_stage_cloud(self, new_points, skip_null=False):
+        self.calls.append("stage")
+        pts = self._np(new_points).reshape(-1, 3).copy()
+        self._staged = pts[np.abs(pts).max(axis=1) > 0] if skip_null else pts
+
+    def map_update_staged(self, rel_pose):
+        assert getattr(self, "_staged", None) is not None, "no staged cloud (icp_map_stage_cloud)"
+        pts, self._staged = self._staged, None
+        self.calls.append("insert_staged")
+        self.lm.update(np.asarray(rel_pose, np.float32), pts)
+        return int(pts.shape[0])
+
     def map_update_vertex_map(self, rel_pose, vmap):
         self.calls.append("insert_vmap")
         self.lm.update(np.asarray(rel_pose, np.float32), None, self._np(vmap))

@@ -44,8 +44,10 @@ def test_frame_loop_host_logic_matches_reference(monkeypatch, golden_c1, c1_scan
     np.testing.assert_allclose(np.stack(odo.absolute_poses), g[f"{run}_abs"], atol=1e-4)
     # the first frame goes in as a vertex map, 0.4 m per frame is above the 0.1 m key-frame threshold: every later
     # frame is inserted as a cloud; the map ends with the reference's size
+    # (frames of up to `stage_insert_max_rows` rows are staged for the map in front of their registration and inserted
+    # from there: icp_map_stage_cloud / icp_map_update_staged)
     calls = odo.ctx.calls
-    assert calls[0] == "insert_vmap" and set(calls[1:]) == {"insert"} and len(calls) == len(scans)
+    assert calls[0] == "insert_vmap" and calls[1:] == ["stage", "insert_staged"] * (len(scans) - 1)
     assert odo.ctx.lm.local_map.shape[0] == int(g[f"{run}_map_size"])
     assert len(odo.elapsed) == len(scans) and odo.get_elapsed() > 0
 
@@ -65,7 +67,19 @@ def test_small_motion_is_a_pose_only_update(monkeypatch):
     for k, p in enumerate(poses):
         odo.process_next_frame({"numpy_pc": render_scan(sc, p, k, dirs)})
     # frames 1, 2: 4 and 8 cm since the last insertion -> pose-only; frame 3: 12 cm -> insertion; frame 4: 4 cm again
-    assert odo.ctx.calls == ["insert_vmap", "move", "move", "insert", "move"]
+    # (every frame is staged in front of its registration; a pose-only update leaves the staged rows unused, the next
+    # staging replaces them)
+    assert odo.ctx.calls == ["insert_vmap", "stage", "move", "stage", "move", "stage", "insert_staged", "stage", "move"]
+    # frames above the row limit are inserted the classic way
+    cfg2 = odo_mod.MI355XICPConfig(max_num_alignments=10, threshold_delta_pose=1e-4, data_key="numpy_pc",
+                                   stage_insert_max_rows=100)
+    odo2 = odo_mod.MI355XICPFrameToModel(cfg2, projector=odo_mod.SphericalProjector(16, 256), device=torch.device("cpu"))
+    odo2.init()
+    for k, p in enumerate(poses):
+        odo2.process_next_frame({"numpy_pc": render_scan(sc, p, k, dirs)})
+    assert odo2.ctx.calls == ["insert_vmap", "move", "move", "insert", "move"]
+    np.testing.assert_array_equal(odo2.get_relative_poses(), odo.get_relative_poses())
+    np.testing.assert_array_equal(odo2.ctx.lm.local_map, odo.ctx.lm.local_map)
     with pytest.raises(AssertionError):
         odo.process_next_frame({"wrong_key": None})
 
