@@ -106,7 +106,8 @@ const char* icp_version(void);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
 int icp_set_stream(icp_ctx* ctx, void* hip_stream);
 int icp_synchronize(icp_ctx* ctx);
-/* MI355X-side tuning options by name (no reference counterpart; none of them changes a result, only the schedule):
+/* MI355X-side tuning options by name (no reference counterpart; none of them changes a result, only the schedule — with ONE
+ * exception, "carry_normals", which changes results by float32 rounding and says so):
  *   "nn_cache" 0 | 1 | 2 (2)        exact nearest-neighbour cache across ICP iterations (2: a missed entry seeds the search)
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
@@ -117,7 +118,7 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   search of round 4 suits the 512-query shape from the first iteration on)
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
- *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (16), "search_stats" 0 | 1 | 2 (0)
+ *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (16), "search_stats" 0 | 1 | 2 | 3 | 4 (0; dev: 3 / 4 = 1 / 2 + a per-workgroup dump on stderr)
  *   "scan_poll_limit" n (2^20)      grid build: polls of a predecessor tile's descriptor before a tile of the one-launch table
  *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
  *   "prune_guard" m (0.002)         searches scan neighbour cells whose box is within m metres of the best distance instead of
@@ -136,8 +137,8 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   cells across its nearer faces that a ball of the best distance reaches (99 % of the queries
  *                                   of an ordinary frame); whatever does not fit goes to the 4-lane / whole-wave searches; same
  *                                   bits.  With it the 512-query shape may serve the first iteration as well ("narrow_from" 0)
- *   "ball_lanes" 1 | 2 | 8 (8)      ... by 2 neighbouring lanes each where the workgroup has at most 256 misses, by 8 where it has
- *                                   at most 64 (the groups of four points of a cell alternate between the lanes, one butterfly
+ *   "ball_lanes" 1 | 2 | 4 | 8 (8)  ... by 2 neighbouring lanes each where the workgroup has at most 256 misses, by 4 where it has
+ *                                   at most 128, by 8 where it has at most 64 (the groups of four points of a cell alternate between the lanes, one butterfly
  *                                   merge of their sorted keys at the end); 1: one lane always, and workgroups with up to
  *                                   "wave_misses" misses go straight to the whole-wave search
  *   "far_lanes" 0 | 16 (16)         what the ball search hands back (own cell empty, a ball that leaves its block, more than
@@ -163,6 +164,12 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   kNN normals stream ring 1 from it — 2: one lane per map point, sorted 32-bit keys, the
  *                                   uncertified points finished by a launch of their own, one wave each; 1: four lanes per point
  *                                   (round 3); 0: no lists, the 27 cells of the neighbour row are walked
+ *   "carry_normals" 0 | 1 (1)       a POSE-ONLY map update (icp_map_update without a cloud and without an eviction: every map
+ *                                   point keeps its neighbours) rotates the normals the grid already holds with the points
+ *                                   (n' = R^-1 n) instead of clearing them; the reference clears its cache on every build_model
+ *                                   (local_map.py:365-369) and re-estimates on first touch — the same vectors up to the float32
+ *                                   rounding of the re-expressed points (poses agree to ~1e-7 m).  0: the reference's schedule,
+ *                                   every rebuild clears the cache.  Updates that insert or evict always clear it
  *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
  *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
  *   "profile_rotate" 0 | 1 (0)      icp_profile_enable brackets one iteration launch per registration (see icp_profile_read_iterations)
@@ -330,7 +337,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
  * the registration only.  With threshold_delta_pose > 0 only a first chunk of iterations is on the stream when this
  * returns ("chunked_launch": as many as the last registration ran, plus one; launches behind an early stop are
  * device-side no-ops); icp_register_end enqueues more while the loop is still running.  Every entry point that changes
- * what those held-back iterations would see — any icp_map_update / icp_map_set / icp_map_init / icp_map_update_vertex_map,
+ * what those held-back iterations would see — any icp_map_update / icp_map_update_staged / icp_map_stage_cloud / icp_map_set / icp_map_init / icp_map_update_vertex_map,
  * icp_set_option / icp_set_cost / icp_set_alignment / icp_set_stream, icp_map_normals_owned / _install, icp_pmap_register,
  * the next icp_register_launch — first enqueues ALL of them, so the stream order is the call order, as if every iteration
  * had been enqueued here. */

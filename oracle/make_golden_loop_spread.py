@@ -1,0 +1,123 @@
+"""How reproducible is the REFERENCE's own published-configuration loop under changes of its float evaluation only?
+TEST INFRASTRUCTURE, build container only:
+
+    python oracle/make_golden_loop_spread.py        # writes tests/golden/loop_spread.npz (four runs of the loop: minutes)
+
+`tests/golden/loop_reference.npz` (oracle/make_golden_loop.py) pins the published configuration — CV + kd-tree F2M,
+neighborhood sigma 0.2, at most 20 iterations with the LIVE stop `delta_pose.norm() < 1e-4`
+(/root/reference/slam/odometry/icp_odometry.py:292) — on 36 synthetic frames.  A stop decided within float32 noise of the
+threshold applies, or does not apply, one more step of up to the threshold's size; the frame's pose, and through the map and
+the constant-velocity guess its successors, move with it.  How far is MEASURED here on the reference itself: its unmodified
+`SLAM` loop (through oracle/shims, as make_golden_loop.py runs it) is repeated under perturbations that are mathematical
+no-ops:
+
+    base      the run of make_golden_loop.py again (must reproduce loop_reference.npz bit for bit)
+    scalar    ATEN_CPU_CAPABILITY=default: ATen's scalar libm kernels instead of the vectorised Sleef ones (sin / cos /
+              atan2 of the pose algebra differ in the last bit; oracle/make_golden_projection_spread.py uses the same switch)
+    gn8       eight intra-op threads inside `GaussNewton.compute` only (another summation order of the float32 J^T J;
+              everything else stays on one thread: the reference's z-buffer races under intra-op parallelism)
+    reversed  the sampled points of every frame handed to the odometry in reverse row order (the same set: another
+              summation order of every float32 reduction over the points, another insertion order in the map)
+
+Stored per run: relative poses, iteration counts; per frame: the largest translation / rotation difference between any
+perturbed run and `base` (`spread_t`, `spread_r`), whether any run stopped after another number of iterations there
+(`flipped`), and `behind_flip` (a flip happened at or before that frame in some run).
+`tests/test_gpu_loop.py::test_published_configuration_loop_matches_the_reference_run` bounds every frame of the HIP loop by
+max(1e-4, 1.5 x that frame's recorded spread of the reference) where the reference itself flips, and by
+max(1e-4, the largest spread the reference shows behind any flip) at a frame where only the HIP loop's iteration count
+differs — instead of the flat 2e-4 of round 4, which was argued, not measured.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "loop_spread.npz")
+
+CHILD = r'''
+import sys, os, logging
+ROOT = %(root)r
+sys.path[:0] = [os.path.join(ROOT, "oracle", "shims"), "/root/reference", os.path.join(ROOT, "pylidar-slam_amd"),
+                os.path.join(ROOT, "oracle")]
+logging.disable(logging.WARNING)
+import numpy as np, torch
+torch.set_num_threads(1)
+mode, out_path = sys.argv[1], sys.argv[2]
+import make_golden_loop as G
+import slam.preprocessing as pp
+from slam.common.pointcloud import voxelise
+import slam.common.optimization as opt
+pp.voxelise = lambda pc, a, b, c: voxelise(pc.astype(np.float64), a, b, c)  # (as make_golden_loop.main)
+if mode == "gn8":
+    inner = opt.GaussNewton.compute
+    def compute(self, *a, **k):
+        torch.set_num_threads(8)
+        try:
+            return inner(self, *a, **k)
+        finally:
+            torch.set_num_threads(1)
+    opt.GaussNewton.compute = compute
+if mode == "reversed":
+    # the to_tensor filter hands `sample_points` to the odometry as `input_data`: reverse the rows behind the grid sample
+    inner_f = pp.GridSample.filter
+    def filt(self, data_dict):
+        r = inner_f(self, data_dict)
+        data_dict["sample_points"] = np.ascontiguousarray(data_dict["sample_points"][::-1])
+        return r
+    pp.GridSample.filter = filt
+from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
+scans, gt_abs = make_sequence(SceneConfig(height=G.H, width=G.W), G.FRAMES)
+res = G.run_loop(scans, gt_abs, G.PUBLISHED, mode)
+np.savez(out_path, rel=res["rel"], iters=res["iters"], capability=np.array(torch.backends.cpu.get_cpu_capability()))
+'''
+
+
+def main():
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import icp_oracle as O
+    src = CHILD % dict(root=ROOT)
+    runs = {}
+    for mode in ("base", "scalar", "gn8", "reversed"):
+        path = f"/tmp/loop_spread_{mode}.npz"
+        env = dict(os.environ)
+        if mode == "scalar":
+            env["ATEN_CPU_CAPABILITY"] = "default"
+        subprocess.run([sys.executable, "-c", src, mode, path], check=True, env=env)
+        runs[mode] = np.load(path)
+        print(mode, "capability", str(runs[mode]["capability"]), flush=True)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "loop_reference.npz"))
+    base = runs["base"]
+    reproduces = bool(np.array_equal(base["rel"], g["rel"]) and np.array_equal(base["iters"], g["iters"]))
+    print("base reproduces loop_reference.npz bit for bit:", reproduces)
+    frames = base["rel"].shape[0]
+    spread_t, spread_r = np.zeros(frames), np.zeros(frames)
+    flipped = np.zeros(frames, bool)
+    out = {"modes": np.array(sorted(runs)), "base_reproduces_loop_reference": np.array(reproduces)}
+    for mode, r in runs.items():
+        out[f"{mode}_rel"] = r["rel"]
+        out[f"{mode}_iters"] = r["iters"]
+        if mode == "base":
+            continue
+        dt = np.zeros(frames)
+        dr = np.zeros(frames)
+        for f in range(1, frames):
+            dt[f], dr[f] = O.pose_error(r["rel"][f], base["rel"][f])
+        fl = r["iters"] != base["iters"]
+        spread_t, spread_r, flipped = np.maximum(spread_t, dt), np.maximum(spread_r, dr), flipped | fl
+        print(f"{mode}: max |dt| {dt.max():.3e} m (frame {int(dt.argmax())}), max |dr| {dr.max():.3e} rad; frames with "
+              f"another iteration count: {np.flatnonzero(fl).tolist()}", flush=True)
+    behind = np.cumsum(flipped) > 0
+    out.update(spread_t=spread_t, spread_r=spread_r, flipped=flipped, behind_flip=behind,
+               max_spread_behind_a_flip_t=np.array(spread_t[behind].max() if behind.any() else 0.0),
+               max_spread_before_any_flip_t=np.array(spread_t[~behind].max() if (~behind).any() else 0.0))
+    np.savez_compressed(OUT, **out)
+    print(json.dumps({"max_spread_t": float(spread_t.max()), "max_spread_r": float(spread_r.max()),
+                      "flipped_frames": np.flatnonzero(flipped).tolist(),
+                      "max_spread_behind_a_flip_t": float(out["max_spread_behind_a_flip_t"]),
+                      "max_spread_before_any_flip_t": float(out["max_spread_before_any_flip_t"])}))
+
+
+if __name__ == "__main__":
+    main()

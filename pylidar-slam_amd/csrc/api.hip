@@ -312,7 +312,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
-                            &ctx->hood};
+                            &ctx->hood,       &ctx->normals_carry};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -391,10 +391,13 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "refresh_at") ctx->refresh_at = iv;
     else if (k == "prune_guard") ctx->prune_guard = value > 0.0 ? (float)value : 0.f;
     else if (k == "hoods") ctx->hoods = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
+    else if (k == "carry_normals") ctx->carry_normals = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 16.0;
     else if (k == "search_stats") {
-        ctx->search_stats = (int)iv;  // 1: path counters + phase stamps, 2: stamps only (no atomics)
+        // 1: path counters + phase stamps, 2: stamps only (no atomics); 3 / 4: as 1 / 2, plus the per-workgroup dump
+        ctx->search_stats_blocks = iv == 3 || iv == 4;
+        ctx->search_stats = iv == 3 ? 1 : (iv == 4 ? 2 : (int)iv);
         if (ctx->search_stats) {  // 16 path counters + 4 phase timestamps per workgroup and iteration
             ICP_HIP(ctx, ctx->dbg_counts.reserve(DBG_BYTES));
             ICP_HIP(ctx, hipMemsetAsync(ctx->dbg_counts.ptr, 0, DBG_BYTES, ctx->stream));
@@ -668,6 +671,7 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
     int rc = ensure_state(ctx);
     if (rc) return rc;
     ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
+    ctx->carry_job = false;
     int64_t inserted = 0;
     int64_t evicted = 0;
     if (ctx->map_m == 0 && ctx->cloud_sizes.empty() && !ctx->grid_valid) {
@@ -702,6 +706,11 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
         DeviceBuffer& dst = ctx->map_xyz[next];
         ICP_HIP(ctx, dst.reserve((size_t)(keep + (has_cloud ? n : 0) + 1) * 12));
         const float* src = ctx->map_xyz[ctx->map_cur].as<float>() + 3 * evict;
+        // a pose-only update (nothing inserted, nothing evicted: every point keeps its neighbours) of a map whose grid holds
+        // estimated normals: they are rotated with the points instead of being cleared (option "carry_normals")
+        ctx->carry_job = ctx->carry_normals && !has_cloud && evict == 0 && keep > 0 && ctx->grid_valid &&
+                         ctx->cost == ICP_COST_POINT_TO_PLANE;
+        ctx->carry_m = keep;
         if (keep > 0) {  // the re-expression rides in the first launch of the grid build below
             MapMoveJob& job = ctx->move_job;
             job.in = src;
@@ -775,11 +784,19 @@ int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz,
 int icp_map_stage_cloud(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int row_mode) {
     DeviceGuard device_guard(ctx);
     if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    {   // (as every entry point that enqueues work: iterations a chunked launch holds back go first — stream order = call order)
+        const int rc_held = continue_launch(ctx, -1);
+        if (rc_held) return rc_held;
+    }
     int rc = ensure_state(ctx);
     if (rc) return rc;
-    ctx->staged_rows = -1;
     if (!ctx->staged_count_host) ICP_HIP(ctx, hipHostMalloc((void**)&ctx->staged_count_host, sizeof(int), hipHostMallocDefault));
     if (!ctx->staged_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->staged_event, hipEventDisableTiming));
+    // an earlier staged cloud that was never consumed (a pose-only frame): its count copy may still be in flight — it must
+    // not land on the pinned word after the host has rewritten it
+    if (ctx->staged_rows >= 0) ICP_HIP(ctx, hipEventSynchronize(ctx->staged_event));
+    ctx->staged_rows = -1;
     *ctx->staged_count_host = 0;
     if (n > 0) {
         const void* in = nullptr;
@@ -1487,7 +1504,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                                     "and published after %.2f more\n",
                             it, (q[0] - first) * 0.01, (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01);
                 }
-                if (it < 4 && getenv("ICP_STATS_BLOCKS")) {  // dev: the search phase of every workgroup, by logical block
+                if (it < 4 && ctx->search_stats_blocks) {  // dev ("search_stats" 3 | 4): the search phase of every workgroup, by logical block
                     fprintf(stderr, "[icp blocks] it %d:", it);
                     for (int i = 0; i < nb; ++i) {
                         const long long* q = t + 4 * i;

@@ -165,17 +165,21 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 // cell-sorted positions still mean something, i.e. before the scatter of this build: it shares the first launch.
 // + (move.m > 0) the re-expression of the kept map points in the new frame (local_map.py:346-348): independent of the
 // other two, one launch less per frame.
+// + (carry_m > 0: a pose-only update, option "carry_normals") the normals the old grid holds, rotated into the new frame
+// like the points (n' = R^-1 n; re-normalised, so that a thousand pose-only updates in a row leave unit vectors) and filed
+// by ORIGINAL index: the scatter of this build puts them at the points' new cell-sorted positions instead of zeros.
 __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
                              int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket,
-                             unsigned long long* __restrict__ hood_used) {
+                             unsigned long long* __restrict__ hood_used, const float4* __restrict__ old_normals,
+                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry) {
     __shared__ float T[16];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
         if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
     }
     const long long first = (long long)blockIdx.x * blockDim.x;
-    const bool moves = first < move.m;  // block-uniform
+    const bool moves = first < move.m;  // block-uniform (a carry job comes with a move job over the same points)
     if (moves && threadIdx.x == 0) map_move_prepare(move, T);
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < size) {
@@ -194,6 +198,19 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
     if (moves) {
         __syncthreads();
         if ((long long)i < move.m) move_point(T, move.in, (long long)i, move.out);
+        if ((int)i < carry_m) {  // (carry_m == move.m: this block has T)
+            float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 p = old_pts[i];
+            if (old_nflag[i] == 1) {
+                const float4 nv = old_normals[i];
+                const float x = T[0] * nv.x + T[1] * nv.y + T[2] * nv.z, y = T[4] * nv.x + T[5] * nv.y + T[6] * nv.z,
+                            z = T[8] * nv.x + T[9] * nv.y + T[10] * nv.z;
+                const float inv = rsqrtf(x * x + y * y + z * z);
+                if (inv < INFINITY) out = make_float4(x * inv, y * inv, z * inv, 1.f);  // (a zero normal stays unestimated)
+            }
+            const int o = __float_as_int(p.w);
+            if (o >= 0 && o < carry_m) carry[o] = out;
+        }
     }
 }
 
@@ -476,7 +493,8 @@ __device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, i
                                 const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
                                 float4* __restrict__ sorted,
                                 float4* __restrict__ csorted, float4* __restrict__ normals, int* __restrict__ nflag,
-                                int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig) {
+                                int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig,
+                                const float4* __restrict__ carry, int carry_m) {
     if (i >= m) return;
     // four +inf pads behind the last point: search_ball_lane reads cells in whole groups of four
     if (i == 0)
@@ -489,9 +507,16 @@ __device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, i
     pos_of_orig[i] = pos;
     sorted[pos] = p;
     csorted[cpos] = p;
-    // the normal cache is cleared on every rebuild (local_map.py:368)
-    normals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    nflag[i] = 0;
+    // the normal cache is cleared on every rebuild (local_map.py:368) — or, behind a pose-only update with
+    // "carry_normals", holds the rotated normals of the old grid (k_grid_clear filed them by original index)
+    if (carry_m > 0) {  // (kernel-uniform; carry_m == m)
+        const float4 c = i < carry_m ? carry[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        normals[pos] = c;
+        nflag[pos] = c.w == 1.f ? 1 : 0;
+    } else {
+        normals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        nflag[i] = 0;
+    }
 }
 
 
@@ -504,13 +529,13 @@ __global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const 
                                     const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
                                     float4* __restrict__ sorted, float4* __restrict__ csorted,
                                     float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
-                                    int* __restrict__ pos_of_orig) {
+                                    int* __restrict__ pos_of_orig, const float4* __restrict__ carry, int carry_m) {
     if ((int)blockIdx.x < row_blocks) {  // block-uniform
         build_rows_part(table, mask, slot_of_cell, ncells_dev, rows, blockIdx.x, row_blocks);
         return;
     }
     grid_scatter_part((blockIdx.x - row_blocks) * blockDim.x + threadIdx.x, xyz, m, table, slot_of, rank_of, cslot_of,
-                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig);
+                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -647,7 +672,16 @@ int build_grid(icp_ctx* ctx) {
         if (change < 0.85 || change > 1.18) ctx->cell_h = (float)wanted;
     }
     const float inv_h = 1.0f / ctx->cell_h;
-    ctx->normals_ready = false;
+    // a pose-only update with "carry_normals" (map_update_impl): the normals of the old grid travel with their points — the
+    // old cell-sorted array, normals and flags are read by the clearing launch, the new ones written by the scatter
+    int carry_m = 0;
+    if (ctx->carry_job && ctx->carry_m == m && ctx->move_job.m == m && ctx->cost == ICP_COST_POINT_TO_PLANE) {
+        ICP_HIP(ctx, ctx->normals_carry.reserve((size_t)m * sizeof(float4)));
+        carry_m = (int)m;
+    }
+    ctx->carry_job = false;
+    const bool carried_all = carry_m > 0 && ctx->normals_ready;  // every normal was there, every normal still is
+    ctx->normals_ready = carried_all;
     ctx->stats_pending = true;
     ctx->stats_m_pending = m;
     ctx->stats_h_pending = ctx->cell_h;
@@ -672,9 +706,15 @@ int build_grid(icp_ctx* ctx) {
     // icp_map_normals_owned — a point-to-point loop, a lazily estimated map or another k never does (480 B per map point
     // and a launch per build otherwise); the list space of a map that stops needing it is given back
     const int kn_hood = ctx->cfg.num_neighbors_normals + 1;
-    const bool with_hoods = ctx->hoods && m <= (1ll << 22) && (kn_hood == 11 || kn_hood == 6) &&
-                            (wants_eager_normals(ctx, ctx->tgt_n > 0 ? ctx->tgt_n : m) || ctx->sharded_normals);
-    if (!with_hoods && ctx->hood.ptr) {
+    const bool hoods_possible = ctx->hoods && m <= (1ll << 22) && (kn_hood == 11 || kn_hood == 6);
+    // (nothing reads them behind a build whose normals were all carried over, unless the map-sharded estimation will)
+    const bool with_hoods = hoods_possible && ((wants_eager_normals(ctx, ctx->tgt_n > 0 ? ctx->tgt_n : m) && !carried_all) ||
+                                               ctx->sharded_normals);
+    // the list space goes back once HOOD_IDLE_RELEASE builds in a row had no use for it (or cannot have any): a map
+    // whose scan size sits at the eager / lazy boundary must not pay a stream synchronisation and a free / malloc pair
+    // per flip
+    if (!carried_all) ctx->hood_idle_builds = with_hoods ? 0 : ctx->hood_idle_builds + 1;  // (a carried build says nothing)
+    if (ctx->hood.ptr && !with_hoods && (!hoods_possible || ctx->hood_idle_builds >= HOOD_IDLE_RELEASE)) {
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a launch of the previous build may still read them)
         ctx->hood.release();
     }
@@ -696,7 +736,8 @@ int build_grid(icp_ctx* ctx) {
         if (move.m > span) span = move.m;
         hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
                            (unsigned int)n2, ctx->nn_cache.as<int4>(), ctx->sorted_pts.as<float4>(), seed_n,
-                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket, hood_used);
+                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket, hood_used,
+                           ctx->normals.as<float4>(), ctx->nflag.as<int>(), carry_m, ctx->normals_carry.as<float4>());
     }
     hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
                        table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
@@ -711,7 +752,7 @@ int build_grid(icp_ctx* ctx) {
                            ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                            ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(), ctx->csorted.as<float4>(),
                            ctx->normals.as<float4>(), ctx->nflag.as<int>(), ctx->row_of_pos.as<int>(),
-                           ctx->pos_of_orig.as<int>());
+                           ctx->pos_of_orig.as<int>(), ctx->normals_carry.as<float4>(), carry_m);
     }
     // neighbourhood lists for the kNN normals (option "hoods"; maps beyond 2^22 points keep the row walk: 27 x 16 B per
     // point would be gigabytes).  The start of a run is an int: 27 M < 2^31 holds for every map that gets here

@@ -49,6 +49,7 @@ struct GridView {
 };
 static constexpr float COARSE_FACTOR = 4.0f;
 static constexpr int COARSE_RINGS = 6;
+static constexpr int HOOD_IDLE_RELEASE = 8;  // builds in a row without a reader before the neighbourhood lists are given back
 static constexpr int HOOD_PER_POINT = 30;  // neighbourhood-list entries reserved per map point (27 + padding of the runs); the counters follow
 static constexpr int SORTED_PAD = 4;   // +inf entries behind the last cell-sorted point (search.hip::search_ball_lane reads groups of four)
 static constexpr int ROW_STRIDE = 28;  // 27 cells + 1 pad: rows are 224 B, 16-byte aligned
@@ -299,6 +300,7 @@ struct icp_ctx {
     int iterate_dense = 1;             // "iterate_dense": 64-VGPR build of that kernel (4 blocks per CU resident)
     int frame_seed = 1;                // "frame_seed": last frame's neighbours seed the first iteration of the next one
     int search_stats = 0;              // "search_stats": count which path resolved each query (dev)
+    bool search_stats_blocks = false;  // ... "search_stats" 3 | 4: + the stamps of every workgroup in the dump (dev)
     icp::DeviceBuffer dbg_counts;
     // a cloud staged for the next map update (icp_map_stage_cloud): its valid rows, in order; their count travels to the host
     // behind the compaction, beside whatever is enqueued after it — the update then needs no synchronisation of its own
@@ -331,6 +333,15 @@ struct icp_ctx {
     int xcd_sectors = 1;               // "xcd_sectors": workgroups of one XCD take one sector of the scan (launch_iterate_fused)
     int hoods = 2;                     // "hoods": neighbourhood lists for the kNN normals (1: four lanes per point, 2: one lane per point + a straggler queue)
     bool hoods_valid = false;          // ... built for the current grid
+    int hood_idle_builds = 0;          // grid builds in a row that had no use for the lists (their space goes back after HOOD_IDLE_RELEASE of them)
+    // "carry_normals": a pose-only map update (no insertion, no eviction: every point keeps its neighbours) rotates the
+    // normals already estimated with the points instead of clearing them (local_map.py:368 zeroes them; re-estimated in
+    // the new frame they are the same vectors up to float32 rounding of the re-expressed points).  0: the reference's
+    // schedule — every rebuild clears the cache
+    int carry_normals = 1;
+    bool carry_job = false;            // the pending grid build carries the normals of the `carry_m` points of the old grid over
+    int64_t carry_m = 0;
+    icp::DeviceBuffer normals_carry;   // float4[M] by ORIGINAL index: (rotated normal, 1) or zeros
     bool sharded_normals = false;      // icp_map_normals_owned has been used on this context (the lists serve it too)
     icp::DeviceBuffer hood;            // float4[<= 30 M] + the fill counter behind it
     int chunked_launch = 1;            // "chunked_launch": launched registrations with a live threshold are enqueued in chunks

@@ -1252,10 +1252,16 @@ __device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ s
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
 }
 
-template <int MINW, int THREADS, int Q>
+// STATS: the dev instrumentation ("search_stats": path counters, phase stamps) is compiled into an instantiation of its
+// own; the product kernel carries none of it (72 s_memrealtime and their branches in a kernel that spills SGPRs).
+template <int MINW, int THREADS, int Q, bool STATS = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                    RegState* __restrict__ st, AlignParams ap,
                                                                    LeadArgs lead) {
+    if (!STATS) {  // (constant-folds every `if (g.dbg)` / `if (stamps)` below and inside the inlined searches)
+        g.dbg = nullptr;
+        g.stamps = nullptr;
+    }
     __shared__ float rowbuf[Q][9];
     __shared__ double part[Q / 32][NEQ];
     __shared__ int2 cellstack[7][THREADS];
@@ -3017,7 +3023,14 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // the first launches of a registration (most queries search) with 1024 threads per workgroup: twice the lanes for the
     // same 512 queries, so every miss gets two (the slowest WAVE sets these launches: a lane that walks 200 candidates of a
     // dense cell alone); same super-rows, same bits
-    if (narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search)
+    const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search;
+    if (wide && ctx->search_stats)  // (dev: the instrumented instantiations exist for the two default shapes only)
+        hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, true>), dim3(grid), dim3(2 * IT_THREADS), 0,
+                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (narrow && ctx->search_stats)
+        hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (wide)
         hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS>), dim3(grid), dim3(2 * IT_THREADS), 0,
                            ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else if (narrow)

@@ -71,6 +71,7 @@ class OracleContext:
     def map_stage_cloud(self, new_points, skip_null=False):
         self.calls.append("stage")
         pts = self._np(new_points).reshape(-1, 3).copy()
+        pts = pts[~np.isnan(pts).any(axis=1)]  # (the library's k_flag_not_nan always drops NaN rows)
         self._staged = pts[np.abs(pts).max(axis=1) > 0] if skip_null else pts
 
     def map_update_staged(self, rel_pose):

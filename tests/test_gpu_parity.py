@@ -436,6 +436,52 @@ def test_lazy_and_eager_normals_give_the_same_registration(torch_cuda):
         np.testing.assert_allclose(got["lazy"].losses, got["eager"].losses, rtol=1e-6)
 
 
+def test_carried_normals_equal_reestimated_ones(torch_cuda):
+    """Option "carry_normals" (default 1): a pose-only map update rotates the normals the grid holds with the points instead
+    of clearing them; 0 is the reference's schedule (local_map.py:365-369: every build_model zeroes the cache, the next
+    touch re-estimates from the re-expressed points).  Over a chain of frames with pose-only updates the two agree to
+    float32 rounding: normals (|dot| > 1 - 1e-6), poses (1e-6 m / rad), losses; the carried schedule estimates nothing
+    after the first frame, an update that inserts a cloud clears the cache under both."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 9)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    got = {}
+    for carry in (0, 1):  # (the reference-exact schedule first)
+        ctx = _ctx(height=32, width=1024, max_num_alignments=10, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3)
+        ctx.set_option("carry_normals", carry)
+        ctx.map_set(model)
+        frames, init = [], None
+        for f in (4, 5, 6, 7):
+            ctx.register_launch(scans[f], init)
+            ctx.map_update(None, None)
+            r = ctx.register_end()
+            frames.append(r)
+            init = r.pose
+        q, nrm, ix = ctx.nearest_neighbor_search(scans[7][::5], with_index=True)
+        # ... then an insertion: the cache is cleared whatever the option says, every normal estimated again
+        ctx.map_update(np.eye(4, dtype=np.float32), scans[8][::16])
+        r8 = ctx.register(scans[8], init)
+        got[carry] = (frames, nrm, ix, ctx.map_points(), r8)
+        ctx.close()
+    (f0, n0, i0, m0, a0), (f1, n1, i1, m1, a1) = got[0], got[1]
+    assert f0[0].normals_computed == model.shape[0] and f1[0].normals_computed == model.shape[0]
+    assert all(r.normals_computed == model.shape[0] for r in f0[1:])  # the reference's schedule re-estimates every frame
+    assert all(r.normals_computed == 0 for r in f1[1:])               # carried: nothing to estimate
+    # behind an insertion: all of them, both ways (the reference's schedule also reports the estimation behind the last
+    # pose-only update, which no registration had collected yet)
+    assert a1.normals_computed == m0.shape[0] and a0.normals_computed == m0.shape[0] + model.shape[0]
+    for r0, r1 in zip(f0 + [a0], f1 + [a1]):
+        assert np.abs(r0.pose - r1.pose).max() < 1e-6, np.abs(r0.pose - r1.pose).max()
+        np.testing.assert_allclose(r1.losses, r0.losses, rtol=1e-5)
+    assert np.abs(m0 - m1).max() < 1e-5  # (the maps moved by poses that differ by 1e-7)
+    same = i0 == i1
+    assert same.mean() > 0.999
+    dots = np.abs((n0[same] * n1[same]).sum(axis=1))
+    assert dots.min() > 1 - 1e-6, dots.min()
+    np.testing.assert_allclose(np.linalg.norm(n1, axis=1), 1.0, atol=1e-6)
+
+
 def _knn_clouds():
     """Point sets that stress the k-nearest-neighbour search behind the normals: a LiDAR map, a volume, exact duplicates
     (ties on the k-th distance by the dozen), a lattice (every distance tied), isolated points, fewer than k + 1 points."""
