@@ -129,6 +129,21 @@ int icp_synchronize(icp_ctx* ctx);
  *   "lead_solve" 0 | 1 (1)          launched / unpolled registrations: the 6x6 solve of iteration k runs in an extra workgroup
  *                                   at the head of the (late, 512-queries-per-block) launch k + 1, which publishes the pose to
  *                                   the workgroups of that launch through a mailbox, instead of a launch of its own; same bits
+ *   "resident_tail" n (0: never)    from ICP iteration n on (and never before the "wide_until" launches are through) ONE launch
+ *                                   runs every remaining iteration of a launched / unpolled registration AND the solve behind the
+ *                                   last one: its workgroups (one per CU, 512 queries each) stay resident, keep their queries'
+ *                                   targets, cache entries and candidate sets in registers, take every pose from the mailbox and
+ *                                   hand their partial rows to the lead — workgroup 0, which also takes its share of the queries
+ *                                   — as tagged 8-byte granules; no launch boundary, no cold L2, no k_sum_solve launch per late
+ *                                   iteration, and a loop with a live stop threshold ends on the device (no chunks).  Needs every
+ *                                   workgroup resident at once (scans of up to 512 x CU count points); every wait is bounded by
+ *                                   "lead_timeout_ms": on a GPU shared with foreign work a wait may run out — the registration is
+ *                                   then finished on per-iteration launches (same bits) and the context keeps to those
+ *                                   (icp_handoff_fallbacks counts such registrations); same bits.  OFF by default: measured at the
+ *                                   headline size it costs 7 % (0.382 vs 0.357 ms per frame: what the launch boundary costs per
+ *                                   late iteration, 1.1 us, is less than the tagged rows and the skew of 256 resident workgroups
+ *                                   add), and nothing is gained on the published configuration's 12-workgroup scans
+ *   "resident_tail_max_blocks" n (4096) ... for scans of up to n x 512 points
  *   "lead_timeout_ms" t (50)        wall-clock bound of that poll: a workgroup that does not see the pose in time gives up and
  *                                   the registration ends with ICP_ERR_HIP instead of hanging the GPU (the hand-off assumes the
  *                                   lead workgroup — blockIdx 0 — is dispatched before the pollers fill the machine; raise the
@@ -254,6 +269,10 @@ int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const floa
                               int64_t* inserted_out);
 int64_t icp_map_size(const icp_ctx* ctx);
 int icp_map_num_clouds(const icp_ctx* ctx);
+/* registrations of this context that were finished on per-iteration launches because a hand-off between workgroups ran out
+ * of its wall-clock budget ("resident_tail", "lead_solve": a GPU shared with foreign work); the first one switches the
+ * context to per-iteration launches for good — results are unaffected (diagnostics; no reference counterpart) */
+int icp_handoff_fallbacks(const icp_ctx* ctx);
 int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem); /* current map [M,3] in insertion order */
 /* nearest_neighbor_search() :372-395 + __get_normals :397-422 — exact Euclidean 1-NN (no distance cap) and the
  * lazily estimated normal of every hit.  Outputs [n,3], [n,3], [n] (any may be NULL). */

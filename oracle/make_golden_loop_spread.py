@@ -66,10 +66,29 @@ if mode == "reversed":
         data_dict["sample_points"] = np.ascontiguousarray(data_dict["sample_points"][::-1])
         return r
     pp.GridSample.filter = filt
+# the value the stop test compares with the threshold, every iteration of every frame: |delta_pose| of
+# GaussNewtonPointToPlaneAlignment.align (icp_odometry.py:283-292), traced without changing it
+import slam.odometry.alignment as al
+norms = []
+inner_align = al.GaussNewtonPointToPlaneAlignment.align
+def align(self, *a, **k):
+    out = inner_align(self, *a, **k)
+    norms[-1].append(float(out[1].norm()))
+    return out
+al.GaussNewtonPointToPlaneAlignment.align = align
+import slam.odometry.icp_odometry as io
+inner_reg = io.ICPFrameToModel.register_new_frame
+def reg(self, *a, **k):
+    norms.append([])
+    return inner_reg(self, *a, **k)
+io.ICPFrameToModel.register_new_frame = reg
 from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
 scans, gt_abs = make_sequence(SceneConfig(height=G.H, width=G.W), G.FRAMES)
 res = G.run_loop(scans, gt_abs, G.PUBLISHED, mode)
-np.savez(out_path, rel=res["rel"], iters=res["iters"], capability=np.array(torch.backends.cpu.get_cpu_capability()))
+dxn = np.full((G.FRAMES, 20), np.nan)
+for f, row in enumerate(norms):  # registration f belongs to frame f + 1
+    dxn[f + 1, :len(row)] = row
+np.savez(out_path, rel=res["rel"], iters=res["iters"], dx_norm=dxn, capability=np.array(torch.backends.cpu.get_cpu_capability()))
 '''
 
 
@@ -98,6 +117,7 @@ def main():
     for mode, r in runs.items():
         out[f"{mode}_rel"] = r["rel"]
         out[f"{mode}_iters"] = r["iters"]
+        out[f"{mode}_dx_norm"] = r["dx_norm"]  # [frame, iteration]: |delta_pose|, NaN behind the stop
         if mode == "base":
             continue
         dt = np.zeros(frames)
@@ -108,6 +128,23 @@ def main():
         spread_t, spread_r, flipped = np.maximum(spread_t, dt), np.maximum(spread_r, dr), flipped | fl
         print(f"{mode}: max |dt| {dt.max():.3e} m (frame {int(dt.argmax())}), max |dr| {dr.max():.3e} rad; frames with "
               f"another iteration count: {np.flatnonzero(fl).tolist()}", flush=True)
+    # how close to the threshold every frame's stop was decided: margin = | |delta_pose| / 1e-4 - 1 | of the iteration that
+    # stopped the loop and of the one before it (the two values a flip would have turned), and how far the same quantity moves
+    # between two runs of the reference (relative difference of |delta_pose|, all iterations of all frames)
+    bn = base["dx_norm"]
+    margin = np.full(frames, np.inf)
+    for f in range(1, frames):
+        row = bn[f][~np.isnan(bn[f])]
+        if row.size:
+            margin[f] = np.min(np.abs(row[-2:] / 1.0e-4 - 1.0))
+    rel_noise = 0.0
+    for mode, r in runs.items():
+        if mode != "base":
+            both = ~np.isnan(bn) & ~np.isnan(r["dx_norm"])
+            rel_noise = max(rel_noise, float(np.max(np.abs(r["dx_norm"][both] - bn[both]) / bn[both])))
+    out.update(stop_margin=margin, dx_norm_relative_noise=np.array(rel_noise))
+    print("closest stop decisions (frame: margin):", {int(f): float(margin[f]) for f in np.argsort(margin)[:5]},
+          "| relative noise of |delta_pose| between runs:", rel_noise, flush=True)
     behind = np.cumsum(flipped) > 0
     out.update(spread_t=spread_t, spread_r=spread_r, flipped=flipped, behind_flip=behind,
                max_spread_behind_a_flip_t=np.array(spread_t[behind].max() if behind.any() else 0.0),

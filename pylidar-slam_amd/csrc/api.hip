@@ -312,7 +312,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
-                            &ctx->hood,       &ctx->normals_carry};
+                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -374,7 +374,9 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
     else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
-    else if (k == "lead_solve") ctx->lead_solve = value != 0.0 ? 1 : 0;
+    else if (k == "lead_solve") { ctx->lead_solve = value != 0.0 ? 1 : 0; if (ctx->lead_solve) ctx->tail_disabled = false; }
+    else if (k == "resident_tail") { ctx->resident_tail = iv < 0 ? 0 : (int)iv; ctx->tail_disabled = false; }
+    else if (k == "resident_tail_max_blocks") ctx->resident_tail_max_blocks = iv < 0 ? 0 : (int)iv;
     else if (k == "ball_search") ctx->ball_search = value != 0.0 ? 1 : 0;
     else if (k == "wide_until") ctx->wide_until = iv < 0 ? 0 : (int)iv;
     else if (k == "far_lanes") ctx->far_lanes = iv >= 16 ? 16 : 0;
@@ -382,7 +384,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "far_max") ctx->far_max = iv < 0 ? 0 : (iv > 512 ? 512 : (int)iv);
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);
-    else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 0.01 ? value : 0.01;
+    else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 1.0e-5 ? value : 1.0e-5;  // (>= one tick of the 100 MHz clock: tests go there)
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;
     else if (k == "flat_rows") ctx->flat_rows = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
     else if (k == "xcd_sectors") ctx->xcd_sectors = value != 0.0 ? 1 : 0;
@@ -719,6 +721,10 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
             memset(job.rel.m, 0, sizeof(job.rel.m));
             if (rel_pose) memcpy(job.rel.m, rel_pose, sizeof(job.rel.m));
             job.st = rel_pose ? (const RegState*)nullptr : (const RegState*)reg_state(ctx);
+            // (a pose-only update by the device-resident pose behind a registration the host has not collected yet: should
+            // that registration turn out to have been cut short by a timed-out hand-off, the device skips the move and
+            // icp_register_end repeats this update once the loop has been finished — recover_handoff)
+            if (!rel_pose && !has_cloud && ctx->result_pending()) ctx->update_behind_registration = true;
         }
         if (has_cloud && known_count >= 0) {
             if (known_count > 0)
@@ -870,6 +876,7 @@ int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const floa
 }
 
 int64_t icp_map_size(const icp_ctx* ctx) { return ctx ? ctx->map_m : 0; }
+int icp_handoff_fallbacks(const icp_ctx* ctx) { return ctx ? ctx->handoff_fallbacks : 0; }
 int icp_map_num_clouds(const icp_ctx* ctx) { return ctx ? (int)ctx->cloud_sizes.size() : 0; }
 
 int icp_map_get(icp_ctx* ctx, float* xyz_out, int out_mem) {
@@ -1411,6 +1418,43 @@ static int continue_launch(icp_ctx* ctx, int count) {
     return rc;
 }
 
+// A hand-off inside a lead launch / the resident tail ran out of its wall-clock budget (RegState.handoff_timeouts: a
+// workgroup the others wait for is not running — the GPU is shared with foreign work).  The launches behind it solved
+// nothing more (lead_solve / k_sum_solve stop at the counter), so the state holds the last complete iteration; a pose-only
+// map update enqueued behind the registration moved nothing (map_move_prepare).  Here: the context stops using hand-offs
+// (per-iteration launches with a solving launch each: "lead_solve" 0), the remaining iterations run on those — the same
+// iterations on the same map, hence the same bits — and the skipped map update is repeated with the final pose.
+// `block` receives the state + histories (the layout of the pinned result block).
+static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block) {
+    ctx->tail_disabled = true;
+    ctx->lead_solve = 0;
+    ctx->handoff_fallbacks += 1;
+    ctx->launch_remaining = 0;
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ICP_HIP(ctx, hipMemcpy(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost));
+    ICP_HIP(ctx, hipMemsetAsync(&reg_state(ctx)->handoff_timeouts, 0, sizeof(int), ctx->stream));
+    int rc = ICP_OK;
+    if (!st.done && st.status == ICP_OK && st.iter < ctx->cfg.max_num_alignments) {
+        ctx->in_registration = true;
+        ctx->iter_in_registration = st.iter;
+        ctx->cache_fresh = false;  // (a map update in between has rebuilt the grid: the first launch searches everything)
+        ctx->searches_in_registration = 0;
+        if (!ctx->normals_ready && wants_eager_normals(ctx, ctx->tgt_n) && (rc = launch_normals_all(ctx))) return rc;
+        rc = enqueue_iterations(ctx, false, st.iter, -1);
+        ctx->in_registration = false;
+        if (rc) return rc;
+    }
+    if (ctx->update_behind_registration) {  // the pose-only update the device skipped, now with the final pose
+        ctx->update_behind_registration = false;
+        if ((rc = map_update_impl(ctx, nullptr, nullptr, nullptr, 0, false, nullptr))) return rc;
+    }
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    block.resize(state_bytes(ctx));
+    ICP_HIP(ctx, hipMemcpy(block.data(), ctx->state.ptr, block.size(), hipMemcpyDeviceToHost));
+    memcpy(&st, block.data(), sizeof(st));
+    return ICP_OK;
+}
+
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
@@ -1451,6 +1495,13 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         ICP_HIP(ctx, hipMemcpyAsync(&st, ctx->state.ptr, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    std::vector<char> recovered;
+    if (st.handoff_timeouts > 0 && ctx->r_count == 0) {  // (with a newer registration already enqueued behind it: the error below)
+        const int rc_rec = recover_handoff(ctx, st, recovered);
+        if (rc_rec) return rc_rec;
+        if (async) pinned = recovered.data();
+    }
+    if (ctx->r_count == 0) ctx->update_behind_registration = false;
     if (had_stats && st.grid_cells > 0) {
         ctx->occupied_cells = st.grid_cells;
         ctx->stats_m = stats_m;
@@ -1612,6 +1663,16 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
     const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0;
     int prev_rows = 0, prev_quad = 1;  // rows a lead launch still has to solve
     for (int it = first; it < iters; ++it) {
+        if (lead && fused_tail_possible(ctx, prev_rows, iters - it)) {
+            // the resident tail: every remaining iteration, and the solve behind the last one, in ONE launch
+            int rows = 0, quad = 1;
+            rc = launch_iterate_fused(ctx, &rows, &quad, true, prev_rows, prev_quad, iters - it);
+            if (rc) {
+                ctx->in_registration = false;
+                return rc;
+            }
+            break;
+        }
         if (lead) {
             // every launch takes its pose from the mailbox; the NARROW ones (late iterations: one workgroup more fits beside
             // the others) also solve the iteration before them, the others follow a summing / solving launch as before
@@ -1667,7 +1728,9 @@ static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, i
     // icp_register_end enqueues further chunks while the loop is still running
     const int iters = ctx->cfg.max_num_alignments;
     int first_chunk = iters;
-    if (ctx->cfg.threshold_delta_pose > 0.f && ctx->chunked_launch) {
+    // (lead launches that end in a resident tail run to the end of the loop on the device: nothing to chunk)
+    const bool tail = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && fused_tail_planned(ctx, iters);
+    if (ctx->cfg.threshold_delta_pose > 0.f && ctx->chunked_launch && !tail) {
         first_chunk = (ctx->last_iterations > 0 ? ctx->last_iterations : 3) + 1;
         if (first_chunk > iters) first_chunk = iters;
     }

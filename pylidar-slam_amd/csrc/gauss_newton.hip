@@ -285,7 +285,9 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
                                                     float* __restrict__ dx_hist, int hist_cap,
                                                     unsigned long long* __restrict__ box, unsigned gen) {
     // the state words are requested first and consumed last: their latency hides behind the partial-row loads
-    const int done = st->done;
+    // (a hand-off that timed out in an earlier launch of this registration — handoff_timeouts — left incomplete rows behind:
+    // nothing is solved from them; icp_register_end re-runs the rest of the loop from the iteration the state holds)
+    const int done = st->done | (st->handoff_timeouts > 0 ? 1 : 0);
     int it = 0;
     float pose_in[16], params_in[6];
     if (threadIdx.x < 64) {  // the solving wave (uniform addresses: one transaction)

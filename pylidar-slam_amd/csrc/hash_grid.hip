@@ -205,8 +205,11 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
                 const float4 nv = old_normals[i];
                 const float x = T[0] * nv.x + T[1] * nv.y + T[2] * nv.z, y = T[4] * nv.x + T[5] * nv.y + T[6] * nv.z,
                             z = T[8] * nv.x + T[9] * nv.y + T[10] * nv.z;
-                const float inv = rsqrtf(x * x + y * y + z * z);
-                if (inv < INFINITY) out = make_float4(x * inv, y * inv, z * inv, 1.f);  // (a zero normal stays unestimated)
+                // (re-normalised only once rounding has moved the length off 1 by more than an ulp or two: a rotation by the
+                // identity — the update behind a registration that failed — leaves every bit where it was)
+                const float n2 = x * x + y * y + z * z;
+                const float sc = fabsf(n2 - 1.f) > 4e-7f ? rsqrtf(n2) : 1.f;
+                if (n2 > 0.f && sc < INFINITY) out = make_float4(x * sc, y * sc, z * sc, 1.f);  // (a zero normal stays unestimated)
             }
             const int o = __float_as_int(p.w);
             if (o >= 0 && o < carry_m) carry[o] = out;

@@ -184,6 +184,19 @@ struct ExchangeView {
     long long timeout_ticks;                  // 100 MHz wall-clock ticks to wait for the peers
 };
 
+// Inside the loop of a persistent kernel (the resident tail, search.hip) the optimiser hoists every value derived from the
+// thread index — dozens of per-lane addresses, group and lane numbers — out of the loop and keeps them in registers around
+// its whole body: 80 spilled VGPRs at a budget of 256, measured.  A local `threadIdx` that shadows the builtin and is
+// re-read through an opaque move per trip keeps those values local to where they are used.
+struct LocalTid {
+    unsigned x;
+};
+__device__ __forceinline__ LocalTid reloaded_tid() {
+    unsigned v = ::threadIdx.x;
+    asm volatile("" : "+v"(v));
+    return LocalTid{v};
+}
+
 struct Pose16 {
     float m[16];
 };
@@ -354,6 +367,21 @@ struct icp_ctx {
     int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)
     double lead_timeout_ms = 50.0;     // "lead_timeout_ms": how long a workgroup of a lead launch polls the pose mailbox before it gives up (-> ICP_ERR_HIP)
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
+    // "resident_tail": from that iteration on (0: never — the default) ONE launch runs all remaining iterations of a launched /
+    // unpolled registration — its workgroups stay resident and hand their partial rows to its lead as tagged granules
+    // (search.hip).  Built for VERDICT r4 item 1 and MEASURED (round 5): 256 workgroups x 20 forced iterations
+    // 0.382 vs 0.357 ms per frame — per late iteration the tail saves the launch boundary (1.1 us) and a cold L2, and pays
+    // 2.4 instead of 1.8 us for the rows to reach the lead (tagged granules through the fabric instead of plain loads behind
+    // a kernel boundary) and ~1 us of skew among 256 resident workgroups: 9.95 vs 9.4 us; 12 workgroups with a live stop
+    // threshold (the published configuration): 0.606-0.613 vs 0.605-0.633 ms per frame, no difference.  Off by default;
+    // the option, its tests and the timed-out-hand-off recovery it made necessary stay
+    int resident_tail = 0;
+    int resident_tail_max_blocks = 4096;  // "resident_tail_max_blocks": ... for scans of up to that many 512-query workgroups
+    bool tail_disabled = false;        // a hand-off of this context timed out once (a GPU shared with foreign work): per-iteration launches from then on
+    int tail_capacity = -1;            // workgroups of the tail's shape the device holds at once (-1: not asked yet)
+    int handoff_fallbacks = 0;         // registrations finished on per-iteration launches behind a timed-out hand-off
+    bool update_behind_registration = false;  // a pose-only map update by the device pose is enqueued behind an uncollected registration
+    icp::DeviceBuffer tail_rows;       // tagged super-rows of the tail: [rows][NEQ][2] granules of 8 bytes
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs
     icp::DeviceBuffer state;           // RegState + histories
     // per-iteration histories live behind the RegState in the same allocation (one D2H copy brings back everything):
@@ -456,7 +484,10 @@ int launch_sum_partials(icp_ctx* ctx, int rows, int quad = 1);
 // rows written; quad: base rows (1) or super-rows (0).  lead: the launch takes its pose from the mailbox; with prev_rows > 0
 // its lead workgroup first solves the equations the previous fused launch left (prev_rows / prev_quad rows of the other
 // parity of ctx->partials)
-int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead = false, int prev_rows = 0, int prev_quad = 1);
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead = false, int prev_rows = 0, int prev_quad = 1,
+                         int tail_iters = 0);  // tail_iters > 0: a resident tail over that many iterations (ask fused_tail_possible first)
+bool fused_tail_possible(icp_ctx* ctx, int prev_rows, int tail_iters);
+bool fused_tail_planned(icp_ctx* ctx, int iters);
 unsigned long long* pose_box(icp_ctx* ctx);   // device pointer of the mailbox (allocated by ensure_state)
 unsigned next_box_generation(icp_ctx* ctx);    // a new generation number for a pose about to be published
 bool next_fused_launch_is_narrow(const icp_ctx* ctx);  // the shape launch_iterate_fused will pick for the next iteration

@@ -60,7 +60,9 @@ __device__ inline void map_move_prepare(const MapMoveJob& job, float* __restrict
     for (int k = 0; k < 16; ++k) pose[k] = job.st ? job.st->pose[k] : job.rel.m[k];
     // a registration that stopped on an error moves nothing: the reference raises before it would touch the map
     // (slam/common/optimization.py:334-336 inside icp_odometry.py:286), the host learns of it in icp_register_end
-    const bool failed = job.st && job.st->status != ICP_OK;
+    // ... and so does one whose loop was cut short by a timed-out hand-off (icp_register_end finishes it on per-iteration
+    // launches and repeats this update with the final pose)
+    const bool failed = job.st && (job.st->status != ICP_OK || job.st->handoff_timeouts > 0);
     if (failed || !invert4(pose, inv))  // a pose built from Euler angles is never singular; the host path checks
         for (int k = 0; k < 16; ++k) inv[k] = (k % 5 == 0) ? 1.f : 0.f;
     for (int k = 0; k < 16; ++k) T[k] = inv[k];

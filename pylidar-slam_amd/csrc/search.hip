@@ -1089,9 +1089,11 @@ static constexpr int IT_QUERIES = IT_THREADS / 4;
 // (S = a quarter of the base rows) -> super-row (r0 + r1) + (r2 + r3); super-rows in the strided 8-accumulator pattern.  A
 // block of 128 queries (Q = 128) writes its base row, a block of 512 queries — four 128-query chunks S base rows apart —
 // its super-row: a quarter of the rows for the summing kernel, same bits.
-template <int Q>
-__device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
-                                         int block) {
+// RET: the sum is returned (threads < NEQ; 0.0 elsewhere) instead of being stored
+template <int Q, bool RET = false>
+__device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
+                                           int block) {
+    const LocalTid threadIdx = RET ? reloaded_tid() : LocalTid{::threadIdx.x};  // (RET: inside the resident tail's loop)
     constexpr int SUB = Q / IT_QUERIES;  // base rows per block
     if ((int)threadIdx.x < SUB * 4 * NEQ) {
         const int e = threadIdx.x & (NEQ - 1), qtr = (threadIdx.x / NEQ) & 3, sb = threadIdx.x / (4 * NEQ);
@@ -1114,8 +1116,10 @@ __device__ inline void block_reduce_rows(const float (*rowbuf)[9], double (*part
             r[sb] = (part[4 * sb][e] + part[4 * sb + 1][e]) + (part[4 * sb + 2][e] + part[4 * sb + 3][e]);
         double v = r[0];
         if (SUB == 4) v = (r[0] + r[1]) + (r[2] + r[3]);
+        if (RET) return v;
         partials[(size_t)block * NEQ + e] = v;
     }
+    return 0.0;
 }
 
 
@@ -1165,6 +1169,9 @@ struct IterInputs {
     int far_min;             // option "far_min": ... and it takes more than that many (fewer: a wave each, phase B1)
     int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
+    int tail_iters;          // resident tail (TAIL instantiation): iterations this launch runs (iter .. iter + tail_iters - 1)
+    int refresh_at;          // ... the one of them the refresh margin applies to (a launch of its own: `refresh_margin` is set for it alone)
+    unsigned long long* tail_rows;  // ... the tagged super-rows its workgroups hand to its lead: [rows][NEQ][2] granules
     // XCD sectors (option "xcd_sectors"): the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
     // an L2 of its own — with consecutive queries in consecutive workgroups every L2 has to hold the rows and points of
     // the WHOLE map.  With swz_bpr_shift >= 0 the workgroups of one XCD take one azimuth sector (x elevation band) of the
@@ -1222,7 +1229,9 @@ __device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ s
     double(*lds)[NEQ] = reinterpret_cast<double(*)[NEQ]>(scratch);
     double* total = scratch + 32 * NEQ;
     if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();  // dev: entry | rows summed | solved and published
-    const int done = st->done;  // block-uniform
+    // (block-uniform; a hand-off that timed out in an earlier launch of this registration left incomplete rows behind: the
+    // chain of solves stops there, as behind the end of the loop — icp_register_end re-runs the rest)
+    const int done = st->done | (st->handoff_timeouts > 0 ? 1 : 0);
     int it = 0;
     float pose_in[16], params_in[6];
     if (threadIdx.x < 64) {  // the solving wave (uniform addresses: one transaction)
@@ -1252,9 +1261,96 @@ __device__ inline void lead_solve(const LeadArgs& lead, RegState* __restrict__ s
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
 }
 
+// The lead's work inside the RESIDENT TAIL (k_iterate_compact<.., TAIL>): workgroup 0 carries out solve j of the launch in
+// front of its own share of iteration j — j = 0 from the rows the PREVIOUS launch left (plain loads), j >= 1 from the tagged
+// rows the workgroups of this launch handed over in iteration j - 1 (sum_tagged_rows_vt; tag = the generation that
+// iteration consumed), j = tail_iters behind the last iteration (what a k_sum_solve launch used to do) — and publishes the
+// pose as generation `gen`.  Pose, parameters and iteration count travel from solve to solve in `carry_s` (LDS; the
+// RegState is written for the host and for later launches, never read back here).  False: the launch is over for this
+// workgroup (the loop had ended before the launch, or a row did not arrive in time).
+template <int THREADS>
+__device__ inline bool tail_lead_step(const LeadArgs& lead, RegState* __restrict__ st, AlignParams ap, double* scratch,
+                                      float* __restrict__ carry_s, int j, unsigned gen,
+                                      const unsigned long long* __restrict__ tail_rows, int nrows, long long* stamps) {
+    const LocalTid threadIdx = reloaded_tid();  // (icp_internal.h)
+    double(*lds)[NEQ] = reinterpret_cast<double(*)[NEQ]>(scratch);
+    double* total = scratch + 32 * NEQ;
+    int* failed = reinterpret_cast<int*>(total + NEQ);
+    if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();  // dev: entry | rows summed | solved and published
+    int done = 0, it = 0;
+    float pose_in[16], params_in[6];
+    if (threadIdx.x == 0) *failed = 0;
+    if (j == 0) {
+        done = st->done | (st->handoff_timeouts > 0 ? 1 : 0);  // (block-uniform, as in lead_solve)
+        if (threadIdx.x < 64) {
+            it = st->iter;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pose_in[k] = st->pose[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) params_in[k] = st->params[k];
+        }
+        sum_partials_vt<THREADS, true>(lead.prev_partials, lead.prev_rows, lead.prev_quad, total, lds);
+    } else {
+        __syncthreads();  // (*failed)
+        sum_tagged_rows_vt<THREADS>(tail_rows, nrows, gen - 1u, total, lds, wall_clock64() + lead.timeout_ticks, failed);
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pose_in[k] = carry_s[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) params_in[k] = carry_s[16 + k];
+            it = __float_as_int(carry_s[22]);
+        }
+    }
+    __syncthreads();
+    if (done) {  // the loop ended before this launch: its workgroups must hear it
+        if (threadIdx.x < BOX_USED) {
+            const int k = threadIdx.x;
+            box_store(lead.box, gen, k, k < 12 ? __float_as_uint(st->pose[k]) : (k == 12 ? 1u : (unsigned)st->iter));
+        }
+        return false;
+    }
+    if (*failed) {  // never seen: a workgroup of this launch is not running (a GPU shared with foreign work): the host re-runs
+        if (threadIdx.x == 0) atomicAdd(&st->handoff_timeouts, 1);  // the rest on per-iteration launches
+        return false;
+    }
+    if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
+    if (threadIdx.x < NEQ) lead.neq[threadIdx.x] = total[threadIdx.x];
+    if (threadIdx.x < 64) {
+        SolveOut o;
+        solve_and_update(st, total, ap, lead.loss_hist, lead.dx_hist, lead.hist_cap, it, pose_in, params_in, lead.box, gen, &o);
+        const int lane = threadIdx.x;  // every lane holds the same `o`: lane k parks element k
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (lane == k) v = o.pose[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (lane == 16 + k) v = o.params[k];
+        if (lane == 22) v = __int_as_float(it + 1);
+        if (lane < 23) carry_s[lane] = v;
+    }
+    if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+    __syncthreads();  // (carry_s; the scratch goes back to the searches)
+    return true;
+}
+
 // STATS: the dev instrumentation ("search_stats": path counters, phase stamps) is compiled into an instantiation of its
 // own; the product kernel carries none of it (72 s_memrealtime and their branches in a kernel that spills SGPRs).
-template <int MINW, int THREADS, int Q, bool STATS = false>
+// TAIL (the resident tail): ONE launch runs iterations in.iter .. in.iter + in.tail_iters - 1.  Every workgroup stays
+// resident and loops: pose of iteration i from the mailbox (generation lead.gen + i - in.iter) -> cache test / searches /
+// rows / block sums as in a launch of its own -> its super-row handed to the lead as TAGGED granules (solve_device.h) instead
+// of a store the next launch reads.  The lead workgroup loops with them (lead_solve<.., true>).  What a launch boundary
+// cost per late iteration — the dispatch of 257 workgroups, a cold L2 (the XCDs' L2s are invalidated at every kernel start:
+// 4.7 MB of fabric reads per launch for a working set that had not changed), the k_sum_solve launch behind the last
+// iteration — is paid once.  The workgroups wait for one another: all of them must be RESIDENT together (257 of the
+// 512-thread shape on 256 CUs); every wait has a wall-clock bound, and a wait that runs out (a GPU shared
+// with foreign work) ends the launch with RegState.handoff_timeouts raised — icp_register_end then re-runs what is left on
+// per-iteration launches and the context stops using the tail.
+// (the tail is built for MINW = 2: ONE workgroup per CU with the whole register file — the loop keeps the launch's uniform
+// state and per-lane addresses alive around the searches, which at 128 registers spilled 65 of them inside the cache test of
+// every iteration — so its lead cannot be a workgroup of its own beside 256 others: workgroup 0 is lead AND takes its share
+// of the queries, tail_lead_step in front of each of its iterations.)
+template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                    RegState* __restrict__ st, AlignParams ap,
                                                                    LeadArgs lead) {
@@ -1272,13 +1368,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     __shared__ float hist_s[CACHE_HIST][12];   // ... and of the CACHE_HIST iterations before it (slot = iteration % CACHE_HIST)
     __shared__ int ctl_s[4];                  // logical block | done | iteration | hand-off failures
     __shared__ int dbg_s[16];                 // dev-only ("search_stats" = 1): this workgroup's path counters
-    static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ) * sizeof(double), "the lead's scratch lives in the cell stacks");
+    __shared__ float carry_s[24];             // TAIL, workgroup 0: pose, parameters and iteration count from solve to solve
+    static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ + 1) * sizeof(double), "the lead's scratch lives in the cell stacks");
     // In a lead launch (LeadArgs) workgroup 0 is the lead: it solves the previous iteration and publishes the pose the
     // others poll for.  The hardware dispatches workgroups in ascending order, so whoever polls, polls for a workgroup
     // placed before it (a role ticket drawn from a counter would make that independent of the dispatch order — and costs
     // a thousand same-address device-scope atomics per launch, ~10 us: measured); should the order ever differ, the
     // wall-clock bound of the poll turns the wait into ICP_ERR_HIP instead of a hang.
-    const int lead_blocks = lead.box ? lead.solve : 0;
+    const int lead_blocks = (lead.box && !TAIL) ? lead.solve : 0;
     if (lead.box) {
         if ((int)blockIdx.x < lead_blocks) {  // block-uniform
             lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]),
@@ -1288,7 +1385,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     } else if (st->done) {
         return;  // classic launch behind the end of the loop (block-uniform)
     }
-    const long long t_entry = g.stamps ? wall_clock64() : 0;
+    long long t_entry = g.stamps ? wall_clock64() : 0;
     const int vb = logical_block(in, (int)blockIdx.x, lead_blocks);  // which queries, which partial row
     // which query a local slot stands for: the 128-query shape takes consecutive queries (one BASE row of the canonical sum,
     // solve_device.h); the 512-query shape takes FOUR base rows a quarter of the scan apart — base rows vb, vb + S, vb + 2S,
@@ -1302,13 +1399,31 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // ---- phase A, first half: everything that does not depend on the pose is requested now — target, cache entry and,
     // behind it, the cached neighbour and its normal (or the frame seed and its map point): in a lead launch these loads
     // are in flight while the lead workgroup solves
-    const int lq = threadIdx.x, qi = query_of(lq);
-    bool valid = false;
+    int* const dbg_global = g.dbg;
+    if (g.dbg) g.dbg = dbg_s;  // the search paths count into LDS (flat atomics); flushed, and stored per workgroup, at the end
+    // (TAIL: the poses of the iterations this launch runs come from the mailbox and are kept in hist_s by the workgroup
+    // itself — the lead's stores to pose_hist are for later launches and the host)
+    if (in.use_cache && (int)threadIdx.x < 12 * CACHE_HIST) {
+        const int e = threadIdx.x / 12, j = in.iter - 1 - e;  // iteration j, most recent first
+        if (j >= 0) hist_s[j % CACHE_HIST][threadIdx.x % 12] = in.pose_hist[(size_t)j * 12 + threadIdx.x % 12];
+    }
+    // what a query brings to its cache test — target, cache entry, the candidate set's points and normals: 32 registers.  The
+    // TAIL keeps them from trip to trip (it is built for 256 registers) and loads again only what a search has rewritten: in
+    // the late iterations, where every query hits, a trip reads nothing but the pose
+    bool valid = false, need_load = true;
     float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cn = cq, cq2 = cq, cn2 = cq,
            cq3 = cq, cn3 = cq;
     int4 c = make_int4(-1, 0, -1, -1);
     int seed_o = -1, seed_sp = -1;
-    if (lq < Q) {
+#pragma unroll 1
+    for (int tj = 0;; ++tj) {  // (one trip unless TAIL)
+    const LocalTid threadIdx = TAIL ? reloaded_tid() : LocalTid{::threadIdx.x};  // (icp_internal.h)
+    const int lq = threadIdx.x, qi = query_of(lq);
+    const int iter_now = in.iter + tj;  // (= the RegState's / the mailbox's iteration count while the loop is running)
+    const unsigned gen_now = lead.gen + (unsigned)tj;
+    if (lq < Q && need_load) {
+        need_load = false;
+        c = make_int4(-1, 0, -1, -1);
         valid = qi < in.n;
         if (valid) {
             t4 = in.tgt[qi];
@@ -1340,28 +1455,26 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             }
         }
     }
-    // the poses of the last CACHE_HIST iterations, for the cache test (written by the solves of EARLIER launches: plain
-    // loads, requested before the wait below like everything else that does not need this launch's pose)
-    if (in.use_cache && (int)threadIdx.x < 12 * CACHE_HIST) {
-        const int e = threadIdx.x / 12, j = in.iter - 1 - e;  // iteration j, most recent first
-        if (j >= 0) hist_s[j % CACHE_HIST][threadIdx.x % 12] = in.pose_hist[(size_t)j * 12 + threadIdx.x % 12];
-    }
+    // (the poses of the last CACHE_HIST iterations, for the cache test, were requested above: written by the solves of
+    // EARLIER launches, plain loads, in flight before the wait below like everything else that does not need this pose)
     // ---- the pose: from the mailbox (lead launch) or from the RegState (classic launch)
     if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
-    int* const dbg_global = g.dbg;
-    if (g.dbg) {  // the search paths count into LDS (flat atomics); flushed, and stored per workgroup, at the end
-        if (threadIdx.x < 16) dbg_s[threadIdx.x] = 0;
-        g.dbg = dbg_s;
-    }
+    if (dbg_global && threadIdx.x < 16) dbg_s[threadIdx.x] = 0;
     __syncthreads();
+    if (TAIL && blockIdx.x == 0) {  // (block-uniform) the lead: solve tj, published as generation gen_now, in front of its own share
+        if (!tail_lead_step<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]), carry_s, tj, gen_now, in.tail_rows,
+                                     (int)gridDim.x,
+                                     (g.stamps && iter_now < 24) ? g.stamps + 4 * ((size_t)iter_now * 1024 + 1023) : nullptr))
+            return;
+    }
     if (lead.box) {
         if (threadIdx.x < BOX_USED) {
-            const unsigned long long* p = box_granule(lead.box, lead.gen, vb % BOX_REPLICAS, threadIdx.x);
+            const unsigned long long* p = box_granule(lead.box, gen_now, vb % BOX_REPLICAS, threadIdx.x);
             const long long t0 = wall_clock64();
             unsigned long long v;
             for (;;) {
                 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(v >> 32) == lead.gen) break;
+                if ((unsigned)(v >> 32) == gen_now) break;
                 if (wall_clock64() - t0 > lead.timeout_ticks) {
                     atomicAdd(&ctl_s[3], 1);
                     break;
@@ -1384,7 +1497,6 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         return;
     }
     if (ctl_s[1]) return;  // the loop is finished (block-uniform)
-    const int iter_now = in.iter;  // (= the RegState's / the mailbox's iteration count while the loop is running)
     // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
     // counters
     long long* stamps = nullptr;
@@ -1408,24 +1520,25 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                     float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
                     float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     int hit_pos = c.x & CACHE_POS_MASK;
+                    float4 wq = cq, wn = cn;  // the winner (the set itself stays as loaded: the tail keeps it for the next trip)
                     // the candidate set: its nearest member is THE neighbour as long as everything else (>= L) stays farther
                     if (c.z >= 0) {
                         dx = cq2.x - px, dy = cq2.y - py, dz = cq2.z - pz;
                         const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                        if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(cq.w))) {
+                        if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(wq.w))) {
                             d2 = e2;
-                            cq = cq2;
-                            cn = cn2;
+                            wq = cq2;
+                            wn = cn2;
                             hit_pos = c.z;
                         }
                     }
                     if (c.w >= 0) {
                         dx = cq3.x - px, dy = cq3.y - py, dz = cq3.z - pz;
                         const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                        if (better(e2, __float_as_int(cq3.w), d2, __float_as_int(cq.w))) {
+                        if (better(e2, __float_as_int(cq3.w), d2, __float_as_int(wq.w))) {
                             d2 = e2;
-                            cq = cq3;
-                            cn = cn3;
+                            wq = cq3;
+                            wn = cn3;
                             hit_pos = c.w;
                         }
                     }
@@ -1434,13 +1547,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
                         const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta - in.refresh_margin;
+                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta - ((!TAIL || iter_now == in.refresh_at) ? in.refresh_margin : 0.f);
                     }
                     if (hit) {  // (nothing to write: the entry stays as the search left it)
-                        point_to_plane_row(px, py, pz, cq.x, cq.y, cq.z, cn.x, cn.y, cn.z, ap.scheme, ap.sigma, row);
+                        point_to_plane_row(px, py, pz, wq.x, wq.y, wq.z, wn.x, wn.y, wn.z, ap.scheme, ap.sigma, row);
                     } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
                         seed_d2 = d2;
-                        seed_idx = __float_as_int(cq.w);
+                        seed_idx = __float_as_int(wq.w);
                         seed_pos = hit_pos;
                     }
                 }
@@ -1451,6 +1564,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 seed_pos = seed_sp;
             }
             if (!hit) {
+                need_load = true;  // (TAIL: the search below rewrites this query's entry)
                 const int k = atomicAdd(&nmiss, 1);
                 miss_p[k] = make_float4(px, py, pz, __int_as_float(lq));
                 miss_seed[k] = make_int4(__float_as_int(seed_d2), seed_idx, seed_pos, 0);
@@ -1522,7 +1636,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         }
         __syncthreads();
     };
-    if (nmiss > 0) {  // block-uniform
+    // (the resident tail runs the late iterations — a handful of misses chip-wide: the whole-wave search, then the 4-lane
+    // groups; the ball search and the 16-lane search are not compiled into it: their registers would be live around its loop)
+    if (!TAIL && nmiss > 0) {  // block-uniform
         if (ball_lpq == 8) ball_phase(std::integral_constant<int, 8>{});
         else if (ball_lpq == 4) ball_phase(std::integral_constant<int, 4>{});
         else if (ball_lpq == 2) ball_phase(std::integral_constant<int, 2>{});
@@ -1534,7 +1650,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     // ---- phase BF (round 4, item 48): a few dozen queries left — too many for a wave each, too few to fill the workgroup
     // four lanes each: 16 lanes per query, THREADS / 16 queries at a time (search_far_w); nothing is left behind
-    if (Q != IT_QUERIES && in.far_lanes >= 16 && nmiss > in.far_min && nmiss <= in.far_max) {  // block-uniform
+    if (!TAIL && Q != IT_QUERIES && in.far_lanes >= 16 && nmiss > in.far_min && nmiss <= in.far_max) {  // block-uniform
         constexpr int W = 16;
         const int listed = nmiss, sub = (int)threadIdx.x % W;
         __syncthreads();
@@ -1632,7 +1748,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
-    block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
+    if (TAIL) {  // the super-row goes to the lead of THIS launch: tagged granules, no fence (solve_device.h)
+        const double v = block_reduce_rows<Q, true>(rowbuf, part, nullptr, vb);
+        if (threadIdx.x < NEQ) tagged_row_store(in.tail_rows, vb, threadIdx.x, gen_now, v);
+    } else {
+        block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
+    }
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
     if (stamps && !dbg_global && threadIdx.x == 0) {  // (top bits of stamps 3 / 0: queries left to B1 / B2, ticks of B0)
         stamps[3] |= (long long)min(dbg_s[12], 65535) << 48;
@@ -1645,6 +1766,22 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
             stamps[3] |= (long long)dbg_s[5] << 48;
             stamps[0] |= (long long)dbg_s[3] << 48;
         }
+    }
+    if (!TAIL) break;
+    if (tj + 1 >= in.tail_iters) {  // behind the last iteration: the solve a k_sum_solve launch used to carry out
+        if (blockIdx.x == 0) {
+            __syncthreads();
+            tail_lead_step<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]), carry_s, tj + 1, gen_now + 1u,
+                                    in.tail_rows, (int)gridDim.x,
+                                    (g.stamps && iter_now + 1 < 24) ? g.stamps + 4 * ((size_t)(iter_now + 1) * 1024 + 1023) : nullptr);
+        }
+        break;
+    }
+    // the next iteration of the tail: its pose history entry is the pose this one ran with (slot iter % CACHE_HIST held
+    // iteration iter - CACHE_HIST, which this iteration's cache test may still have read: hence behind the barriers above)
+    if (threadIdx.x < 12) hist_s[iter_now % CACHE_HIST][threadIdx.x] = pose_s[threadIdx.x];
+    if (g.stamps) t_entry = wall_clock64();
+    __syncthreads();  // (pose_s, ctl_s, rowbuf, part: read above, rewritten by the next trip)
     }
 }
 
@@ -2935,10 +3072,46 @@ bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
     return (use_cache || ctx->ball_search) && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
 }
 
-int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad) {
+// the most workgroups of the resident tail's shape the device holds at once (cached per context; 0: unknown -> no tail)
+static int tail_capacity(icp_ctx* ctx) {
+    if (ctx->tail_capacity < 0) {
+        int per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_compact<2, IT_THREADS, IT_THREADS, false, true>,
+                                                         IT_THREADS, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, ctx->cfg.device) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        ctx->tail_capacity = per_cu * cus;
+    }
+    return ctx->tail_capacity;
+}
+
+// may the launch of the NEXT iteration be a resident tail over `tail_iters` iterations?  (a lead launch of the plain
+// 512-query shape with rows to solve in front of it, every workgroup resident at once, the NN cache live)
+bool fused_tail_possible(icp_ctx* ctx, int prev_rows, int tail_iters) {
+    if (ctx->resident_tail <= 0 || ctx->tail_disabled || tail_iters < 2 || prev_rows <= 0) return false;
+    if (ctx->iter_in_registration < ctx->resident_tail || !fused_cache_mode(ctx) || !next_fused_launch_is_narrow(ctx)) return false;
+    if (ctx->iter_in_registration < ctx->wide_until && ctx->ball_search) return false;  // (the 1024-thread shape has no tail)
+    const int blocks = (int)((ctx->tgt_n + IT_THREADS - 1) / IT_THREADS);
+    return ctx->tgt_n > 0 && blocks <= tail_capacity(ctx) && blocks <= ctx->resident_tail_max_blocks;
+}
+
+// before the first launch of a registration of up to `iters` iterations: will its lead launches end in a resident tail?
+// (then a live stop threshold needs no chunked launches: the tail ends on the device when the loop does)
+bool fused_tail_planned(icp_ctx* ctx, int iters) {
+    if (ctx->resident_tail <= 0 || ctx->tail_disabled || !ctx->use_nn_cache || ctx->map_m >= (1 << 24) || ctx->tgt_n <= 0) return false;
+    const int from = (ctx->ball_search && ctx->wide_until > ctx->resident_tail) ? ctx->wide_until : ctx->resident_tail;
+    if (ctx->narrow_from < 0 || ctx->narrow_from > from || iters - from < 2) return false;
+    const int blocks = (int)((ctx->tgt_n + IT_THREADS - 1) / IT_THREADS);
+    return blocks <= tail_capacity(ctx) && blocks <= ctx->resident_tail_max_blocks;
+}
+
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad,
+                         int tail_iters) {
     const int n = (int)ctx->tgt_n;
     const int use_cache = fused_cache_mode(ctx);
     const bool narrow = next_fused_launch_is_narrow(ctx);
+    const bool tail = tail_iters > 0;  // (the caller has asked fused_tail_possible)
     const int per_block = narrow ? IT_THREADS : IT_QUERIES;
     const int blocks = n > 0 ? (n + per_block - 1) / per_block : 1;
     {
@@ -2966,6 +3139,13 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         lead.box = pose_box(ctx);
         lead.solve = prev_rows > 0 ? 1 : 0;
         lead.gen = lead.solve ? next_box_generation(ctx) : ctx->box_gen;  // the lead publishes it / already published
+        if (tail) {  // generations lead.gen .. lead.gen + tail_iters: one per iteration + the solve behind the last one
+            if (lead.gen > 0xffffffffu - (unsigned)tail_iters - 2u) {  // (no wrap inside a tail: tag 0 = never written)
+                ctx->box_gen = 0;
+                lead.gen = next_box_generation(ctx);
+            }
+            ctx->box_gen = lead.gen + (unsigned)tail_iters;
+        }
         lead.prev_partials = (const double*)(ctx->partials.as<char>() + (size_t)(parity ^ 1) * ctx->partials_half);
         lead.prev_rows = prev_rows;
         lead.prev_quad = prev_quad;
@@ -2976,7 +3156,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         lead.timeout_ticks = (long long)(ctx->lead_timeout_ms * 1.0e5);  // 100 MHz wall clock (option "lead_timeout_ms")
         ctx->partials_parity = parity ^ 1;
     }
-    const int grid = blocks + (lead_mode ? lead.solve : 0);
+    const int grid = blocks + ((lead_mode && !tail) ? lead.solve : 0);  // (the tail's lead is its workgroup 0)
     in.n = n;
     in.iter = ctx->iter_in_registration;
     in.mode = ctx->tgt_mode;
@@ -2986,13 +3166,24 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // 4-lane groups take up to 128 misses in 10-15 us — whole waves only for a handful)
     in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
     in.chunk_stride = narrow ? blocks : 0;  // (S = ceil(base rows / 4) = the number of 512-query workgroups)
+    in.tail_iters = tail ? tail_iters : 0;
+    in.refresh_at = ctx->refresh_at;
+    in.tail_rows = nullptr;
+    if (tail) {
+        const size_t need = (size_t)blocks * NEQ * 2 * sizeof(unsigned long long);
+        if (ctx->tail_rows.bytes < need) {  // (tag 0 belongs to no generation: a fresh allocation is zeroed)
+            ICP_HIP(ctx, ctx->tail_rows.reserve(need));
+            ICP_HIP(ctx, hipMemsetAsync(ctx->tail_rows.ptr, 0, ctx->tail_rows.bytes, ctx->stream));
+        }
+        in.tail_rows = ctx->tail_rows.as<unsigned long long>();
+    }
     in.ball = ctx->ball_search;
     in.ball_lanes = ctx->ball_lanes;
     in.far_lanes = ctx->far_lanes;
     in.far_max = min(ctx->far_max, IT_THREADS);
     in.far_min = ctx->far_min;
     in.ball_max = ctx->ball_max < BALL_MAX_CAND ? ctx->ball_max : BALL_MAX_CAND;
-    in.refresh_margin = ctx->iter_in_registration == ctx->refresh_at ? ctx->refresh_margin : 0.f;
+    in.refresh_margin = (tail || ctx->iter_in_registration == ctx->refresh_at) ? ctx->refresh_margin : 0.f;  // (a tail applies it in iteration `refresh_at` only)
     in.swz_bpr_shift = -1;
     in.swz_sectors = in.swz_band_rows = in.swz_row_blocks = 1;
     if (ctx->xcd_sectors && blocks >= 64 && blocks % 8 == 0) {
@@ -3024,7 +3215,13 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // same 512 queries, so every miss gets two (the slowest WAVE sets these launches: a lane that walks 200 candidates of a
     // dense cell alone); same super-rows, same bits
     const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search;
-    if (wide && ctx->search_stats)  // (dev: the instrumented instantiations exist for the two default shapes only)
+    if (tail && ctx->search_stats)
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, true, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (tail)
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
+                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (wide && ctx->search_stats)  // (dev: the instrumented instantiations exist for the two default shapes only)
         hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, true>), dim3(grid), dim3(2 * IT_THREADS), 0,
                            ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else if (narrow && ctx->search_stats)
@@ -3044,7 +3241,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     prof_end(ctx, tok);
     ICP_HIP(ctx, hipGetLastError());
-    ctx->iter_in_registration += 1;
+    ctx->iter_in_registration += tail ? tail_iters : 1;
     ctx->cache_fresh = true;
     ctx->cache_n = n;  // nn_cache now describes these targets against the current grid
     ctx->cache_m = ctx->map_m;

@@ -222,10 +222,12 @@ __device__ inline void solve_core(const double* __restrict__ neq, AlignParams ap
 __device__ inline void solve_and_update(RegState* __restrict__ st, const double* __restrict__ neq, AlignParams ap,
                                         double* __restrict__ loss_hist, float* __restrict__ dx_hist, int hist_cap,
                                         int it, const float* pose_in, const float* params_in,
-                                        unsigned long long* __restrict__ box = nullptr, unsigned gen = 0) {
+                                        unsigned long long* __restrict__ box = nullptr, unsigned gen = 0,
+                                        SolveOut* __restrict__ carry = nullptr) {
     float* __restrict__ pose_hist = ap.pose_hist;
     SolveOut o;
     solve_core(neq, ap, it, pose_in, params_in, o);
+    if (carry) *carry = o;  // (every lane: the resident tail's lead solves the next iteration from it, without reading the RegState back)
     if (box) {  // the pose mailbox first (workgroups of this very launch may be polling for it), one granule per lane
         const int lane = threadIdx.x & 63;
         float v = 0.f;
@@ -279,10 +281,11 @@ __device__ inline double load_super_row(const double* __restrict__ partials, int
     return (r0 + r1) + (r2 + r3);
 }
 
-template <int THREADS>
+template <int THREADS, bool RELOAD_TID = false>
 __device__ inline void sum_partials_vt(const double* __restrict__ partials, int nrows, int quad, double* out,
                                        double (*lds)[NEQ]) {
     static_assert(1024 % THREADS == 0, "virtual threads");
+    const LocalTid threadIdx = RELOAD_TID ? reloaded_tid() : LocalTid{::threadIdx.x};  // (icp_internal.h)
     const int ns = quad ? (nrows + 3) / 4 : nrows;  // super-rows
     if (!quad && ns == 256 && THREADS < 1024) {
         // 256 super-rows (a 131 072-point scan in the 512-query shape): every virtual thread makes exactly one eight-wide
@@ -335,6 +338,105 @@ __device__ inline void sum_partials_vt(const double* __restrict__ partials, int 
         }
         for (; b < ns; b += 32) s0 += load_super_row(partials, nrows, quad, b, col);
         lds[grp][col] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    }
+    __syncthreads();
+    if (threadIdx.x < NEQ) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += lds[g][threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Partial rows handed over INSIDE a launch (the resident tail of the fused iteration kernel, search.hip): a row is NEQ
+// doubles = 2 NEQ granules of 8 bytes, (tag << 32) | 32 payload bits (low half, high half), each written and read by ONE
+// relaxed agent-scope access — the data-tagged granule of the pose mailbox: no fence orders anything, a reader takes a
+// granule when its tag is the one it waits for (tag = the mailbox generation of the iteration that produced the row).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline void tagged_row_store(unsigned long long* __restrict__ rows, int row, int col, unsigned tag, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    unsigned long long* p = rows + ((size_t)row * NEQ + col) * 2;
+    __hip_atomic_store(p, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one element = both granules in ONE 16-byte load (agent-coherent: sc1, as the 8-byte atomic loads of the mailbox): the
+// lead pulls 256 rows x 32 elements per iteration, and it is the NUMBER of wave-level load instructions that bounds it
+// (1.7 us with two 8-byte loads per element, measured).  A 16-byte aligned load cannot tear inside an aligned 8-byte half.
+// Only the FIRST look at an element is such a load: an element that has not arrived yet is polled with the 8-byte atomic
+// loads of the mailbox — measured inside the fused kernel, a buffer load repeated in the spin loop kept returning the stale
+// element for the whole 50 ms of the wait (with and without the volatile bit; the same loop in a stand-alone kernel,
+// tools/dev/t/handoff_bench.hip, sees the new element after 2 us), the atomic loads see it at once.
+typedef unsigned int tagged_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t tagged_rows_rsrc(const unsigned long long* rows, int nrows) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(rows), 0, nrows * NEQ * 16, 0x00020000);
+}
+__device__ inline tagged_u32x4 tagged_pair_load(__amdgpu_buffer_rsrc_t rsrc, int row, int col) {
+    // (bit 31: volatile — the load is repeated in a spin loop and must not be hoisted out of it or merged with its predecessor)
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row * NEQ + col) * 16, 0, (int)0x80000010u /* sc1 | volatile */);
+}
+
+// polls one element until both granules carry `tag`; *failed is raised (and 0.0 returned) once `deadline` has passed
+__device__ inline double tagged_row_wait(const unsigned long long* __restrict__ rows, int row, int col, unsigned tag,
+                                         tagged_u32x4 v, long long deadline, int* __restrict__ failed) {
+    const unsigned long long* p = rows + ((size_t)row * NEQ + col) * 2;
+    for (;;) {
+        if (v.y == tag && v.w == tag) return __longlong_as_double((long long)(((unsigned long long)v.z << 32) | v.x));
+        if (wall_clock64() > deadline) {
+            *failed = 1;
+            return 0.0;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        // (the re-poll: two 8-byte agent-scope atomic loads, as the mailbox polls)
+        const unsigned long long lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.x = (unsigned)lo, v.y = (unsigned)(lo >> 32), v.z = (unsigned)hi, v.w = (unsigned)(hi >> 32);
+    }
+}
+
+// sum of `ns` tagged SUPER-rows in the canonical order of sum_partials_vt (quad = 0) -> out[NEQ]; the same bits as the
+// summing kernels form from plain rows.  *failed (LDS) is raised when a row did not arrive before `deadline`.
+template <int THREADS>
+__device__ inline void sum_tagged_rows_vt(const unsigned long long* __restrict__ rows, int ns, unsigned tag, double* out,
+                                          double (*lds)[NEQ], long long deadline, int* __restrict__ failed) {
+    static_assert(1024 % THREADS == 0, "virtual threads");
+    constexpr int V = 1024 / THREADS;
+    const LocalTid threadIdx = reloaded_tid();  // (icp_internal.h: this runs inside the loop of a persistent kernel)
+    const __amdgpu_buffer_rsrc_t rsrc = tagged_rows_rsrc(rows, ns);
+    if (ns == 256 && V <= 2) {
+        // (a 131 072-point scan: one eight-wide trip per virtual thread — all 8 V elements requested at once)
+        tagged_u32x4 q[V][8];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int v = threadIdx.x + k * THREADS, col = v & 31, grp = v >> 5;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[k][i] = tagged_pair_load(rsrc, grp + 32 * i, col);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int v = threadIdx.x + k * THREADS, col = v & 31, grp = v >> 5;
+            double x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = tagged_row_wait(rows, grp + 32 * i, col, tag, q[k][i], deadline, failed);
+            lds[grp][col] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        }
+    } else {
+#pragma unroll 1
+        for (int v = threadIdx.x; v < 1024; v += THREADS) {
+            const int col = v & 31, grp = v >> 5;
+            double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int b = grp;
+            for (; b + 224 < ns; b += 256) {
+                tagged_u32x4 q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = tagged_pair_load(rsrc, b + 32 * i, col);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += tagged_row_wait(rows, b + 32 * i, col, tag, q[i], deadline, failed);
+            }
+            for (; b < ns; b += 32) s[0] += tagged_row_wait(rows, b, col, tag, tagged_pair_load(rsrc, b, col), deadline, failed);
+            lds[grp][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
     }
     __syncthreads();
     if (threadIdx.x < NEQ) {

@@ -92,6 +92,7 @@ EXPORTED_SYMBOLS = {
     "icp_map_update_vertex_map": (_INT, [_P, _P, _P, _INT, C.POINTER(_I64)]),
     "icp_map_size": (_I64, [_P]),
     "icp_map_num_clouds": (_INT, [_P]),
+    "icp_handoff_fallbacks": (_INT, [_P]),
     "icp_map_get": (_INT, [_P, _P, _INT]),
     "icp_nearest_neighbor_search": (_INT, [_P, _P, _I64, _INT, _P, _P, _P, _INT]),
     "icp_last_neighbors": (_INT, [_P, _P, _P, _INT]),

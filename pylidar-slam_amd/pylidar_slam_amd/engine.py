@@ -330,6 +330,10 @@ class IcpContext:
     def map_num_clouds(self) -> int:
         return int(self._lib.icp_map_num_clouds(self._h))
 
+    def handoff_fallbacks(self) -> int:
+        """Registrations finished on per-iteration launches behind a timed-out hand-off (`icp_handoff_fallbacks`)."""
+        return int(self._lib.icp_handoff_fallbacks(self._h))
+
     def map_points(self) -> np.ndarray:
         out = np.empty((self.map_size(), 3), np.float32)
         if out.shape[0]:

@@ -86,38 +86,52 @@ def test_forced_iteration_loop_matches_the_reference_run_frame_by_frame(torch_cu
 
 @pytest.mark.parametrize("preprocessing", ["host", "device"])
 def test_published_configuration_loop_matches_the_reference_run(torch_cuda, golden_loop, loop_scans, preprocessing):
-    """The published configuration itself (live stop at |dx| < 1e-4, at most 20 iterations).  A stop decided within
-    float32 noise of the threshold moves a frame by up to the threshold — the step that one evaluation applies and the
-    other does not — and its successors with it (map and constant-velocity guess carry the difference on): inherent to
-    comparing two float evaluations of a thresholded loop, the reference on another CPU included.  Hence: every frame
-    within threshold + 1e-4 = 2e-4 m / 1e-4 rad of the reference's run, frames of equal iteration history within 1e-4 m,
-    and the trajectory metrics (ATE / ARE / segment translation error) equal to 2e-5."""
+    """The published configuration itself (live stop at |dx| < 1e-4, at most 20 iterations).  Every frame whose loop ran the
+    reference's number of iterations: within 1e-4 m / 1e-4 rad of the reference's run.  A frame may stop after another
+    number of iterations only where the REFERENCE's own stop was a close call, and by what it then differs is bounded by
+    what the reference measured there (tests/golden/loop_spread.npz, oracle/make_golden_loop_spread.py: |delta_pose| of
+    every iteration of the reference's run, and the same under three perturbations of its float evaluation): the deciding
+    |delta_pose| within 2 % of the threshold (frame 24: 1.0064e-4 — the reference's scalar and vector ATen paths move that
+    very number by 0.18 %), and the frame off by at most that step — the one evaluation applies it, the other does not
+    (icp_odometry.py:292-297) — plus the 1e-4 of a frame without a flip.  (Round 4 allowed a flat 2e-4 behind any flip:
+    argued, not measured.)  The trajectory metrics (ATE / ARE / segment translation error) equal to 2e-5."""
+    import os
     import icp_oracle as O
+    from conftest import GOLDEN
     g = golden_loop
+    spread = np.load(os.path.join(GOLDEN, "loop_spread.npz"))
+    assert bool(spread["base_reproduces_loop_reference"])  # the fixture describes the run loop_reference.npz holds
     scans, gt_abs = loop_scans
-    worst, iters_off, same_so_far, odo = (0.0, 0.0), 0, True, None
+    worst, flips, odo = (0.0, 0.0), [], None
     for f, d, odo in _drive(torch_cuda, scans, published_config(), preprocessing):
         assert int(d["sample_points"].shape[0]) == int(g["samples"][f])
         if f == 0:
             continue
         dt, dr = O.pose_error(d["odometry_pose"], g["rel"][f])
         worst = (max(worst[0], dt), max(worst[1], dr))
-        same = odo.last_result.iterations == int(g["iters"][f])
-        iters_off += int(not same)
-        same_so_far = same_so_far and same
-        assert dt < (1e-4 if same_so_far else 2e-4) and dr < 1e-4, (preprocessing, f, dt, dr, same_so_far)
+        ours, theirs = int(odo.last_result.iterations), int(g["iters"][f])
+        bound = 1e-4
+        if ours != theirs:
+            margin = float(spread["stop_margin"][f])
+            step = float(spread["base_dx_norm"][f, min(ours, theirs) - 1])  # the step one loop applied and the other did not
+            flips.append((f, ours, theirs, margin, step, dt))
+            assert abs(ours - theirs) == 1 and margin < 0.02, (preprocessing, f, ours, theirs, margin)
+            bound = 1e-4 + step
+        assert dt < bound and dr < 1e-4, (preprocessing, f, dt, dr, ours, theirs)
         assert abs(odo.ctx.map_size() - int(g["map_sizes"][f])) <= 2, (f, odo.ctx.map_size(), int(g["map_sizes"][f]))
     assert odo.ctx.map_num_clouds() == 30
+    assert odo.ctx.handoff_fallbacks() == 0  # (no hand-off of the lead launches may have timed out: it would be repaired silently)
     rel = odo.get_relative_poses()
     ate, are, tr, rot, n = trajectory_metrics(rel, gt_abs, g["segments"])
     assert n == int(g["num_segments"])
     print(f"loop ({preprocessing} preprocessing): worst frame {worst[0]:.1e} m / {worst[1]:.1e} rad vs the reference; ATE "
           f"{ate:.4e} (reference {g['ate'][0]:.4e}) m, tr_err {tr:.4e} ({g['kitti'][0]:.4e}) m/m, r_err {rot:.4e} "
-          f"({g['kitti'][1]:.4e}) rad/m; frames with another iteration count: {iters_off}")
+          f"({g['kitti'][1]:.4e}) rad/m; frames with another iteration count (frame, ours, reference's, the reference's "
+          f"stop margin, the step, |dt|): {flips}")
     assert abs(ate - g["ate"][0]) < 2e-5 and abs(are - g["are"][0]) < 2e-5
     assert abs(tr - g["kitti"][0]) < 2e-5
     # the segment ROTATION error is arccos((trace - 1) / 2) of float32 pose products: at 1e-4 rad it sits below the
     # sqrt(float32 epsilon) = 3e-4 rad noise floor of that formula (the reference's own figure is noise too), so it is
     # bounded, not compared; ARE above (linear in the error) is the rotation figure that is compared
     assert rot < 1e-3 and g["kitti"][1] < 1e-3
-    assert iters_off <= 6
+    assert len(flips) <= 3

@@ -364,6 +364,12 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 # what the ball search hands back: 4 lanes / a wave each (far_lanes 0), 16 lanes however many, ... and a small ball cap
                 "no_far_lanes": {"far_lanes": 0}, "far_lanes_two_passes": {"far_max": 512},
                 "far_lanes_small_balls": {"far_max": 512, "ball_max": 16},
+                # the resident tail (off by default) from iteration 3, 1, 5 and 11 (one iteration left: no tail)
+                "tail_from_3": {"resident_tail": 3}, "tail_from_1": {"resident_tail": 1, "wide_until": 0},
+                "tail_from_5": {"resident_tail": 5}, "tail_from_11": {"resident_tail": 11},
+                "tail_no_cache_seed": {"resident_tail": 3, "nn_cache": 1},
+                "tail_no_guard": {"resident_tail": 3, "prune_guard": 0.0, "refresh_margin": 0.0},
+                "tail_small_scans_only": {"resident_tail": 3, "resident_tail_max_blocks": 8},  # (this scan has 64 workgroups: no tail)
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -381,6 +387,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
             init = r.pose
         _, nrm, _ = ctx.nearest_neighbor_search(scans[6][::7])
         results[name] = (frames, ctx.map_points(), nrm)
+        assert ctx.handoff_fallbacks() == 0, name  # (a hand-off that timed out would be repaired silently: same bits, 50 ms late)
         ctx.close()
     with pytest.raises(AssertionError):
         c = _ctx()
@@ -434,6 +441,45 @@ def test_lazy_and_eager_normals_give_the_same_registration(torch_cuda):
         assert got["eager"].iterations == got["lazy"].iterations
         np.testing.assert_allclose(got["lazy"].pose, got["eager"].pose, atol=2e-7)
         np.testing.assert_allclose(got["lazy"].losses, got["eager"].losses, rtol=1e-6)
+
+
+def test_timed_out_handoff_finishes_on_per_iteration_launches(torch_cuda):
+    """The resident tail and the lead launches wait for one another inside a launch; every wait has a wall-clock bound
+    ("lead_timeout_ms").  With the bound at one tick of the clock the first wait that is not served at once runs out: the
+    registration must be FINISHED on per-iteration launches — same poses, losses and steps bit for bit as the schedule
+    without hand-offs — the pose-only map update enqueued behind it must move the map by the FINAL pose, the context must
+    keep to per-iteration launches afterwards (`icp_handoff_fallbacks` counts once), with the forced iteration count and
+    with a live stop threshold."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_fixed_map, make_sequence
+    cfg = SceneConfig(height=32, width=1024)
+    scans, poses = make_sequence(cfg, 7)
+    model = make_fixed_map(cfg, scans[:4], poses[:4], ref_frame=3, num_points=30_000)
+    for threshold in (0.0, 1.0e-4):
+        got = {}
+        for name, opts in (("plain", {"lead_solve": 0}), ("timed_out", {"lead_timeout_ms": 1.0e-5, "resident_tail": 3}),
+                           ("timed_out_no_tail", {"lead_timeout_ms": 1.0e-5})):
+            ctx = _ctx(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=threshold, scheme="geman_mcclure",
+                       sigma=0.3)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.map_set(model)
+            frames, init = [], None
+            for f in (4, 5, 6):
+                ctx.register_launch(scans[f], init)
+                ctx.map_update(None, None)
+                r = ctx.register_end()
+                frames.append(r)
+                init = r.pose
+            got[name] = (frames, ctx.map_points(), ctx.handoff_fallbacks())
+            ctx.close()
+        assert got["plain"][2] == 0
+        for name in ("timed_out", "timed_out_no_tail"):
+            frames, mp, fallbacks = got[name]
+            assert fallbacks == 1, (name, fallbacks)  # the first frame fell back, the context kept to plain launches
+            for r, ref in zip(frames, got["plain"][0]):
+                assert r.iterations == ref.iterations and r.converged == ref.converged
+                assert np.array_equal(r.pose, ref.pose) and np.array_equal(r.losses, ref.losses) and np.array_equal(r.dx, ref.dx)
+            assert np.array_equal(mp, got["plain"][1])
 
 
 def test_carried_normals_equal_reestimated_ones(torch_cuda):
@@ -734,7 +780,9 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
                 "no_far_lanes": {"far_lanes": 0}, "far_lanes_many": {"far_max": 512},
                 "far_lanes_small_balls": {"far_max": 512, "ball_max": 32},
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
-                "round3": {"ball_search": 0, "narrow_from": 3}}
+                "round3": {"ball_search": 0, "narrow_from": 3},
+                # round 4's schedule (a launch per iteration) / the resident tail from iteration 7
+                "tail_from_3": {"resident_tail": 3}, "tail_from_7": {"resident_tail": 7}}  # the resident tail (off by default)
     results = {}
     for name, opts in variants.items():
         ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0, scheme="geman_mcclure",
@@ -754,6 +802,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
         ix, pose12 = ctx.last_neighbors(scans[7].shape[0])
         _, nrm, _ = ctx.nearest_neighbor_search(scans[7][::13])
         results[name] = (frames, ix, pose12, nrm, ctx.map_points())
+        assert ctx.handoff_fallbacks() == 0, name
         ctx.close()
     ref = results["default"]
     problems = []
