@@ -226,6 +226,17 @@ int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double vo
 int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                         double* points_out, int64_t* count_out, int out_mem);
 
+/* The same selections for the DEVICE-RESIDENT pipeline (device pointers only; no reference counterpart beyond GridSample
+ * itself): nothing is read back to the host — no synchronisation, every launch asynchronous on the context's stream.  The
+ * outputs hold n rows: the V samples first (ascending int64 hash, as above), then NaN points and index -1; V goes to
+ * *count_out, a DEVICE int32 (NULL: not reported).  Consumers that mask NaN rows — icp_project, the registration entry
+ * points, icp_map_stage_cloud / icp_map_update — take the padded array as it is: a frame then needs ONE synchronisation, the
+ * one that hands its pose to the host. */
+int icp_grid_sample_padded(icp_ctx* ctx, const float* xyz, int64_t n, double voxel_size, int64_t* indices_out,
+                           float* points_out, int32_t* count_out);
+int icp_grid_sample_padded_f64(icp_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices_out,
+                               double* points_out, int32_t* count_out);
+
 /* Voxelization.filter / voxel_normal_distribution (slam/preprocessing.py:63-98, slam/common/pointcloud.py:83-167):
  * voxel coordinates [n,3] and hashes [n] (optional), voxel_ids_out [n] = rank of the point's hash among the distinct
  * hashes, *num_voxels_out = V, and (all three or none) sizes_out [V] int64 point counts, means_out [V,3] float32,

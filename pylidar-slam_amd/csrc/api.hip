@@ -588,6 +588,41 @@ int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, dou
     return ICP_OK;
 }
 
+// the device-resident pipeline's grid sample: nothing comes back to the host (see include/icp_mi355x.h)
+static int grid_sample_padded(icp_ctx* ctx, const void* xyz, int64_t n, double voxel_size, int64_t* indices_out,
+                              void* points_out, int32_t* count_out, size_t elem) {
+    if (!ctx || n < 0 || !(voxel_size > 0) || (n > 0 && (!xyz || !points_out))) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    int* count_dev = count_out ? (int*)count_out : ctx->counter.as<int>();
+    if (n == 0) {
+        ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
+        return ICP_OK;
+    }
+    // rows behind the V samples: NaN points (0xFFFFFFFF / 0xFFFFFFFFFFFFFFFF are NaNs), index -1
+    ICP_HIP(ctx, hipMemsetAsync(points_out, 0xFF, (size_t)n * 3 * elem, ctx->stream));
+    if (indices_out) ICP_HIP(ctx, hipMemsetAsync(indices_out, 0xFF, (size_t)n * 8, ctx->stream));
+    int unused = 0;
+    if (elem == 4)
+        return grid_sample_device(ctx, (const float*)xyz, n, voxel_size, (long long*)indices_out, (float*)points_out, count_dev,
+                                  &unused, true);
+    return grid_sample_f64_device(ctx, (const double*)xyz, n, voxel_size, (long long*)indices_out, (double*)points_out,
+                                  count_dev, &unused, true);
+}
+
+int icp_grid_sample_padded(icp_ctx* ctx, const float* xyz, int64_t n, double voxel_size, int64_t* indices_out,
+                           float* points_out, int32_t* count_out) {
+    DeviceGuard device_guard(ctx);
+    return grid_sample_padded(ctx, xyz, n, voxel_size, indices_out, points_out, count_out, sizeof(float));
+}
+
+int icp_grid_sample_padded_f64(icp_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices_out,
+                               double* points_out, int32_t* count_out) {
+    DeviceGuard device_guard(ctx);
+    return grid_sample_padded(ctx, xyz, n, voxel_size, indices_out, points_out, count_out, sizeof(double));
+}
+
 int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                         double* points_out, int64_t* count_out, int out_mem) {
     DeviceGuard device_guard(ctx);

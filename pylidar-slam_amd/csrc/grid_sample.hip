@@ -220,9 +220,346 @@ __global__ void k_emit_sorted(const T* __restrict__ xyz, const int* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sort of the V distinct (hash, index) pairs + emission of the samples in ONE launch of ONE workgroup, V read on the
+// device: no host round trip to size a library sort, no library kernels in the frame (five rocPRIM launches
+// and two synchronisations per grid sample for ~6 000 pairs).  LSD radix sort over the bits in which the keys differ
+// (key - min: a LiDAR frame's hashes span ~2^37, five 8-bit passes instead of eight), pairs ping-ponging between two
+// global buffers (L2-resident), per-pass: every wave owns a contiguous chunk, counts its digits tile by tile (64 pairs; the
+// lanes of a tile with the same digit found by eight ballots), one scan over (digit, wave) gives every wave its bases,
+// the waves scatter their tiles in the same order — stable.  ~5 us per pass at V = 6 000; any V is sorted (a workgroup's
+// worth of threads per pass: meant for thousands of voxels — the exact-shape entry point hands V > 32 768 to rocPRIM).
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int SORT_THREADS = 1024;
+static constexpr int SORT_WAVES = SORT_THREADS / 64;
+
+template <typename T>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_emit(unsigned long long* __restrict__ ka, int* __restrict__ va,
+                                                            unsigned long long* __restrict__ kb, int* __restrict__ vb,
+                                                            const int* __restrict__ side, const T* __restrict__ xyz,
+                                                            long long* __restrict__ indices, T* __restrict__ points,
+                                                            int* __restrict__ count_out) {
+    __shared__ int hist[SORT_WAVES][256];
+    __shared__ unsigned long long red[2][SORT_WAVES];
+    __shared__ int wave_tot[SORT_WAVES];
+    const int V = side[1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (count_out && tid == 0) *count_out = V;
+    if (V <= 0) return;
+    // ---- the bits in which the keys differ
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int i = tid; i < V; i += SORT_THREADS) {
+        const unsigned long long k = ka[i];
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = ((unsigned long long)__shfl_xor((unsigned)(kmin >> 32), o, 64) << 32) | __shfl_xor((unsigned)kmin, o, 64);
+        const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(kmax >> 32), o, 64) << 32) | __shfl_xor((unsigned)kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) {
+        red[0][w] = kmin;
+        red[1][w] = kmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < SORT_WAVES; ++k) {
+        kmin = red[0][k] < kmin ? red[0][k] : kmin;
+        kmax = red[1][k] > kmax ? red[1][k] : kmax;
+    }
+    const unsigned long long range = kmax - kmin;
+    const int bits = range ? 64 - __clzll((long long)range) : 0, passes = (bits + 7) / 8;
+    // every wave's chunk: a whole number of 64-pair tiles
+    const int tiles_total = (V + 63) / 64, tiles_per_wave = (tiles_total + SORT_WAVES - 1) / SORT_WAVES;
+    const int first = w * tiles_per_wave * 64;
+    int last = first + tiles_per_wave * 64;
+    last = last < V ? last : V;
+    unsigned long long* src_k = ka;
+    unsigned long long* dst_k = kb;
+    int* src_v = va;
+    int* dst_v = vb;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes in front of this one
+    constexpr int REG_TILES = 8;  // up to 8 x 64 pairs per wave (V <= 8192) stay in registers through a pass
+    const bool in_regs = tiles_per_wave <= REG_TILES;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        for (int k = tid; k < SORT_WAVES * 256; k += SORT_THREADS) (&hist[0][0])[k] = 0;
+        if (in_regs) {
+            // every pair of the wave's chunk is requested at once — ONE memory latency per pass instead of one per tile and
+            // phase (six tiles, two phases: 83 us for 6 000 pairs in five passes, measured) — and kept for the scatter
+            unsigned long long key[REG_TILES];
+            int val[REG_TILES];
+#pragma unroll
+            for (int t = 0; t < REG_TILES; ++t) {
+                const int i = first + t * 64 + lane;
+                key[t] = 0ull;
+                val[t] = 0;
+                if (i < last) {
+                    key[t] = src_k[i];
+                    val[t] = src_v[i];
+                }
+            }
+            __syncthreads();
+            unsigned long long same[REG_TILES];
+#pragma unroll
+            for (int t = 0; t < REG_TILES; ++t) {
+                const bool valid = first + t * 64 + lane < last;
+                const unsigned d = (unsigned)(((key[t] - kmin) >> shift) & 255ull);
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const unsigned long long bb = __ballot(valid && ((d >> b) & 1u));
+                    m &= ((d >> b) & 1u) ? bb : ~bb;
+                }
+                same[t] = valid ? m : 0ull;
+                if (valid && (m & below) == 0ull) hist[w][d] += __popcll(m);
+            }
+            __syncthreads();
+            {
+                int v4[4], sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int L = 4 * tid + k;
+                    v4[k] = hist[L % SORT_WAVES][L / SORT_WAVES];
+                    sum += v4[k];
+                }
+                int incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t2 = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t2;
+                }
+                if (lane == 63) wave_tot[w] = incl;
+                __syncthreads();
+                int off = incl - sum;
+                for (int k = 0; k < w; ++k) off += wave_tot[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int L = 4 * tid + k;
+                    hist[L % SORT_WAVES][L / SORT_WAVES] = off;
+                    off += v4[k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < REG_TILES; ++t) {
+                const bool valid = same[t] != 0ull;
+                const unsigned d = (unsigned)(((key[t] - kmin) >> shift) & 255ull);
+                const int start = valid ? hist[w][d] : 0;
+                const int rank = __popcll(same[t] & below);
+                if (valid) {
+                    dst_k[start + rank] = key[t];
+                    dst_v[start + rank] = val[t];
+                    if (rank == 0) hist[w][d] = start + __popcll(same[t]);
+                }
+            }
+            __syncthreads();
+            unsigned long long* tk = src_k;
+            src_k = dst_k;
+            dst_k = tk;
+            int* tv = src_v;
+            src_v = dst_v;
+            dst_v = tv;
+            continue;
+        }
+        __syncthreads();
+        for (int base = first; base < last; base += 64) {  // (wave-uniform bounds)
+            const int i = base + lane;
+            const bool valid = i < last;
+            const unsigned d = valid ? (unsigned)(((src_k[i] - kmin) >> shift) & 255ull) : 0u;
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bb = __ballot(valid && ((d >> b) & 1u));
+                same &= ((d >> b) & 1u) ? bb : ~bb;
+            }
+            if (valid && (same & below) == 0ull) hist[w][d] += __popcll(same);  // the first lane of every digit group
+        }
+        __syncthreads();
+        // exclusive scan over (digit major, wave minor): linear index L = d * SORT_WAVES + wave, four consecutive L per thread
+        {
+            int v4[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = 4 * tid + k;
+                v4[k] = hist[L % SORT_WAVES][L / SORT_WAVES];
+                sum += v4[k];
+            }
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wave_tot[w] = incl;
+            __syncthreads();
+            int off = incl - sum;
+            for (int k = 0; k < w; ++k) off += wave_tot[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = 4 * tid + k;
+                hist[L % SORT_WAVES][L / SORT_WAVES] = off;
+                off += v4[k];
+            }
+        }
+        __syncthreads();
+        for (int base = first; base < last; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < last;
+            unsigned long long key = 0ull;
+            int val = 0;
+            if (valid) {
+                key = src_k[i];
+                val = src_v[i];
+            }
+            const unsigned d = valid ? (unsigned)(((key - kmin) >> shift) & 255ull) : 0u;
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bb = __ballot(valid && ((d >> b) & 1u));
+                same &= ((d >> b) & 1u) ? bb : ~bb;
+            }
+            const int start = valid ? hist[w][d] : 0;  // (every lane of the group reads it before its first lane moves it on)
+            const int rank = __popcll(same & below);
+            if (valid) {
+                dst_k[start + rank] = key;
+                dst_v[start + rank] = val;
+                if (rank == 0) hist[w][d] = start + __popcll(same);
+            }
+        }
+        __syncthreads();  // (the pairs written above are read by other waves in the next pass: workgroup-scope release / acquire)
+        unsigned long long* tk = src_k;
+        src_k = dst_k;
+        dst_k = tk;
+        int* tv = src_v;
+        src_v = dst_v;
+        dst_v = tv;
+    }
+    // ---- the samples, by ascending hash: original index + gathered point
+    for (int o = tid; o < V; o += SORT_THREADS) {
+        const int src = src_v[o];
+        if (indices) indices[o] = src;
+        if (points) {
+            points[3 * o] = xyz[3 * src];
+            points[3 * o + 1] = xyz[3 * src + 1];
+            points[3 * o + 2] = xyz[3 * src + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same result from BUCKET_BLOCKS workgroups in one launch (round 5: the one-workgroup radix sort above is a chain of five
+// passes of load -> count -> scan -> scatter, 72 us for 6 000 pairs, whatever is kept in registers).  Every workgroup reads
+// ALL V pairs (72 KB from L2), finds the keys' range, keeps the pairs of ITS slice of that range — slice b = (key - min)
+// >> shift, monotone in the key — in LDS and counts the pairs of the slices below it; a member's place in the output is
+// that count + its rank among the members (a compare against every member: a slice holds V / 64 pairs, ~100).  No
+// ordering between workgroups, no atomics on global memory, V read on the device.  A slice that outgrows the LDS list (a
+// degenerate key distribution) is ranked against all V keys instead: slow, correct.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int BUCKET_BLOCKS = 64;
+static constexpr int BUCKET_THREADS = 512;
+static constexpr int BUCKET_CAP = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(BUCKET_THREADS) void k_bucket_sort_emit(const unsigned long long* __restrict__ keys,
+                                                                     const int* __restrict__ vals,
+                                                                     const int* __restrict__ side, const T* __restrict__ xyz,
+                                                                     long long* __restrict__ indices, T* __restrict__ points,
+                                                                     int* __restrict__ count_out) {
+    __shared__ unsigned long long mk[BUCKET_CAP];
+    __shared__ int mv[BUCKET_CAP];
+    __shared__ unsigned long long red[2][BUCKET_THREADS / 64];
+    __shared__ int lower_s[BUCKET_THREADS / 64];
+    __shared__ int members;
+    const int V = side[1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, me = blockIdx.x;
+    if (count_out && me == 0 && tid == 0) *count_out = V;
+    if (V <= 0) return;
+    if (tid == 0) members = 0;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int i = tid; i < V; i += BUCKET_THREADS) {
+        const unsigned long long k = keys[i];
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = ((unsigned long long)__shfl_xor((unsigned)(kmin >> 32), o, 64) << 32) | __shfl_xor((unsigned)kmin, o, 64);
+        const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(kmax >> 32), o, 64) << 32) | __shfl_xor((unsigned)kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) {
+        red[0][w] = kmin;
+        red[1][w] = kmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < BUCKET_THREADS / 64; ++k) {
+        kmin = red[0][k] < kmin ? red[0][k] : kmin;
+        kmax = red[1][k] > kmax ? red[1][k] : kmax;
+    }
+    const unsigned long long range = kmax - kmin;
+    const int bits = range ? 64 - __clzll((long long)range) : 0;
+    const int shift = bits > 6 ? bits - 6 : 0;  // (range >> shift) < 64 = BUCKET_BLOCKS slices
+    // ---- my slice's members into LDS, the pairs of lower slices counted
+    int lower = 0;
+    for (int i = tid; i < V; i += BUCKET_THREADS) {
+        const unsigned long long k = keys[i];
+        const int b = (int)((k - kmin) >> shift);
+        lower += b < me ? 1 : 0;
+        if (b == me) {
+            const int slot = atomicAdd(&members, 1);
+            if (slot < BUCKET_CAP) {
+                mk[slot] = k;
+                mv[slot] = vals[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o, 64);
+    if (lane == 0) lower_s[w] = lower;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < BUCKET_THREADS / 64; ++k) base += lower_s[k];
+    const int m = members;
+    if (m <= BUCKET_CAP) {
+        for (int i = tid; i < m; i += BUCKET_THREADS) {
+            const unsigned long long k = mk[i];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += mk[j] < k ? 1 : 0;  // (the keys are distinct hashes)
+            const int o = base + rank, src = mv[i];
+            if (indices) indices[o] = src;
+            if (points) {
+                points[3 * o] = xyz[3 * src];
+                points[3 * o + 1] = xyz[3 * src + 1];
+                points[3 * o + 2] = xyz[3 * src + 2];
+            }
+        }
+        return;
+    }
+    // ---- a slice larger than the list (never seen on LiDAR frames): every member ranked against all V keys
+    for (int i = tid; i < V; i += BUCKET_THREADS) {
+        const unsigned long long k = keys[i];
+        if ((int)((k - kmin) >> shift) != me) continue;
+        int rank = 0;
+        for (int j = 0; j < V; ++j) rank += keys[j] < k ? 1 : 0;
+        const int src = vals[i];
+        if (indices) indices[rank] = src;
+        if (points) {
+            points[3 * rank] = xyz[3 * src];
+            points[3 * rank + 1] = xyz[3 * src + 1];
+            points[3 * rank + 2] = xyz[3 * src + 2];
+        }
+    }
+}
+
+// padded = true: nothing is read back — the outputs hold n rows, the V samples first, NaN points / index -1 behind them
+// (the caller filled them with 0xFF bytes), *count_dev = V on the device only
 template <typename T>
 static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                            T* points_dev, int* count_dev, int* count_host) {
+                            T* points_dev, int* count_dev, int* count_host, bool padded = false) {
     *count_host = 0;
     if (n <= 0) {
         ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
@@ -248,13 +585,29 @@ static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double vo
                        side);
     hipLaunchKernelGGL(k_hash_collect, dim3(COLLECT_BLOCKS), dim3(COLLECT_THREADS), 0, ctx->stream, table, tsize, side,
                        ka, va);
-    // the number of pairs is only known on the device: the host needs it to size the sort (and returns it anyway)
+    if (padded) {  // the device-resident pipeline: one more launch, nothing read back
+        if (n <= 262144)  // (every workgroup reads all pairs: thousands of voxels — a frame; beyond: the one-workgroup radix sort)
+            hipLaunchKernelGGL(k_bucket_sort_emit<T>, dim3(BUCKET_BLOCKS), dim3(BUCKET_THREADS), 0, ctx->stream, ka, va, side,
+                               xyz_dev, indices_dev, points_dev, count_dev);
+        else
+            hipLaunchKernelGGL(k_sort_emit<T>, dim3(1), dim3(SORT_THREADS), 0, ctx->stream, ka, va, kb, vb, side, xyz_dev,
+                               indices_dev, points_dev, count_dev);
+        ICP_HIP(ctx, hipGetLastError());
+        *count_host = -1;
+        return ICP_OK;
+    }
+    // exact shapes: the host hands back V rows, so it needs V (one round trip; it also picks the sort)
     int v = 0;
     ICP_HIP(ctx, hipMemcpyAsync(&v, side + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ICP_HIP(ctx, hipMemcpyAsync(count_dev, side + 1, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     *count_host = v;
-    if (v <= 0) return ICP_OK;
+    if (v <= 32768) {  // thousands of voxels: the in-tree bucket sort (no library launches in the frame)
+        hipLaunchKernelGGL(k_bucket_sort_emit<T>, dim3(BUCKET_BLOCKS), dim3(BUCKET_THREADS), 0, ctx->stream, ka, va, side,
+                           xyz_dev, indices_dev, points_dev, count_dev);
+        ICP_HIP(ctx, hipGetLastError());
+        return ICP_OK;
+    }
+    ICP_HIP(ctx, hipMemcpyAsync(count_dev, side + 1, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     size_t tmp_bytes = 0;
     ICP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, va, vb, (size_t)v, 0, 64, ctx->stream));
     ICP_HIP(ctx, ctx->sort_tmp.reserve(tmp_bytes));
@@ -267,13 +620,13 @@ static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double vo
 }
 
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                       float* points_dev, int* count_dev, int* count_host) {
-    return grid_sample_impl<float>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host);
+                       float* points_dev, int* count_dev, int* count_host, bool padded) {
+    return grid_sample_impl<float>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host, padded);
 }
 
 int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                           double* points_dev, int* count_dev, int* count_host) {
-    return grid_sample_impl<double>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host);
+                           double* points_dev, int* count_dev, int* count_host, bool padded) {
+    return grid_sample_impl<double>(ctx, xyz_dev, n, voxel, indices_dev, points_dev, count_dev, count_host, padded);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -518,7 +518,7 @@ int pmap_associate(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows9_d
 int voxel_hash_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                       long long* hashes_dev);
 int grid_sample_f64_device(icp_ctx* ctx, const double* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                           double* points_dev, int* count_dev, int* count_host);
+                           double* points_dev, int* count_dev, int* count_host, bool padded = false);
 int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int64_t n, const double* rel_pose16,
                    double* out_dev);
 // targets -> float4 rows (x, y, z, bits(row)) in ctx->tgt4
@@ -529,7 +529,7 @@ int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, doubl
                             long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
                             float* covs_dev, int* count_dev);
 int grid_sample_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* indices_dev,
-                       float* points_dev, int* count_dev, int* count_host);
+                       float* points_dev, int* count_dev, int* count_host, bool padded = false);
 
 // ---- profiling helpers (api.hip)
 int prof_begin(icp_ctx* ctx, int kind, int iter = -1);  // iter: index of the ICP iteration (search kernel)

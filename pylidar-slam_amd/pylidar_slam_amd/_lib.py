@@ -83,6 +83,8 @@ EXPORTED_SYMBOLS = {
     "icp_grid_sample": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, C.POINTER(_I64), _INT]),
     "icp_voxel_hash": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, _INT]),
     "icp_grid_sample_f64": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, C.POINTER(_I64), _INT]),
+    "icp_grid_sample_padded": (_INT, [_P, _P, _I64, C.c_double, _P, _P, _P]),
+    "icp_grid_sample_padded_f64": (_INT, [_P, _P, _I64, C.c_double, _P, _P, _P]),
     "icp_distort": (_INT, [_P, _P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_map_init": (_INT, [_P]),
     "icp_map_set": (_INT, [_P, _P, _I64, _INT]),

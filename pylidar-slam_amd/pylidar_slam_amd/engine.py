@@ -209,6 +209,23 @@ class IcpContext:
                                               pts.ctypes.data, C.byref(count), MEM_HOST))
         return pts[:count.value].copy(), idx[:count.value].copy()
 
+    def grid_sample_padded(self, points: "torch.Tensor", voxel_size: float):
+        """The grid sample of the device-resident pipeline (`icp_grid_sample_padded[_f64]`): a cuda tensor in, and —
+        without any synchronisation — (points [n,3] with the V samples first and NaN rows behind them, indices [n] int64
+        with -1 behind the samples, V as a 0-dim int32 cuda tensor) out."""
+        self._bind(points)
+        if not (isinstance(points, torch.Tensor) and points.is_cuda):
+            raise AssertionError("grid_sample_padded takes a cuda tensor (the device-resident pipeline)")
+        f64 = points.dtype == torch.float64
+        t = points.contiguous() if f64 else points.to(torch.float32).contiguous()
+        n = int(t.shape[0])
+        idx = torch.empty(max(n, 1), dtype=torch.int64, device=t.device)
+        out = torch.empty((max(n, 1), 3), dtype=t.dtype, device=t.device)
+        count = torch.empty((), dtype=torch.int32, device=t.device)
+        fn = self._lib.icp_grid_sample_padded_f64 if f64 else self._lib.icp_grid_sample_padded
+        self._check(fn(self._h, t.data_ptr(), n, float(voxel_size), idx.data_ptr(), out.data_ptr(), count.data_ptr()))
+        return out[:n], idx[:n], count
+
     def voxel_statistics(self, points: np.ndarray, voxel_size: float, with_normal_distribution: bool = True):
         """`Voxelization.filter` (slam/preprocessing.py:63-98): dict with voxel_coordinates [n,3] i64, voxel_hashes [n]
         i64, voxel_indices [n] i64 and — with_normal_distribution — voxel_sizes [V] i64, voxel_means [V,3] f32,

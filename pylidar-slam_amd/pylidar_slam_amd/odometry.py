@@ -198,6 +198,12 @@ class GridSampleConfig:
     pointcloud_key: str = "numpy_pc"
     output_indices_key: str = "sample_indices"
     output_sample_key: str = "sample_points"
+    # MI355X-side: True = the device-resident pipeline's variant for cuda tensors — NO synchronisation: `sample_points` /
+    # `sample_indices` keep the n rows of the input, the V samples first (same order), NaN rows / index -1 behind them, and
+    # `sample_count` (a 0-dim int32 cuda tensor) holds V.  The MI355X odometry masks NaN rows, so a frame then synchronises
+    # once, for its pose.  False (default): the reference's shapes — V rows, which costs the host a round trip for V
+    padded: bool = False
+    output_count_key: str = "sample_count"
 
 
 def _is_device_tensor(a) -> bool:
@@ -220,8 +226,12 @@ class GridSample:
         if _is_device_tensor(pc):
             ctx = self._ctx or _shared_context(pc.device)
             ctx.use_torch_stream()
-            sample, indices = ctx.grid_sample_f64(pc, self.config.voxel_size) if pc.dtype == torch.float64 else \
-                ctx.grid_sample(pc, self.config.voxel_size)
+            if bool(getattr(self.config, "padded", False)) and hasattr(ctx, "grid_sample_padded"):
+                sample, indices, count = ctx.grid_sample_padded(pc, self.config.voxel_size)
+                data_dict[getattr(self.config, "output_count_key", "sample_count")] = count
+            else:
+                sample, indices = ctx.grid_sample_f64(pc, self.config.voxel_size) if pc.dtype == torch.float64 else \
+                    ctx.grid_sample(pc, self.config.voxel_size)
         else:
             sample, indices = grid_sample(pc, self.config.voxel_size, self._ctx)
         data_dict[self.config.output_sample_key] = sample
@@ -254,6 +264,9 @@ class ToDevice:
             a = data_dict[old_key]
             t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
             assert_debug(isinstance(t, torch.Tensor), f"cannot upload `{old_key}` of type {type(a)}")
+            # (round 5: a persistent pinned staging buffer + an asynchronous DMA on this stream — what `_upload` of the
+            # odometry does on a stream of its own — cut this call from 165 to 62 us and stalled later HIP calls of the frame
+            # for 2.4 ms each, twice per frame; left as torch's own pageable copy, which overlaps the GPU's map update)
             data_dict[new_key] = t.to(self.device, non_blocking=True)
 
 
@@ -663,6 +676,11 @@ class MI355XICPConfig:
     # that the map update after it needs no host round trip of its own: 6 106-row frames 0.64 -> 0.61 ms; a 131 072-row
     # frame pays more for the compaction on the registration's critical path than the round trip costs (0.516 -> 0.540 ms)
     stage_insert_max_rows: int = 32768
+    # the non-null pixels of a sparse vertex map (a grid-sampled frame: 6 000 of 131 072) are compacted into consecutive
+    # target rows in front of the registration (True: round 4's schedule), or the registration walks all H x W pixels and
+    # masks the null ones inside its kernels (False: the valid queries stay spread over all 256 workgroups of a launch instead
+    # of filling 12 — measured in round 5 on the published configuration: 0.52-0.55 vs 0.60 ms per frame)
+    compact_sparse_vertex_map: bool = False
 
 
 def _get(obj, key, default=None):
@@ -799,7 +817,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             # well below H * W (a grid-sampled frame: 6 000 of 131 072) they are compacted on the device, in pixel order,
             # so the registration walks N rows — and estimates normals lazily for what N rows touch — instead of H * W
             n_in = self._tgt_pc.shape[0] if (self._tgt_pc is not None and not self._pc_is_pixels) else h * w
-            if pixels.is_cuda and 2 * n_in <= h * w and hasattr(self.ctx, "compact_targets"):
+            if pixels.is_cuda and 2 * n_in <= h * w and hasattr(self.ctx, "compact_targets") and \
+                    bool(_get(self.config, "compact_sparse_vertex_map", True)):
                 return self.ctx.compact_targets(pixels, n_in, skip_null=True), True
             return pixels, True
         return self._tgt_pc, self._pc_is_pixels
@@ -839,9 +858,12 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             # NOW, in front of the registration, so that the update finds the count on the host (one synchronisation less)
             # (rows in host memory would make the staging call wait for their upload: no round trip saved — except under
             # the CPU stand-in of tests/, which exercises this flow without a GPU)
+            # (a frame that comes padded from the device-resident grid sample — a handful of valid rows among NaN rows —
+            # is staged whatever its row count: the compaction walks flags, what it copies is the handful)
             self._staged = hasattr(self.local_map, "stage") and \
                 (self._tgt_pc.is_cuda or self.device.type != "cuda") and \
-                int(self._tgt_pc.shape[0]) <= int(_get(self.config, "stage_insert_max_rows", 32768))
+                (int(self._tgt_pc.shape[0]) <= int(_get(self.config, "stage_insert_max_rows", 32768)) or
+                 data_dict.get("sample_count", None) is not None)
             if self._staged:
                 self.local_map.stage(self._tgt_pc, skip_null=self._pc_is_pixels)
             self.ctx.register_launch(targets, initial_estimate, skip_null=skip_null)

@@ -26,12 +26,19 @@ def _filters(kind, dev):
         return [our.Distortion(our.DistortionConfig(output_key="distorted")),
                 our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted")),
                 our.ToTensor(our.ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}), device=dev)]
+    # "device_padded": the grid sample that reads nothing back (sample rows padded with NaN rows to the frame's size, the
+    # count left on the device): one host synchronisation per frame
     return [our.ToDevice(our.ToDeviceConfig(device=str(dev)), device=dev),
             our.Distortion(our.DistortionConfig(pointcloud_key="pc_device", timestamps_key="timestamps_device",
                                                 output_key="distorted")),
-            our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted")),
+            our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted", padded=kind == "device_padded")),
             our.ToTensor(our.ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}, dtype="float32"),
                          device=dev)]
+
+
+def _sample_count(d) -> int:
+    """Rows the grid sample selected: the row count of `sample_points`, or — padded variant — the device-side count."""
+    return int(d["sample_count"]) if "sample_count" in d else int(d["sample_points"].shape[0])
 
 
 def _drive(torch, scans, config, preprocessing):
@@ -53,7 +60,7 @@ def _drive(torch, scans, config, preprocessing):
         yield f, d, odo
 
 
-@pytest.mark.parametrize("preprocessing", ["host", "device"])
+@pytest.mark.parametrize("preprocessing", ["host", "device", "device_padded"])
 def test_forced_iteration_loop_matches_the_reference_run_frame_by_frame(torch_cuda, golden_loop, loop_scans, preprocessing):
     """The loop with the stop test off (threshold 0, 6 iterations per frame; `forced_*` of the fixture): grid sample ->
     registration -> sliding-window map with an insertion per frame and evictions from frame 30 on.  EVERY frame within
@@ -65,7 +72,7 @@ def test_forced_iteration_loop_matches_the_reference_run_frame_by_frame(torch_cu
     cfg = published_config(max_num_alignments=int(g["forced_iters_per_frame"]), threshold_delta_pose=0.0)
     worst, odo = (0.0, 0.0), None
     for f, d, odo in _drive(torch_cuda, scans, cfg, preprocessing):
-        assert int(d["sample_points"].shape[0]) == int(g["forced_samples"][f])  # grid sampling is index-exact
+        assert _sample_count(d) == int(g["forced_samples"][f])  # grid sampling is index-exact
         if f == 0:
             assert "odometry_pose" not in d
             continue
@@ -84,7 +91,7 @@ def test_forced_iteration_loop_matches_the_reference_run_frame_by_frame(torch_cu
     assert abs(tr - g["forced_kitti"][0]) < 1e-5
 
 
-@pytest.mark.parametrize("preprocessing", ["host", "device"])
+@pytest.mark.parametrize("preprocessing", ["host", "device", "device_padded"])
 def test_published_configuration_loop_matches_the_reference_run(torch_cuda, golden_loop, loop_scans, preprocessing):
     """The published configuration itself (live stop at |dx| < 1e-4, at most 20 iterations).  Every frame whose loop ran the
     reference's number of iterations: within 1e-4 m / 1e-4 rad of the reference's run.  A frame may stop after another
@@ -104,7 +111,7 @@ def test_published_configuration_loop_matches_the_reference_run(torch_cuda, gold
     scans, gt_abs = loop_scans
     worst, flips, odo = (0.0, 0.0), [], None
     for f, d, odo in _drive(torch_cuda, scans, published_config(), preprocessing):
-        assert int(d["sample_points"].shape[0]) == int(g["samples"][f])
+        assert _sample_count(d) == int(g["samples"][f])
         if f == 0:
             continue
         dt, dr = O.pose_error(d["odometry_pose"], g["rel"][f])

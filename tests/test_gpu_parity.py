@@ -126,6 +126,34 @@ def test_voxel_hash_and_grid_sample(torch_cuda, O, golden_components):
     np.testing.assert_array_equal(ib, O.grid_sample(big, 1e-3)[1])
 
 
+def test_padded_grid_sample_equals_the_exact_one(torch_cuda, O, golden_components):
+    """`icp_grid_sample_padded[_f64]` (the device-resident pipeline's variant: no synchronisation, the count stays on the
+    device): the first V rows / indices are the exact entry point's — which are the reference's (test above) — the rows
+    behind them NaN / -1; float32 and float64 inputs, a full 64x2048 scan, a two-point cloud, an empty one, and a cloud
+    whose voxels outnumber one workgroup's tiles several times over (the one-workgroup radix sort walks them chunk by
+    chunk)."""
+    from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
+    ctx = _ctx()
+    scan = make_sequence(SceneConfig(height=64, width=2048), 1)[0][0]
+    rng = np.random.default_rng(5)
+    clouds = [(scan, 0.4), (scan, 0.05), (golden_components["gs_pc"], float(golden_components["gs_voxel"])),
+              (np.array([[0.1, 0.2, 0.3], [5.0, -4.0, 1.0]], np.float32), 0.5),
+              ((rng.random((70_000, 3)) * 200 - 100).astype(np.float32), 0.7), (np.zeros((0, 3), np.float32), 0.3)]
+    for pts, voxel in clouds:
+        for dtype in (torch_cuda.float32, torch_cuda.float64):
+            dev = torch_cuda.from_numpy(np.ascontiguousarray(pts)).cuda().to(dtype)
+            exact_p, exact_i = (ctx.grid_sample_f64 if dtype == torch_cuda.float64 else ctx.grid_sample)(dev, voxel)
+            pad_p, pad_i, count = ctx.grid_sample_padded(dev, voxel)
+            v = int(count)
+            assert v == exact_p.shape[0] and pad_p.shape[0] == pts.shape[0] and pad_p.dtype == dtype
+            assert torch_cuda.equal(pad_p[:v], exact_p) and torch_cuda.equal(pad_i[:v], exact_i)
+            assert bool(torch_cuda.isnan(pad_p[v:]).all()) and bool((pad_i[v:] == -1).all())
+            if pts.shape[0]:  # ... and the exact one is the reference's order: ascending int64 hash, first point of every voxel
+                oi = O.grid_sample(pts.astype(np.float64 if dtype == torch_cuda.float64 else np.float32), voxel)[1]
+                assert np.array_equal(exact_i.cpu().numpy(), oi)
+    ctx.close()
+
+
 def test_distortion_filter_and_f64_grid_sample(torch_cuda, O):
     """SURVEY §8f rank 1 (`Distortion` -> `GridSample` on the float64 de-skewed cloud): HIP vs the reference's outputs."""
     import os
