@@ -313,6 +313,7 @@ class SequenceThread(threading.Thread):
         with torch.cuda.stream(stream):
             tr = Tracker(self.args, self.seq, self.args.trajectory, self.frames, self.device_index)
             tr.ctx.set_option("lead_solve", 0)  # (several sequences share the GPU: see throughput_leg)
+            tr.ctx.set_option("overlap_map_update", 0)  # (... and the process's four hardware queues: one stream per sequence)
             self.ready.set()
             while True:
                 self.go.wait()
@@ -340,6 +341,7 @@ def throughput_leg(args, S, device_index, main_tr):
     # boundary — a gain for ONE latency-bound sequence, a loss when other sequences could have used those slots
     # (measured: 2370 vs 2890 scans/s with four sequences)
     main_tr.ctx.set_option("lead_solve", 0)
+    main_tr.ctx.set_option("overlap_map_update", 0)  # (one stream per sequence: a process has four hardware queues)
     # never fewer than 60 timed steps per sequence, whatever --steps says (the driver's 20 steps were a 25 ms window opened
     # by three freshly started Python threads: 3212-3872 scans/s where 60 steps of the same build gave 4330 — VERDICT r4)
     steps = max(60, args.steps)
@@ -378,7 +380,7 @@ def throughput_leg(args, S, device_index, main_tr):
             "ms_per_step_spread_main_sequence": {"min": sm[0], "median": sm[len(sm) // 2], "p90": sm[int(0.9 * (len(sm) - 1))],
                                                  "max": sm[-1]},
             "whole_path_algorithmic_GBps": frame_bytes * value / 1e9,
-            "whole_path_frac_of_hbm_peak": frame_bytes * value / HBM_PEAK, "options": ["lead_solve=0"],
+            "whole_path_frac_of_hbm_peak": frame_bytes * value / HBM_PEAK, "options": ["lead_solve=0", "overlap_map_update=0"],
             "max_pose_error_vs_ground_truth_m": err}
 
 
@@ -840,6 +842,7 @@ def main():
                       sharded=(world, rank) if sharded else None)
     if S > 1:
         main_tr.ctx.set_option("lead_solve", 0)  # (several sequences share the GPU: see throughput_leg)
+        main_tr.ctx.set_option("overlap_map_update", 0)
     extra = [SequenceThread(args, rank * S + j, local_rank) for j in range(1, S)]
     for t_ in extra:
         t_.start()

@@ -185,6 +185,25 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   (local_map.py:365-369) and re-estimates on first touch — the same vectors up to the float32
  *                                   rounding of the re-expressed points (poses agree to ~1e-7 m).  0: the reference's schedule,
  *                                   every rebuild clears the cache.  Updates that insert or evict always clear it
+ *   "lazy_fused" 0 | 1 | 2 (0)      normals ON DEMAND inside the fused iteration kernel (KdTreeLocalMap.__get_normals' own schedule,
+ *                                   local_map.py:397-422: estimate on first touch, cache until the next build_model): a query whose
+ *                                   neighbour has no normal yet waits in its workgroup, whole waves estimate those normals behind
+ *                                   the searches — the same exact kNN, covariance and eigen-solve as the all-at-once kernels: the
+ *                                   same bits — and store them for every later launch.  1: where the map holds more than
+ *                                   "lazy_fused_ratio" times the valid targets of the last registration (a grid-sampled frame
+ *                                   against a window of key frames: 6 000 normals estimated instead of 180 000 per frame); 2:
+ *                                   wherever the kernel exists (point-to-plane, 10 or 5 neighbours, one GPU); 0 (default): never
+ *                                   — measured on the published configuration it moves 137 us of estimation from behind the map
+ *                                   update (in the shadow of the host's next frame) onto the path to the pose: 0.55 vs 0.46 ms
+ *   "lazy_fused_ratio" r (4)        see "lazy_fused"
+ *   "overlap_map_update" 0 | 1 (0)  a map update that needs none of the context's scratch buffers — a pose-only update, or the
+ *                                   insertion of a cloud staged with icp_map_stage_cloud — runs on a stream of the context's own,
+ *                                   behind everything enqueued so far and beside what the caller enqueues next as long as that
+ *                                   touches neither the map nor a registration: the upload, grid sample and projection of the
+ *                                   next frame overlap the re-expression, grid rebuild and normal estimation of this one; every
+ *                                   other entry point first orders the caller's stream behind the update.  Off by default:
+ *                                   measured, the two event hand-offs between the streams cost more than the overlap returns
+ *                                   (headline loop 2549 vs 2840 scans/s; published-configuration loop unchanged)
  *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
  *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
  *   "profile_rotate" 0 | 1 (0)      icp_profile_enable brackets one iteration launch per registration (see icp_profile_read_iterations)

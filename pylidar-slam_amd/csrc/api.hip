@@ -124,10 +124,20 @@ static constexpr size_t DBG_BYTES = DBG_ITER_BYTES + 8192 * 4 * sizeof(long long
 // ---- helpers --------------------------------------------------------------------------------------------------------
 // Every entry point runs on the context's device and leaves the calling thread's current device as it found it (a
 // process may hold contexts on several GPUs, and torch shares the thread's current device with us).
+// ... and — `join` — orders itself behind a map update still running on the context's map stream ("overlap_map_update":
+// the re-expression, grid rebuild and normal estimation behind a registration run on a stream of their own, beside the next
+// frame's preprocessing on the caller's stream).  Entry points that touch neither the map nor its search structure nor the
+// registration state (projection, grid sample, de-skew, compaction of targets, the wait for a pose) do not join.
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
-    explicit DeviceGuard(const icp_ctx* ctx) : DeviceGuard(ctx ? ctx->cfg.device : -1) {}
+    explicit DeviceGuard(const icp_ctx* ctx, bool join = true) : DeviceGuard(ctx ? ctx->cfg.device : -1) {
+        if (join && ctx && ctx->map_stream_busy) {
+            icp_ctx* c = const_cast<icp_ctx*>(ctx);
+            (void)hipStreamWaitEvent(c->stream, c->map_done_event, 0);
+            c->map_stream_busy = false;
+        }
+    }
     explicit DeviceGuard(int device) {
         if (device < 0) return;
         if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
@@ -319,6 +329,9 @@ void icp_destroy(icp_ctx* ctx) {
         if (r.event) (void)hipEventDestroy(r.event);
     }
     if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
+    if (ctx->map_done_event) (void)hipEventDestroy(ctx->map_done_event);
+    if (ctx->map_start_event) (void)hipEventDestroy(ctx->map_start_event);
+    if (ctx->map_stream) (void)hipStreamDestroy(ctx->map_stream);
     ctx->staged_xyz.release();
     if (ctx->staged_count_host) (void)hipHostFree(ctx->staged_count_host);
     if (ctx->staged_event) (void)hipEventDestroy(ctx->staged_event);
@@ -334,13 +347,15 @@ void icp_destroy(icp_ctx* ctx) {
 const char* icp_last_error(const icp_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
 int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (callers re-announce their stream before every call: no join for the same stream)
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    hipStream_t next = (hipStream_t)hip_stream;
+    if (next == ctx->stream) return ICP_OK;
+    { DeviceGuard join_map_stream(ctx); }  // a new stream: the old one first takes in the map stream, the new one follows it
     {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
         const int rc_held = continue_launch(ctx, -1);
         if (rc_held) return rc_held;
     }
-    hipStream_t next = (hipStream_t)hip_stream;
     if (next != ctx->stream) {
         // work already enqueued on the previous stream (map builds, a registration in flight) must precede what follows
         if (!ctx->switch_event) ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
@@ -393,7 +408,10 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "refresh_at") ctx->refresh_at = iv;
     else if (k == "prune_guard") ctx->prune_guard = value > 0.0 ? (float)value : 0.f;
     else if (k == "hoods") ctx->hoods = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
+    else if (k == "lazy_fused") ctx->lazy_fused = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv);
+    else if (k == "lazy_fused_ratio") ctx->lazy_fused_ratio = value > 0.0 ? value : 4.0;
     else if (k == "carry_normals") ctx->carry_normals = value != 0.0 ? 1 : 0;
+    else if (k == "overlap_map_update") ctx->overlap_map_update = value != 0.0 ? 1 : 0;
     else if (k == "eager_normals_limit") ctx->eager_normals_limit = value > 0.0 ? (long long)value : 0;
     else if (k == "target_occupancy") ctx->target_occupancy = value > 0.1 ? value : 16.0;
     else if (k == "search_stats") {
@@ -427,7 +445,7 @@ int icp_set_cost(icp_ctx* ctx, int32_t cost) {
 int icp_synchronize(icp_ctx* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
-    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the guard above has ordered the stream behind the map stream)
     return ICP_OK;
 }
 
@@ -450,7 +468,7 @@ int icp_set_alignment(icp_ctx* ctx, int32_t scheme, float sigma, int32_t max_num
 
 // ---- projection -----------------------------------------------------------------------------------------------------
 int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_out, int32_t* index_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0) return ICP_ERR_INVALID_ARGUMENT;
     const size_t npix = (size_t)ctx->cfg.height * ctx->cfg.width;
     const void* in;
@@ -468,7 +486,7 @@ int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_
 
 int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
                        int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !rows_out || !cols_out) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -485,7 +503,7 @@ int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float
 
 int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int stride, int mem, double* xyz_out,
                            int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || stride < 3 || (n > 0 && (!scan || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, scan, (size_t)n * stride * 4, mem, ctx->stage_in, &in);
@@ -501,7 +519,7 @@ int icp_kitti_correct_scan(icp_ctx* ctx, const float* scan, int64_t n, int strid
 // ---- grid sampling --------------------------------------------------------------------------------------------------
 int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                    int64_t* hashes_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !(voxel_size > 0)) return ICP_ERR_INVALID_ARGUMENT;
     const void* in;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -518,7 +536,7 @@ int icp_voxel_hash(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double vo
 
 int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                     float* points_out, int64_t* count_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -541,7 +559,7 @@ int icp_grid_sample(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double v
 int icp_voxel_statistics(icp_ctx* ctx, const float* xyz, int64_t n, int mem, double voxel_size, int64_t* voxels_out,
                          int64_t* hashes_out, int64_t* voxel_ids_out, int64_t* num_voxels_out, int64_t* sizes_out,
                          float* means_out, float* covs_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !(voxel_size > 0) || !num_voxels_out || !voxel_ids_out) return ICP_ERR_INVALID_ARGUMENT;
     const bool stats = sizes_out || means_out || covs_out;
     if (stats && !(sizes_out && means_out && covs_out)) return ICP_ERR_INVALID_ARGUMENT;
@@ -613,19 +631,19 @@ static int grid_sample_padded(icp_ctx* ctx, const void* xyz, int64_t n, double v
 
 int icp_grid_sample_padded(icp_ctx* ctx, const float* xyz, int64_t n, double voxel_size, int64_t* indices_out,
                            float* points_out, int32_t* count_out) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     return grid_sample_padded(ctx, xyz, n, voxel_size, indices_out, points_out, count_out, sizeof(float));
 }
 
 int icp_grid_sample_padded_f64(icp_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices_out,
                                double* points_out, int32_t* count_out) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     return grid_sample_padded(ctx, xyz, n, voxel_size, indices_out, points_out, count_out, sizeof(double));
 }
 
 int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, double voxel_size, int64_t* indices_out,
                         double* points_out, int64_t* count_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !(voxel_size > 0) || !count_out) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -649,7 +667,7 @@ int icp_grid_sample_f64(icp_ctx* ctx, const double* xyz, int64_t n, int mem, dou
 // ---- de-skew --------------------------------------------------------------------------------------------------------
 int icp_distort(icp_ctx* ctx, const float* xyz, const double* timestamps, int64_t n, int mem, const double rel_pose[16],
                 double* xyz_out, int out_mem) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || !rel_pose || (n > 0 && (!xyz || !timestamps || !xyz_out))) return ICP_ERR_INVALID_ARGUMENT;
     const void *in, *ts;
     int rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in);
@@ -703,10 +721,41 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
 // shared tail of the two update flavours: `new_dev` [n,3] device rows with flags, or nothing
 // `known_count` >= 0: `new_dev` holds exactly that many valid rows, already in order (a staged cloud) — copied, not compacted,
 // and nothing is read back
+static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
+                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count);
+
+// The update on the context's MAP STREAM where nothing it does needs the context's scratch buffers (a pose-only update, or
+// a cloud whose valid rows have been compacted and counted already: the staged insertion): ordered behind everything the
+// caller's stream holds so far, ahead of the next entry point that touches the map (DeviceGuard's join) — and beside what
+// touches neither: the upload, grid sample and projection of the NEXT frame.  Measured on the published configuration:
+// the GPU was busy end to end with ~250 us of map update in front of ~110 us of preprocessing per frame.
 static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
                            int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count = -1) {
     int rc = ensure_state(ctx);
     if (rc) return rc;
+    const bool scratch_free = !has_cloud || known_count >= 0;
+    const bool first_cloud = ctx->map_m == 0 && ctx->cloud_sizes.empty() && !ctx->grid_valid;
+    if (!ctx->overlap_map_update || !scratch_free || first_cloud || ctx->exchange_on || ctx->prof.enabled || ctx->search_stats)
+        return map_update_body(ctx, rel_pose, new_dev, flags_dev, n, has_cloud, inserted_out, known_count);
+    if (!ctx->map_stream) {
+        ICP_HIP(ctx, hipStreamCreateWithFlags(&ctx->map_stream, hipStreamNonBlocking));
+        ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_done_event, hipEventDisableTiming));
+        ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_start_event, hipEventDisableTiming));
+    }
+    ICP_HIP(ctx, hipEventRecord(ctx->map_start_event, ctx->stream));
+    ICP_HIP(ctx, hipStreamWaitEvent(ctx->map_stream, ctx->map_start_event, 0));
+    hipStream_t caller = ctx->stream;
+    ctx->stream = ctx->map_stream;
+    rc = map_update_body(ctx, rel_pose, new_dev, flags_dev, n, has_cloud, inserted_out, known_count);
+    ctx->stream = caller;
+    ICP_HIP(ctx, hipEventRecord(ctx->map_done_event, ctx->map_stream));
+    ctx->map_stream_busy = true;
+    return rc;
+}
+
+static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
+                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count) {
+    int rc = ICP_OK;
     ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
     ctx->carry_job = false;
     int64_t inserted = 0;
@@ -879,7 +928,7 @@ int icp_map_update_staged(icp_ctx* ctx, const float rel_pose[16], int64_t* inser
 }
 
 int icp_compact_targets(icp_ctx* ctx, const float* xyz, int64_t n, int target_mode, float* out, int64_t cap) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || n < 0 || cap < 0 || (n > 0 && !xyz) || (cap > 0 && !out)) return ICP_ERR_INVALID_ARGUMENT;
     int rc = ensure_state(ctx);
     if (rc) return rc;
@@ -1365,6 +1414,8 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     // normals: lazily for the map points the scan touches (local_map.py:397-422) when the map is much larger than the
     // scan, all at once otherwise (same values; one dense launch instead of a sparse one per iteration)
     if (!ctx->normals_ready && wants_eager_normals(ctx, n) && (rc = launch_normals_all(ctx))) return rc;
+    // ... or on demand inside the fused iteration kernel, where the scan touches a small part of the map ("lazy_fused")
+    ctx->lazy_now = !ctx->normals_ready && wants_lazy_fused(ctx, n);
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     ctx->cache_fresh = false;
@@ -1381,7 +1432,7 @@ int icp_register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int t
 
 // the fused search + rows kernel needs every normal it may touch: the eager schedule
 static bool fused_path(const icp_ctx* ctx) {
-    return ctx->cost == ICP_COST_POINT_TO_PLANE && ctx->normals_ready && ctx->fuse_iteration;
+    return ctx->cost == ICP_COST_POINT_TO_PLANE && (ctx->normals_ready || ctx->lazy_now) && ctx->fuse_iteration;
 }
 
 int icp_iteration_accumulate(icp_ctx* ctx) {
@@ -1461,6 +1512,7 @@ static int continue_launch(icp_ctx* ctx, int count) {
 // iterations on the same map, hence the same bits — and the skipped map update is repeated with the final pose.
 // `block` receives the state + histories (the layout of the pinned result block).
 static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block) {
+    { DeviceGuard join_map_stream(ctx); }  // (a map update on its own stream: everything below follows it)
     ctx->tail_disabled = true;
     ctx->lead_solve = 0;
     ctx->handoff_fallbacks += 1;
@@ -1491,7 +1543,7 @@ static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block)
 }
 
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (the pose arrives while the map update runs)
     if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
     RegState st;
     const bool async = ctx->result_pending();
@@ -1654,6 +1706,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     memcpy(result->params, st.params, sizeof(st.params));
     result->iterations = st.iter;
     ctx->last_iterations = st.iter;
+    ctx->last_valid_targets = st.n_targets;
     result->converged = st.converged;
     result->status = st.status;
     result->num_targets = st.n_targets;
@@ -1924,7 +1977,7 @@ int icp_profile_enable(icp_ctx* ctx, int enable) {
 }
 
 int icp_profile_read_iterations(icp_ctx* ctx, double* ms_out, int64_t* launches_out, int32_t cap) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx || !ms_out || !launches_out || cap < 1) return ICP_ERR_INVALID_ARGUMENT;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
@@ -1965,7 +2018,7 @@ int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out
 
 int icp_profile_read(icp_ctx* ctx, double* search_ms_out, int64_t* search_launches_out, double* reduce_ms_out,
                      double* normals_ms_out) {
-    DeviceGuard device_guard(ctx);
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);

@@ -366,6 +366,19 @@ struct icp_ctx {
     int ball_lanes = 8;                // "ball_lanes": a miss of a workgroup with few of them gets 2 or 8 lanes of the ball search (IterInputs)
     int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)
     double lead_timeout_ms = 50.0;     // "lead_timeout_ms": how long a workgroup of a lead launch polls the pose mailbox before it gives up (-> ICP_ERR_HIP)
+    // "lazy_fused": normals on demand INSIDE the fused iteration kernel (its LAZY instantiation, search.hip) instead of all of
+    // them behind every map update: 0 never (default), 1 where the map holds more than `lazy_fused_ratio` times the valid
+    // targets of the last registration, 2 wherever the kernel exists (point-to-plane, 10 or 5 neighbours, fused iterations).
+    // Built for VERDICT r4 item 3(i) and MEASURED on the published configuration (6 100 valid targets, 181 000 map points):
+    // the same bits as the all-at-once estimation, 6 100 normals instead of 181 000 per frame — and 0.55 instead of 0.46 ms
+    // per frame: the all-at-once kernel (89 + 15 us for its lists) runs behind the map update, in the shadow of the host's
+    // preparation of the next frame, while the on-demand estimation (24 waiting queries per workgroup, four lanes each: a
+    // 45 us chain at two busy waves per CU) sits inside the first iteration launch, on the path to the frame's pose:
+    // 222 us of iteration launches per frame instead of 85.  Off by default
+    int lazy_fused = 0;
+    double lazy_fused_ratio = 4.0;
+    bool lazy_now = false;             // ... the registration in progress runs on it
+    int64_t last_valid_targets = 0;    // valid target rows of the last collected registration (RegState.n_targets)
     int lead_solve = 1;                // "lead_solve": the solve of iteration k in the head of launch k + 1 (no k_sum_solve launches)
     // "resident_tail": from that iteration on (0: never — the default) ONE launch runs all remaining iterations of a launched /
     // unpolled registration — its workgroups stay resident and hand their partial rows to its lead as tagged granules
@@ -425,6 +438,15 @@ struct icp_ctx {
     void* x_peer[icp::EXCHANGE_MAX_RANKS] = {};  // peers' inboxes opened through IPC (nullptr for the own rank)
     icp::DeviceBuffer x_seq;
     double exchange_timeout_ms = 5000.0;  // option "exchange_timeout_ms"
+    // "overlap_map_update": a map update that needs none of the context's scratch buffers runs on a stream of its own
+    // (api.hip::map_update_impl); entry points that touch the map join it first (DeviceGuard)
+    // MEASURED (round 5) and left off: the two event hand-offs between the streams cost more than the overlap returns — the
+    // headline loop 2549 vs 2840 scans/s (its next frame has 9 us of projection to overlap), the published configuration's
+    // loop 0.44-0.48 vs 0.44-0.46 ms per frame
+    int overlap_map_update = 0;
+    hipStream_t map_stream = nullptr;
+    hipEvent_t map_done_event = nullptr, map_start_event = nullptr;
+    bool map_stream_busy = false;
     hipEvent_t switch_event = nullptr;  // orders a change of stream (icp_set_stream) behind the work of the old one
     // ---- scratch for projection / sampling / io
     int seed_job_n = 0, seed_job_m = 0, seed_job_evicted = 0;  // NN cache -> frame seeds, pending for the next grid build
@@ -543,8 +565,21 @@ inline RegState* reg_state(icp_ctx* ctx) { return ctx->state.as<RegState>(); }
 // twice the scan, and for any scan while the map stays below ~10^6 points (a 6 000-point grid sample against 180 000
 // map points: 0.19 ms eager vs 0.45 ms for four lazy iterations; 200 000 points against 10^6: 2.8 vs 4.7 ms per frame of
 // twenty iterations).  n = the number of targets (of the registration at hand, or of the last one as a stand-in).
+// normals on demand inside the fused kernel (option "lazy_fused")?  n = target rows of the registration at hand (valid or
+// not: a padded frame has 131 072 of which 6 000 count — the last registration's valid count is the better estimate)
+inline bool wants_lazy_fused(const icp_ctx* ctx, int64_t n) {
+    const int kn = ctx->cfg.num_neighbors_normals + 1;
+    if (ctx->cost != ICP_COST_POINT_TO_PLANE || !ctx->fuse_iteration || ctx->lazy_fused <= 0 || (kn != 11 && kn != 6) ||
+        ctx->exchange_on || ctx->sharded_normals || ctx->map_m >= (1 << 24))
+        return false;
+    if (ctx->lazy_fused >= 2) return true;
+    const int64_t valid = ctx->last_valid_targets > 0 && ctx->last_valid_targets < n ? ctx->last_valid_targets : n;
+    return (double)ctx->map_m > ctx->lazy_fused_ratio * (double)valid;
+}
+
 inline bool wants_eager_normals(const icp_ctx* ctx, int64_t n) {
     if (ctx->cost != ICP_COST_POINT_TO_PLANE) return false;
+    if (wants_lazy_fused(ctx, n)) return false;
     return ctx->map_m <= 2 * n || ctx->map_m <= (int64_t)ctx->eager_normals_limit;
 }
 

@@ -1169,6 +1169,9 @@ struct IterInputs {
     int far_min;             // option "far_min": ... and it takes more than that many (fewer: a wave each, phase B1)
     int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
+    float4* normals_rw;      // LAZY instantiation: the normal cache and its flags, writable; fine rings of its kNN
+    int* nflag;
+    int knn_rings;
     int tail_iters;          // resident tail (TAIL instantiation): iterations this launch runs (iter .. iter + tail_iters - 1)
     int refresh_at;          // ... the one of them the refresh margin applies to (a launch of its own: `refresh_margin` is set for it alone)
     unsigned long long* tail_rows;  // ... the tagged super-rows its workgroups hand to its lead: [rows][NEQ][2] granules
@@ -1350,7 +1353,25 @@ __device__ inline bool tail_lead_step(const LeadArgs& lead, RegState* __restrict
 // state and per-lane addresses alive around the searches, which at 128 registers spilled 65 of them inside the cache test of
 // every iteration — so its lead cannot be a workgroup of its own beside 256 others: workgroup 0 is lead AND takes its share
 // of the queries, tail_lead_step in front of each of its iterations.)
-template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false>
+// LAZY_KN > 0 (the point-to-plane normals ON DEMAND, `KdTreeLocalMap.__get_normals`, local_map.py:397-422: a normal is
+// estimated when a scan first touches its map point and cached until the next build_model): a neighbour whose normal has
+// not been estimated yet does not form its row at once — the query waits in an LDS list, and behind the searches whole
+// waves estimate those normals (the exact LAZY_KN-nearest neighbours from scratch: wave_knn_rings over rings 0.., coarse
+// level, exhaustive scan — the straggler path of the eager kernels, same neighbours, same order-independent covariance
+// sums, same eigen-solve: the same bits), store them for every later launch and form the rows.  For a scan that touches a
+// few per cent of the map (the published configuration: 6 000 targets, 180 000 map points) this replaces the estimation
+// of EVERY normal behind every map update (89 + 15 us per frame) by ~6 000 whole-wave searches spread over the chip
+// inside the first iteration launch.  Built for 256 registers (MINW = 2) and the 512-query shape.
+template <int KN>
+__device__ inline void lazy_cov_wave(const GridView& g, int s, int lane, int max_rings, int* __restrict__ wl,
+                                     float* __restrict__ cov);
+template <int KN>
+__device__ inline bool lazy_cov_group(const GridView& g, int s, int sub, float* __restrict__ cov, int2* __restrict__ stack,
+                                      int stride);
+__device__ inline void normal_from_cov(const float* __restrict__ cov, int s, float4* __restrict__ normals,
+                                       int* __restrict__ nflag);
+
+template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false, int LAZY_KN = 0>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                    RegState* __restrict__ st, AlignParams ap,
                                                                    LeadArgs lead) {
@@ -1369,6 +1390,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     __shared__ int ctl_s[4];                  // logical block | done | iteration | hand-off failures
     __shared__ int dbg_s[16];                 // dev-only ("search_stats" = 1): this workgroup's path counters
     __shared__ float carry_s[24];             // TAIL, workgroup 0: pose, parameters and iteration count from solve to solve
+    constexpr bool LAZY = LAZY_KN > 0;
+    __shared__ float4 lazy_p[LAZY ? Q : 1];   // LAZY: transformed target + bits(query slot) of a query that waits for a normal
+    __shared__ int lazy_pos[LAZY ? Q : 1];    // ... the map point whose normal it waits for
+    __shared__ float lazy_cov[LAZY ? Q : 1][7];
+    __shared__ int nlazy;
     static_assert(sizeof(cellstack) >= (32 * NEQ + NEQ + 1) * sizeof(double), "the lead's scratch lives in the cell stacks");
     // In a lead launch (LeadArgs) workgroup 0 is the lead: it solves the previous iteration and publishes the pose the
     // others poll for.  The hardware dispatches workgroups in ascending order, so whoever polls, polls for a workgroup
@@ -1489,7 +1515,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         pose_s[threadIdx.x] = st->pose[threadIdx.x];
         if (threadIdx.x == 0) ctl_s[2] = st->iter;
     }
-    if (threadIdx.x == 0) nmiss = 0;
+    if (threadIdx.x == 0) {
+        nmiss = 0;
+        nlazy = 0;
+    }
     __syncthreads();
 
     if (ctl_s[3]) {  // never seen: the hand-off did not arrive within its wall-clock budget -> a loud error, not a hang
@@ -1549,7 +1578,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                         const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
                         hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta - ((!TAIL || iter_now == in.refresh_at) ? in.refresh_margin : 0.f);
                     }
-                    if (hit) {  // (nothing to write: the entry stays as the search left it)
+                    if (hit && LAZY && wn.w != 1.f) {  // the neighbour's normal has not been estimated yet: phase N forms the row
+                        const int k2 = atomicAdd(&nlazy, 1);
+                        lazy_p[k2] = make_float4(px, py, pz, __int_as_float(lq));
+                        lazy_pos[k2] = hit_pos;
+                        need_load = true;
+                    } else if (hit) {  // (nothing to write: the entry stays as the search left it)
                         point_to_plane_row(px, py, pz, wq.x, wq.y, wq.z, wn.x, wn.y, wn.z, ap.scheme, ap.sigma, row);
                     } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
                         seed_d2 = d2;
@@ -1584,6 +1618,19 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // ---- phase B0 (round 4): every miss by ONE lane — or, where the workgroup has few of them, by 2 or 8 neighbouring
     // lanes (search_ball_lane); what does not fit its pattern (own cell empty, a ball that leaves the 2x2x2 block, more than
     // 256 candidates, four candidates within a key's resolution) goes back on the list for the generic paths below
+    // the row of a query whose neighbour a search has just named — or (LAZY) the query on the waiting list of phase N
+    const auto row_or_wait = [&](int slot, const float4 mp, const float4 q, const float4 nn, int pos) {
+        if (LAZY && nn.w != 1.f) {
+            const int k2 = atomicAdd(&nlazy, 1);
+            lazy_p[k2] = make_float4(mp.x, mp.y, mp.z, __int_as_float(slot));
+            lazy_pos[k2] = pos;
+            return;
+        }
+        float row[9];
+        point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
+    };
     const int ball_lpq = !in.ball ? 0
                          : (in.ball_lanes >= 8 && nmiss * 8 <= THREADS)   ? 8
                          : (in.ball_lanes >= 4 && nmiss * 4 <= THREADS)   ? 4
@@ -1617,10 +1664,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                     const float4 q = g.pts[p0];
                     const float4 nn = in.normals[p0];
                     in.nn_cache[query_of(lq2)] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
-                    float row[9];
-                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) rowbuf[lq2][k] = row[k];
+                    row_or_wait(lq2, mp, q, nn, p0);
                     if (g.dbg) atomicAdd(&g.dbg[0], 1);
                 } else {
                     if (sp >= 0) {  // a better seed than the one it came with: the nearest point of its own cell (exact distance)
@@ -1667,10 +1711,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
-                    float row[9];
-                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                    row_or_wait(lq, mp, q, nn, b.pos);
                 }
             }
         }
@@ -1699,10 +1740,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
-                    float row[9];
-                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                    row_or_wait(lq, mp, q, nn, b.pos);
                 }
                 miss_seed[m].w = 1;  // settled
             }
@@ -1737,16 +1775,46 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
-                    float row[9];
-                    point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+                    row_or_wait(lq, mp, q, nn, b.pos);
                 }
             }
             if (THREADS >= 4 * Q) break;  // a group for every query: one trip
         }
     }
     __syncthreads();
+    if (LAZY && nlazy > 0) {  // ---- phase N (block-uniform): the normals the queries of this workgroup wait for
+        const int listed = nlazy, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = threadIdx.x & 3;
+        // (another query of this workgroup may wait for the same map point — estimated twice, the same bits; so may another
+        // workgroup of this launch)
+        // four lanes per waiting query: ring 1 from the cell's neighbour row (estimate_cov, the round-2 kernel's group: a
+        // whole wave per query — 64-lane merges of sorted lists — took 60 us each); what ring 1 does not certify is marked
+        // and finished by whole waves below (the stragglers' path of the eager kernels)
+        if (threadIdx.x == 0) nmiss = 0;  // (the miss list is through: its counter numbers the stragglers)
+        __syncthreads();
+        for (int m = threadIdx.x >> 2; m < listed; m += THREADS / 4) {  // group-uniform
+            if (!lazy_cov_group<LAZY_KN>(g, lazy_pos[m], sub, lazy_cov[m], &cellstack[0][threadIdx.x], THREADS) && sub == 0)
+                miss_seed[atomicAdd(&nmiss, 1)].x = m;
+        }
+        __syncthreads();
+        int* wl = reinterpret_cast<int*>(&cellstack[0][0]) + wave * 128;
+        for (int k = wave; k < nmiss; k += THREADS / 64) {
+            const int m = miss_seed[k].x;
+            lazy_cov_wave<LAZY_KN>(g, lazy_pos[m], lane, in.knn_rings, wl, lazy_cov[m]);
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < listed; m += THREADS) {  // the eigen-solves, one lane per waiting query
+            const int pos = lazy_pos[m];
+            normal_from_cov(lazy_cov[m], pos, in.normals_rw, in.nflag);
+            const float4 nn = in.normals_rw[pos], q = g.pts[pos], mp = lazy_p[m];
+            float row[9];
+            point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+            const int slot = __float_as_int(mp.w);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
+        }
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)listed);
+        __syncthreads();
+    }
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     if (TAIL) {  // the super-row goes to the lead of THIS launch: tagged granules, no fence (solve_device.h)
         const double v = block_reduce_rows<Q, true>(rowbuf, part, nullptr, vb);
@@ -2323,6 +2391,39 @@ __device__ inline void finish_cov_wave(const GridView& g, int s, int lane, int m
         exact = wave_knn_rings<KN>(coarse_view(g), px, py, pz, lane, 0, COARSE_RINGS, limit, m, wl);
     }
     if (!exact) {  // farther than COARSE_RINGS coarse cells from k map points: exhaustive
+        TopK<KN> t;
+        t.init();
+        m.init();
+        for (int k = lane; k < g.m; k += 64) t.insert(point_key(g.pts[k], px, py, pz));
+        merge_group<KN, 64>(t, m);
+    }
+    if (lane == 0) neighbourhood_cov<KN>(g, px, py, pz, m, cov);
+}
+
+// ring 1 by a 4-lane group (estimate_cov without a caller for its merged list)
+template <int KN>
+__device__ inline bool lazy_cov_group(const GridView& g, int s, int sub, float* __restrict__ cov, int2* __restrict__ stack,
+                                      int stride) {
+    TopK<KN> m;
+    return estimate_cov<KN, 4>(g, s, sub, cov, stack, stride, m);
+}
+
+// The covariance of map point `s` from scratch by a whole wave (the fused iteration kernel's LAZY instantiation: normals on
+// demand): rings 0 .. max_rings of the fine level, then the continuation of finish_cov_wave.  lane 0 writes cov[0..6].
+template <int KN>
+__device__ inline void lazy_cov_wave(const GridView& g, int s, int lane, int max_rings, int* __restrict__ wl,
+                                     float* __restrict__ cov) {
+    const float4 P = g.pts[s];
+    const float px = P.x, py = P.y, pz = P.z;
+    TopK<KN> m;
+    m.init();
+    bool exact = wave_knn_rings<KN>(g, px, py, pz, lane, 0, max_rings, INFINITY, m, wl);
+    if (!exact && g.ctable) {
+        const float limit = m.kth();
+        m.init();
+        exact = wave_knn_rings<KN>(coarse_view(g), px, py, pz, lane, 0, COARSE_RINGS, limit, m, wl);
+    }
+    if (!exact) {
         TopK<KN> t;
         t.init();
         m.init();
@@ -3069,6 +3170,7 @@ bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
     // (without the NN cache — the first iteration of a registration — every query searches: one lane each with the ball
     // search, which suits the 512-query shape; the 4-lane groups of the generic path want the 128-query shape)
     const int use_cache = fused_cache_mode(ctx);
+    if (ctx->lazy_now) return true;  // (normals on demand exist in the 512-query shape only)
     return (use_cache || ctx->ball_search) && ctx->narrow_from >= 0 && ctx->iter_in_registration >= ctx->narrow_from;
 }
 
@@ -3089,7 +3191,7 @@ static int tail_capacity(icp_ctx* ctx) {
 // may the launch of the NEXT iteration be a resident tail over `tail_iters` iterations?  (a lead launch of the plain
 // 512-query shape with rows to solve in front of it, every workgroup resident at once, the NN cache live)
 bool fused_tail_possible(icp_ctx* ctx, int prev_rows, int tail_iters) {
-    if (ctx->resident_tail <= 0 || ctx->tail_disabled || tail_iters < 2 || prev_rows <= 0) return false;
+    if (ctx->resident_tail <= 0 || ctx->tail_disabled || tail_iters < 2 || prev_rows <= 0 || ctx->lazy_now) return false;
     if (ctx->iter_in_registration < ctx->resident_tail || !fused_cache_mode(ctx) || !next_fused_launch_is_narrow(ctx)) return false;
     if (ctx->iter_in_registration < ctx->wide_until && ctx->ball_search) return false;  // (the 1024-thread shape has no tail)
     const int blocks = (int)((ctx->tgt_n + IT_THREADS - 1) / IT_THREADS);
@@ -3099,7 +3201,7 @@ bool fused_tail_possible(icp_ctx* ctx, int prev_rows, int tail_iters) {
 // before the first launch of a registration of up to `iters` iterations: will its lead launches end in a resident tail?
 // (then a live stop threshold needs no chunked launches: the tail ends on the device when the loop does)
 bool fused_tail_planned(icp_ctx* ctx, int iters) {
-    if (ctx->resident_tail <= 0 || ctx->tail_disabled || !ctx->use_nn_cache || ctx->map_m >= (1 << 24) || ctx->tgt_n <= 0) return false;
+    if (ctx->resident_tail <= 0 || ctx->tail_disabled || !ctx->use_nn_cache || ctx->map_m >= (1 << 24) || ctx->tgt_n <= 0 || ctx->lazy_now) return false;
     const int from = (ctx->ball_search && ctx->wide_until > ctx->resident_tail) ? ctx->wide_until : ctx->resident_tail;
     if (ctx->narrow_from < 0 || ctx->narrow_from > from || iters - from < 2) return false;
     const int blocks = (int)((ctx->tgt_n + IT_THREADS - 1) / IT_THREADS);
@@ -3166,6 +3268,9 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // 4-lane groups take up to 128 misses in 10-15 us — whole waves only for a handful)
     in.wave_misses = min(narrow ? ctx->wave_misses : ctx->wave_misses_dense, IT_QUERIES);
     in.chunk_stride = narrow ? blocks : 0;  // (S = ceil(base rows / 4) = the number of 512-query workgroups)
+    in.normals_rw = ctx->normals.as<float4>();
+    in.nflag = ctx->nflag.as<int>();
+    in.knn_rings = ctx->knn_rings >= 0 ? ctx->knn_rings : (ctx->cfg.max_rings < 2 ? ctx->cfg.max_rings : 2);
     in.tail_iters = tail ? tail_iters : 0;
     in.refresh_at = ctx->refresh_at;
     in.tail_rows = nullptr;
@@ -3214,8 +3319,15 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // the first launches of a registration (most queries search) with 1024 threads per workgroup: twice the lanes for the
     // same 512 queries, so every miss gets two (the slowest WAVE sets these launches: a lane that walks 200 candidates of a
     // dense cell alone); same super-rows, same bits
-    const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search;
-    if (tail && ctx->search_stats)
+    const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search && !ctx->lazy_now;
+    const int kn_lazy = ctx->lazy_now ? ctx->cfg.num_neighbors_normals + 1 : 0;
+    if (kn_lazy == 11)  // (normals on demand: the 512-query shape from the first iteration on, built for 256 registers)
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 11>), dim3(grid), dim3(IT_THREADS), 0,
+                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (kn_lazy == 6)
+        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 6>), dim3(grid), dim3(IT_THREADS), 0,
+                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
+    else if (tail && ctx->search_stats)
         hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, true, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
                            make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
     else if (tail)

@@ -245,6 +245,10 @@ class ToDeviceConfig:
     device: str = "cuda:0"
     keys: Dict[str, str] = field(default_factory=lambda: {"numpy_pc": "pc_device",
                                                           "numpy_pc_timestamps": "timestamps_device"})
+    # pageable arrays travel through a persistent pinned buffer on an upload stream of their own, into two alternating
+    # device slots: the tensor a frame receives is overwritten TWO frames later — a consumer that keeps frames around
+    # longer clones them, or sets this to False (torch's own blocking copy into a fresh tensor)
+    pinned_staging: bool = True
 
 
 class ToDevice:
@@ -256,6 +260,41 @@ class ToDevice:
         self.config = config
         dev = torch.device(device if device is not None and str(device) != "cpu" else config.device)
         self.device = dev if dev.type == "cuda" else torch.device(config.device)
+        self._slots: Dict[str, Any] = {}
+        self._stream = None
+
+    def _upload(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        """Pageable host memory -> device the way the odometry uploads its frames (`MI355XICPFrameToModel._upload`): one host
+        memcpy into a persistent pinned buffer, an asynchronous DMA on a stream of ITS OWN into one of two alternating
+        device slots, the caller's stream made to wait for it — `tensor.to(device)` from pageable memory blocks the host
+        for the whole transfer (165 us for a 131 072-point frame).  (The DMA enqueued on the caller's stream itself, behind
+        the previous frame's map update, stalled later HIP calls of the frame for 2.4 ms each: measured in round 5.)"""
+        if self.device.type != "cuda" or t.is_cuda or t.numel() == 0 or not getattr(self.config, "pinned_staging", True):
+            return t.to(self.device, non_blocking=True)
+        slot = self._slots.get(key)
+        if slot is None or slot["pin"].numel() < t.numel() or slot["pin"].dtype != t.dtype:
+            slot = self._slots[key] = {"pin": torch.empty(t.numel(), dtype=t.dtype, pin_memory=True), "free": None,
+                                       "dev": [None, None], "which": 0}
+        if slot["free"] is not None:
+            slot["free"].synchronize()  # the previous frame's DMA has left the staging buffer (long done in practice)
+        stage = slot["pin"][:t.numel()].view(t.shape)
+        # (numpy's memcpy: `stage.copy_(t)` goes through torch's intra-op thread pool for 1.5 MB — waking it cost 5 ms per
+        # frame on the 256-thread host)
+        stage.numpy()[...] = t.numpy()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        slot["which"] ^= 1
+        dev = slot["dev"][slot["which"]]
+        if dev is None or dev.numel() < t.numel() or dev.dtype != t.dtype:
+            dev = slot["dev"][slot["which"]] = torch.empty(t.numel(), dtype=t.dtype, device=self.device)
+        out = dev[:t.numel()].view(t.shape)
+        with torch.cuda.stream(self._stream):
+            out.copy_(stage, non_blocking=True)
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(self._stream)
+        main.wait_event(slot["free"])
+        return out
 
     def filter(self, data_dict: dict):
         for old_key, new_key in dict(self.config.keys).items():
@@ -264,10 +303,7 @@ class ToDevice:
             a = data_dict[old_key]
             t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
             assert_debug(isinstance(t, torch.Tensor), f"cannot upload `{old_key}` of type {type(a)}")
-            # (round 5: a persistent pinned staging buffer + an asynchronous DMA on this stream — what `_upload` of the
-            # odometry does on a stream of its own — cut this call from 165 to 62 us and stalled later HIP calls of the frame
-            # for 2.4 ms each, twice per frame; left as torch's own pageable copy, which overlaps the GPU's map update)
-            data_dict[new_key] = t.to(self.device, non_blocking=True)
+            data_dict[new_key] = self._upload(old_key, t)
 
 
 @dataclass

@@ -398,6 +398,13 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "tail_no_cache_seed": {"resident_tail": 3, "nn_cache": 1},
                 "tail_no_guard": {"resident_tail": 3, "prune_guard": 0.0, "refresh_margin": 0.0},
                 "tail_small_scans_only": {"resident_tail": 3, "resident_tail_max_blocks": 8},  # (this scan has 64 workgroups: no tail)
+                # normals on demand inside the fused kernel (by default only where the map dwarfs the scan) / never
+                # (compared with `no_carry`: a normal estimated on first touch in a LATER frame is estimated from the re-expressed
+                # points, where the default schedule has carried the first frame's estimate over by rotation: rounding apart)
+                "no_carry": {"carry_normals": 0}, "lazy_fused": {"lazy_fused": 2, "carry_normals": 0},
+                "lazy_fused_no_lead": {"lazy_fused": 2, "lead_solve": 0, "carry_normals": 0},
+                "lazy_fused_nocache": {"lazy_fused": 2, "nn_cache": 0, "carry_normals": 0}, "never_lazy_fused": {"lazy_fused": 0},
+                "lazy_fused_carried": {"lazy_fused": 2},  # (held to 1e-6 below, not to the bit)
                 "unfused": {"fuse_iteration": 0}}
     results = {}
     for name, opts in variants.items():
@@ -420,9 +427,16 @@ def test_schedule_options_are_bit_identical(torch_cuda):
     with pytest.raises(AssertionError):
         c = _ctx()
         c.set_option("no_such_option", 1)
-    ref_frames, ref_map, ref_nrm = results["default"]
     problems = []
     for name, (frames, mp, nrm) in results.items():
+        ref_frames, ref_map, ref_nrm = results["no_carry" if variants[name].get("carry_normals", 1) == 0 else "default"]
+        if name == "no_carry":  # (the reference's schedule against the carried one: rounding apart)
+            ref_frames, ref_map, ref_nrm = results["default"]
+        if name in ("no_carry", "lazy_fused_carried"):
+            for r, ref in zip(frames, ref_frames):
+                np.testing.assert_allclose(r.pose, ref.pose, atol=1e-6)
+                np.testing.assert_allclose(r.losses, ref.losses, rtol=1e-5)
+            continue
         for f, (r, ref) in enumerate(zip(frames, ref_frames)):
             assert r.iterations == ref.iterations == 12
             if name == "unfused":
@@ -810,7 +824,9 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
                 "round3": {"ball_search": 0, "narrow_from": 3},
                 # round 4's schedule (a launch per iteration) / the resident tail from iteration 7
-                "tail_from_3": {"resident_tail": 3}, "tail_from_7": {"resident_tail": 7}}  # the resident tail (off by default)
+                "tail_from_3": {"resident_tail": 3}, "tail_from_7": {"resident_tail": 7},  # the resident tail (off by default)
+                "no_carry": {"carry_normals": 0},
+                "lazy_fused": {"lazy_fused": 2, "carry_normals": 0}}  # normals on demand inside the fused kernel: equal to `no_carry`
     results = {}
     for name, opts in variants.items():
         ctx = _ctx(height=64, width=2048, max_num_alignments=20, threshold_delta_pose=0.0, scheme="geman_mcclure",
@@ -832,9 +848,13 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
         results[name] = (frames, ix, pose12, nrm, ctx.map_points())
         assert ctx.handoff_fallbacks() == 0, name
         ctx.close()
-    ref = results["default"]
     problems = []
     for name, (frames, ix, pose12, nrm, mp) in results.items():
+        ref = results["no_carry" if name == "lazy_fused" else "default"]
+        if name == "no_carry":  # (the reference's schedule against the carried one: rounding apart)
+            for r, rr in zip(frames, results["default"][0]):
+                np.testing.assert_allclose(r.pose, rr.pose, atol=1e-6)
+            continue
         for f, (r, rr) in enumerate(zip(frames, ref[0])):
             assert r.iterations == 20
             if not (np.array_equal(r.pose, rr.pose) and np.array_equal(r.losses, rr.losses) and np.array_equal(r.dx, rr.dx)):
@@ -850,6 +870,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
         if not np.array_equal(mp, ref[4]):
             problems.append(f"{name}: map differs")
     assert not problems, "\n".join(problems)
+    ref = results["default"]
     # ---- the neighbours of the last iteration against the kd-tree, every target.  The device transforms in float32:
     # p = fma(z, T2, fma(y, T1, x * T0)) + T3 (search_device.h::transform_point), restated here (products of two floats
     # are exact in float64)

@@ -11,7 +11,7 @@ cfg = our.MI355XICPConfig(max_num_alignments=20, threshold_delta_pose=1e-4, data
                           local_map=dict(type="kdtree_local_map", local_map_size=30, num_neighbors_normals=10),
                           alignment=dict(mode="point_to_plane_gauss_newton", gauss_newton_config=dict(max_iters=1, scheme="neighborhood", sigma=0.2)))
 odo = our.MI355XICPFrameToModel(cfg, projector=our.SphericalProjector(64, 2048), device=dev)
-filters = [our.ToDevice(our.ToDeviceConfig(device=str(dev)), device=dev),
+filters = [our.ToDevice(our.ToDeviceConfig(device=str(dev), pinned_staging=os.environ.get("PIN", "1") == "1"), device=dev),
            our.Distortion(our.DistortionConfig(pointcloud_key="pc_device", timestamps_key="timestamps_device", output_key="distorted")),
            our.GridSample(our.GridSampleConfig(voxel_size=0.4, pointcloud_key="distorted", padded=os.environ.get("PAD", "1") == "1")),
            our.ToTensor(our.ToTensorConfig(device=str(dev), keys={"sample_points": "input_data"}, dtype="float32"), device=dev)]
