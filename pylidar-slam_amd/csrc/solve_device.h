@@ -100,6 +100,15 @@ __device__ inline int gauss_newton_from_neq(const double* neq, float* dx, double
     return ICP_OK;
 }
 
+// SGPR broadcasts of a lane's value (constant lane: v_readlane, not the LDS crossbar of __shfl)
+__device__ inline float wave_bcast_f32(float v, int lane_const) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}
+
+// (Round 5 also built the 6x6 solve row-parallel — lane r holding row r of [H | g], Gauss-Jordan with the pivot row
+// travelling by v_readlane: 0.80 us against the 0.78 us of the one-lane Cholesky, tools/dev/t/solve_bench.hip: either way
+// the step is a chain of six dependent float64 reciprocals / reciprocal square roots.  Not kept.)
+
 // rotation matrix from the sines / cosines of the three Euler angles: Rz(ez) @ Ry(ey) @ Rx(ex)
 // (torch_euler_to_mat, slam/common/rotation.py:144-150), float32
 __device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float sy, float cz, float sz, float* R) {
@@ -122,11 +131,12 @@ __device__ inline void euler_trig_to_mat_f32(float cx, float sx, float cy, float
 __device__ inline void wave_sincos3(float e0, float e1, float e2, float* sn, float* cs) {
     const int a = (int)(threadIdx.x & 63) % 3;
     const float ang = a == 0 ? e0 : (a == 1 ? e1 : e2);
-    const float s = sinf(ang), c = cosf(ang);
+    float s, c;
+    sincosf(ang, &s, &c);  // (one range reduction for both)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        sn[k] = __shfl(s, k, 64);
-        cs[k] = __shfl(c, k, 64);
+    for (int k = 0; k < 3; ++k) {  // lanes 0, 1, 2 hold the three angles: SGPR broadcasts, not the LDS crossbar
+        sn[k] = wave_bcast_f32(s, k);
+        cs[k] = wave_bcast_f32(c, k);
     }
 }
 
@@ -160,9 +170,9 @@ __device__ inline void wave_from_pose_f32(const float* T, float* p) {  // pose.p
     p[0] = T[3];
     p[1] = T[7];
     p[2] = T[11];
-    p[3] = __shfl(e, 0, 64);
-    p[4] = __shfl(e, 1, 64);
-    p[5] = regular ? __shfl(e, 2, 64) : 0.f;
+    p[3] = wave_bcast_f32(e, 0);
+    p[4] = wave_bcast_f32(e, 1);
+    p[5] = regular ? wave_bcast_f32(e, 2) : 0.f;
 }
 
 // One Gauss-Newton step + the pose update of register_new_frame, executed by ALL 64 lanes of one wave: the f64 Cholesky
@@ -206,12 +216,20 @@ __device__ inline void solve_core(const double* __restrict__ neq, AlignParams ap
     // new_pose_params = from_pose_matrix(delta @ pose); pose = build_pose_matrix(params)   (:296-297), float32
     float D[16], P[16];
     wave_build_pose_f32(o.dx, D);
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            float s = 0.f;
-            for (int k2 = 0; k2 < 4; ++k2) s += D[4 * r + k2] * pose_in[4 * k2 + c];
-            P[4 * r + c] = s;
+    {   // P = D @ pose_in, the twelve elements of rows 0-2 one per lane (row 3 of a rigid product is 0 0 0 1) — the same
+        // products added in the same order as the scalar triple loop: s = ((0 + d0 p0) + d1 p1) + d2 p2) + d3 p3
+        const int l = (int)(threadIdx.x & 63), rr = (l >> 2) % 3, cc = l & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const float dv = rr == 0 ? D[k2] : (rr == 1 ? D[4 + k2] : D[8 + k2]);
+            const float pv = cc == 0 ? pose_in[4 * k2] : (cc == 1 ? pose_in[4 * k2 + 1] : (cc == 2 ? pose_in[4 * k2 + 2] : pose_in[4 * k2 + 3]));
+            s += dv * pv;
         }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) P[e] = wave_bcast_f32(s, e);
+        P[12] = 0.f, P[13] = 0.f, P[14] = 0.f, P[15] = 1.f;
+    }
     wave_from_pose_f32(P, o.params);
     wave_build_pose_f32(o.params, o.pose);
     o.moved = 1;

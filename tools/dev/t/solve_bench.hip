@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void k_bench(const double* neq_in, int reps, lo
             for (int k = 0; k < 6; ++k) params[k] = o.params[k];
             if (threadIdx.x == 0) neq[21] += 1e-9 * o.dx[0];  // (a dependence from step to step)
             acc += o.dx[1];
-        } else if (stage == 1) {  // Cholesky only
+        } else if (stage == 1) {  // Cholesky only (one lane's chain, every lane redundantly)
             float dx[6]; double loss; int stopped;
             gauss_newton_from_neq(neq, dx, &loss, &stopped);
             if (threadIdx.x == 0) neq[21] += 1e-9 * dx[0];
@@ -57,7 +57,7 @@ int main() {
         hipLaunchKernelGGL(k_bench, dim3(1), dim3(64), 0, 0, d, reps, t, o, stage);
         hipDeviceSynchronize();
         long long ticks; float ov; hipMemcpy(&ticks, t, 8, hipMemcpyDeviceToHost); hipMemcpy(&ov, o, 4, hipMemcpyDeviceToHost);
-        printf("stage %d (%s): %.3f us per step (%g) %s\n", stage, stage == 0 ? "whole step" : (stage == 1 ? "H assembly + Cholesky + dx" : "pose algebra"), ticks * 0.01 / reps, ov, hipGetErrorString(hipGetLastError()));
+        printf("stage %d (%s): %.3f us per step (%g) %s\n", stage, stage == 0 ? "whole step" : (stage == 1 ? "H assembly + Cholesky + dx" : (stage == 2 ? "pose algebra" : "row-parallel elimination + dx")), ticks * 0.01 / reps, ov, hipGetErrorString(hipGetLastError()));
     }
     return 0;
 }
