@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "icp_internal.h"
 #include "map_move_device.h"
 
@@ -146,6 +148,30 @@ struct DeviceGuard {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+
+// Contexts of this process with a registration in flight, per device: the lead launches (and the resident tail) make the
+// workgroups of a launch wait for one another, which is only worth it — and only safe from a 50 ms bail-out — while no
+// other launch competes for the CUs.  A context that finds another one registering on its device enqueues per-iteration
+// launches with a solving launch each for that registration (contexts of OTHER processes cannot be
+// seen: there the timed-out hand-off is recovered and the context keeps to plain launches, recover_handoff).
+static std::atomic<int> g_registering[64];
+
+static void registering_enter(icp_ctx* ctx) {
+    if (ctx->counted_registering) return;
+    const int d = ctx->cfg.device >= 0 && ctx->cfg.device < 64 ? ctx->cfg.device : 0;
+    g_registering[d].fetch_add(1);
+    ctx->counted_registering = true;
+}
+static void registering_leave(icp_ctx* ctx) {
+    if (!ctx->counted_registering) return;
+    const int d = ctx->cfg.device >= 0 && ctx->cfg.device < 64 ? ctx->cfg.device : 0;
+    g_registering[d].fetch_sub(1);
+    ctx->counted_registering = false;
+}
+static bool device_shared_with_another_registration(const icp_ctx* ctx) {
+    const int d = ctx->cfg.device >= 0 && ctx->cfg.device < 64 ? ctx->cfg.device : 0;
+    return g_registering[d].load() > (ctx->counted_registering ? 1 : 0);
+}
 
 static int fail(icp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->error = msg;
@@ -310,6 +336,7 @@ int icp_create(const icp_config* cfg, icp_ctx** out) {
 void icp_destroy(icp_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard device_guard(ctx);
+    registering_leave(ctx);
     (void)hipDeviceSynchronize();
     DeviceBuffer* bufs[] = {&ctx->map_xyz[0], &ctx->map_xyz[1], &ctx->table,   &ctx->sorted_pts, &ctx->normals,
                             &ctx->nflag,      &ctx->slot_of,    &ctx->rank_of, &ctx->scan_tmp,   &ctx->worklist,
@@ -1416,6 +1443,7 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     if (!ctx->normals_ready && wants_eager_normals(ctx, n) && (rc = launch_normals_all(ctx))) return rc;
     // ... or on demand inside the fused iteration kernel, where the scan touches a small part of the map ("lazy_fused")
     ctx->lazy_now = !ctx->normals_ready && wants_lazy_fused(ctx, n);
+    registering_enter(ctx);
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     ctx->cache_fresh = false;
@@ -1588,7 +1616,10 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         if (rc_rec) return rc_rec;
         if (async) pinned = recovered.data();
     }
-    if (ctx->r_count == 0) ctx->update_behind_registration = false;
+    if (ctx->r_count == 0) {
+        ctx->update_behind_registration = false;
+        registering_leave(ctx);
+    }
     if (had_stats && st.grid_cells > 0) {
         ctx->occupied_cells = st.grid_cells;
         ctx->stats_m = stats_m;
@@ -1748,7 +1779,8 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
     // lead launches: the solve of iteration k rides in the head of launch k + 1 (LeadArgs, icp_internal.h); one summing /
     // solving launch remains, behind the last iteration.  Not with the host polling in between (it reads the RegState,
     // which would lag one iteration) and not with the in-library exchange (its solve waits for the peers)
-    const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0;
+    const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0 &&
+                      !device_shared_with_another_registration(ctx);
     int prev_rows = 0, prev_quad = 1;  // rows a lead launch still has to solve
     for (int it = first; it < iters; ++it) {
         if (lead && fused_tail_possible(ctx, prev_rows, iters - it)) {
@@ -1817,7 +1849,8 @@ static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, i
     const int iters = ctx->cfg.max_num_alignments;
     int first_chunk = iters;
     // (lead launches that end in a resident tail run to the end of the loop on the device: nothing to chunk)
-    const bool tail = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && fused_tail_planned(ctx, iters);
+    const bool tail = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && fused_tail_planned(ctx, iters) &&
+                      !device_shared_with_another_registration(ctx);
     if (ctx->cfg.threshold_delta_pose > 0.f && ctx->chunked_launch && !tail) {
         first_chunk = (ctx->last_iterations > 0 ? ctx->last_iterations : 3) + 1;
         if (first_chunk > iters) first_chunk = iters;

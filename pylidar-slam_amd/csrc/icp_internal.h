@@ -393,6 +393,7 @@ struct icp_ctx {
     bool tail_disabled = false;        // a hand-off of this context timed out once (a GPU shared with foreign work): per-iteration launches from then on
     int tail_capacity = -1;            // workgroups of the tail's shape the device holds at once (-1: not asked yet)
     int handoff_fallbacks = 0;         // registrations finished on per-iteration launches behind a timed-out hand-off
+    bool counted_registering = false;  // this context is counted among the registering contexts of its device (api.hip)
     bool update_behind_registration = false;  // a pose-only map update by the device pose is enqueued behind an uncollected registration
     icp::DeviceBuffer tail_rows;       // tagged super-rows of the tail: [rows][NEQ][2] granules of 8 bytes
     icp::DeviceBuffer vox_out;         // staging of icp_voxel_statistics' host outputs

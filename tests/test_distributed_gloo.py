@@ -129,15 +129,16 @@ def test_shard_bounds_tile_the_scan():
         shard_bounds(10, 2, 2)
 
 
-def test_sharded_registration_world2_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])  # (8: the node the driver's scaling runs use — uneven shards, 8-way all-reduce)
+def test_sharded_registration_matches_single_process(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = np.load(out)
     # every rank ends with the identical pose (same all-reduced vector, same solve)
-    assert np.array_equal(got["all"][0], got["all"][1])
+    assert all(np.array_equal(got["all"][0], got["all"][r]) for r in range(1, world))
     # and it is the single-process registration of the whole scan
     from pylidar_slam_amd.distributed import sharded_register
     model, scan = _workload()
