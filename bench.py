@@ -1042,6 +1042,9 @@ def main():
                                "frac_long": (BYTES_PER_POINT_ITER * n_local / (long_us * 1e-6) / HBM_PEAK) if long_us else None,
                                "event_overhead_us": overhead, "event_pair_on_20us_spin_kernel_us": event_floor_us + 20.0,
                                "rocprof_spin_kernel_us": spin_us,
+                               # (the calibration constant comes from a committed trace: its commit is printed with it —
+                               # where it is not this build's, read avg_launch_us_raw_events as the upper bound)
+                               "rocprof_spin_kernel_from": {"file": (rp or {}).get("file"), "head": (rp or {}).get("head")},
                                "avg_launch_us_by_iteration_raw": per_iter_us,
                                "launches": prof["search_launches"],
                                "timed_frames": "one iteration launch of every timed frame (launch = frame number mod "

@@ -854,7 +854,7 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             # so the registration walks N rows — and estimates normals lazily for what N rows touch — instead of H * W
             n_in = self._tgt_pc.shape[0] if (self._tgt_pc is not None and not self._pc_is_pixels) else h * w
             if pixels.is_cuda and 2 * n_in <= h * w and hasattr(self.ctx, "compact_targets") and \
-                    bool(_get(self.config, "compact_sparse_vertex_map", True)):
+                    bool(_get(self.config, "compact_sparse_vertex_map", False)):
                 return self.ctx.compact_targets(pixels, n_in, skip_null=True), True
             return pixels, True
         return self._tgt_pc, self._pc_is_pixels

@@ -483,3 +483,33 @@ def test_staged_map_update_equals_the_direct_update(torch_cuda):
         for a, b in zip(results, ref[3]):
             np.testing.assert_array_equal(a.pose, b.pose, err_msg=str(key))
             np.testing.assert_array_equal(a.losses, b.losses, err_msg=str(key))
+
+
+def test_masked_sparse_vertex_map_equals_the_compacted_one(torch_cuda):
+    """`sample_points` of the reference (icp_odometry.py:301-308) keeps the non-null pixels of the new vertex map.  The
+    plugin either compacts them on the device (`compact_sparse_vertex_map: true`, round 4) or hands all H x W pixels to
+    the registration, which masks the null ones in its kernels (default since round 5).  Same targets in the same pixel
+    order: the same iteration counts, and poses equal up to the summation order of the float32 normal equations (the
+    rows sit in other workgroups)."""
+    torch = torch_cuda
+    from pylidar_slam_amd import odometry as our
+    scans, _ = _scans(32, 1024, 5)
+    runs = {}
+    for compact in (True, False):
+        cfg = our.MI355XICPConfig(sample_pointcloud=False, compact_sparse_vertex_map=compact, max_num_alignments=10,
+                                  threshold_delta_pose=1e-4)
+        odo = our.MI355XICPFrameToModel(cfg, projector=our.SphericalProjector(32, 1024), device=torch.device("cuda:0"))
+        odo.init()
+        poses, iters = [], []
+        for s in scans:
+            # a grid-sampled frame: a few thousand of the 32768 pixels are set
+            pts, _ = our.grid_sample(s, 0.4)
+            d = {"input_data": torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()}
+            odo.process_next_frame(d)
+            if "odometry_pose" in d:
+                poses.append(np.asarray(d["odometry_pose"]))
+                iters.append(int(odo.last_result.iterations))
+        runs[compact] = (np.stack(poses), iters)
+        assert odo.ctx.handoff_fallbacks() == 0
+    assert runs[True][1] == runs[False][1]
+    np.testing.assert_allclose(runs[True][0], runs[False][0], atol=2e-6, rtol=0)
