@@ -518,6 +518,8 @@ def odometry_loop_leg(args, device_index, frames=36):
            "ms_per_frame_full_window": float(np.mean(per_frame[30:])) if frames > 31 else None,
            "ms_per_frame_spread": {"min": min(per_frame[1:]), "median": sorted(per_frame[1:])[len(per_frame[1:]) // 2],
                                    "max": max(per_frame[1:])},
+           "ms_by_frame": [round(v, 3) for v in per_frame],
+           "iterations_by_frame": iters,
            "iterations_per_frame": {"min": min(iters), "mean": float(np.mean(iters)), "max": max(iters)},
            "samples_per_frame_mean": float(np.mean(samples)), "map_points_end": int(odo.ctx.map_size()),
            "map_clouds_end": int(odo.ctx.map_num_clouds()), "ate_vs_ground_truth_m": float(ate),

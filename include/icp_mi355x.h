@@ -221,6 +221,11 @@ int icp_set_cost(icp_ctx* ctx, int32_t cost);
  * xyz [n,3] -> vertex map [3,H,W] planar (zeros where empty), nearest point wins each pixel.
  * index_out (optional, [H*W] int32): winning point index per pixel, -1 where empty. */
 int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_out, int32_t* index_out, int out_mem);
+/* The same projection for the DEVICE-RESIDENT pipeline (device pointers only): vmap_out [3,H,W] as above and rows_out
+ * [H*W,3] = the same pixels as rows, i.e. vmap.permute(1, 2, 0).reshape(-1, 3) — what ICPFrameToModel.sample_points
+ * (slam/odometry/icp_odometry.py:301-308) indexes and the registration takes as targets — written by the same launch
+ * instead of a transposing copy per frame. */
+int icp_project_rows(icp_ctx* ctx, const float* xyz, int64_t n, float* vmap_out, float* rows_out);
 /* torch__spherical_projection (slam/common/projection.py:11-73): float pixel coordinates rows/cols [n] (diagnostics) */
 int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
                        int out_mem);

@@ -81,11 +81,9 @@ static void prof_collect(icp_ctx* ctx) {
 // ---- small kernels owned by the API layer ---------------------------------------------------------------------------
 __global__ void k_state_init(RegState* st, Pose16 init, int keep_pose, unsigned long long* box, unsigned gen,
                              float* hist) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    state_init(st, init.m, keep_pose);
-    if (box) box_publish_serial(box, gen, st->pose, 0, 0);  // generation `gen` of the pose mailbox: the initial guess
-    if (hist)
-        for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // pose history, entry 0
+    if (threadIdx.x >= 64 || blockIdx.x != 0) return;
+    // the state, generation `gen` of the pose mailbox (the initial guess) and entry 0 of the pose history
+    state_init_wave(st, init.m, keep_pose, box, gen, hist, (int)threadIdx.x);
 }
 
 // what an event pair adds: icp_profile_event_floor brackets this kernel like a real launch — it spins for `ticks` of the
@@ -511,6 +509,12 @@ int icp_project(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* vmap_
     return ICP_OK;
 }
 
+int icp_project_rows(icp_ctx* ctx, const float* xyz, int64_t n, float* vmap_out, float* rows_out) {
+    DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
+    if (!ctx || n < 0 || (n > 0 && !xyz) || !vmap_out || !rows_out) return ICP_ERR_INVALID_ARGUMENT;
+    return project_device(ctx, xyz, n, vmap_out, nullptr, false, rows_out);
+}
+
 int icp_project_pixels(icp_ctx* ctx, const float* xyz, int64_t n, int mem, float* rows_out, float* cols_out,
                        int out_mem) {
     DeviceGuard device_guard(ctx, false);  // (beside a map update on its own stream)
@@ -645,9 +649,8 @@ static int grid_sample_padded(icp_ctx* ctx, const void* xyz, int64_t n, double v
         ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
         return ICP_OK;
     }
-    // rows behind the V samples: NaN points (0xFFFFFFFF / 0xFFFFFFFFFFFFFFFF are NaNs), index -1
-    ICP_HIP(ctx, hipMemsetAsync(points_out, 0xFF, (size_t)n * 3 * elem, ctx->stream));
-    if (indices_out) ICP_HIP(ctx, hipMemsetAsync(indices_out, 0xFF, (size_t)n * 8, ctx->stream));
+    // rows behind the V samples: NaN points (0xFFFFFFFF / 0xFFFFFFFFFFFFFFFF are NaNs), index -1 — filled by the first launch
+    // of the sample
     int unused = 0;
     if (elem == 4)
         return grid_sample_device(ctx, (const float*)xyz, n, voxel_size, (long long*)indices_out, (float*)points_out, count_dev,
@@ -918,16 +921,13 @@ int icp_map_stage_cloud(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int 
     if (n > 0) {
         const void* in = nullptr;
         if ((rc = import_buffer(ctx, xyz, (size_t)n * 12, mem, ctx->stage_in, &in))) return rc;
-        ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
         ICP_HIP(ctx, ctx->staged_xyz.reserve((size_t)n * 12));
-        hipLaunchKernelGGL(k_flag_not_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)in,
-                           (long long)n, row_mode == ICP_TARGETS_SKIP_NULL ? 1 : 0, ctx->flags.as<int>());
-        int* count_dev = ctx->counter.as<int>();
-        if ((rc = compact_rows(ctx, (const float*)in, ctx->flags.as<int>(), n, 3, ctx->staged_xyz.as<float>(), count_dev)))
+        // two launches; the second one stores the count straight into the pinned word (mapped into the device)
+        int* count_mapped = nullptr;
+        ICP_HIP(ctx, hipHostGetDevicePointer((void**)&count_mapped, ctx->staged_count_host, 0));
+        if ((rc = compact_valid_rows(ctx, (const float*)in, n, row_mode == ICP_TARGETS_SKIP_NULL,
+                                     ctx->staged_xyz.as<float>(), nullptr, -1, count_mapped)))
             return rc;
-        // (the flags, the scan space and the counter are the context's scratch: whatever is enqueued next may reuse them —
-        // behind this copy, in stream order)
-        ICP_HIP(ctx, hipMemcpyAsync(ctx->staged_count_host, count_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
     }
     ICP_HIP(ctx, hipEventRecord(ctx->staged_event, ctx->stream));
@@ -961,10 +961,7 @@ int icp_compact_targets(icp_ctx* ctx, const float* xyz, int64_t n, int target_mo
     if (rc) return rc;
     if (cap > 0) ICP_HIP(ctx, hipMemsetAsync(out, 0, (size_t)cap * 12, ctx->stream));
     if (n == 0 || cap == 0) return ICP_OK;
-    ICP_HIP(ctx, ctx->flags.reserve((size_t)n * 4));
-    hipLaunchKernelGGL(k_flag_not_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz, (long long)n,
-                       target_mode == ICP_TARGETS_SKIP_NULL ? 1 : 0, ctx->flags.as<int>());
-    return compact_rows(ctx, xyz, ctx->flags.as<int>(), n, 3, out, ctx->counter.as<int>(), cap);
+    return compact_valid_rows(ctx, xyz, n, target_mode == ICP_TARGETS_SKIP_NULL, out, ctx->counter.as<int>(), cap, nullptr);
 }
 
 int icp_map_update_vertex_map(icp_ctx* ctx, const float rel_pose[16], const float* vmap, int mem,

@@ -99,8 +99,15 @@ struct DedupeSlot {
     int pad;
 };
 
-__global__ void k_dedupe_clear(DedupeSlot* __restrict__ table, unsigned int size, int* __restrict__ side) {
+// + (padded outputs) the 0xFF bytes behind the samples — NaN points, index -1: the same launch writes them (two memset
+// launches less in front of every frame)
+__global__ void k_dedupe_clear(DedupeSlot* __restrict__ table, unsigned int size, int* __restrict__ side,
+                               unsigned* __restrict__ fill_a, unsigned long long words_a, unsigned* __restrict__ fill_b,
+                               unsigned long long words_b) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long w = i; w < words_a; w += stride) fill_a[w] = 0xFFFFFFFFu;
+    for (unsigned long long w = i; w < words_b; w += stride) fill_b[w] = 0xFFFFFFFFu;
     if (i < size) {
         DedupeSlot e;
         e.key = DEDUPE_EMPTY;
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(BUCKET_THREADS) void k_bucket_sort_emit(const unsig
 }
 
 // padded = true: nothing is read back — the outputs hold n rows, the V samples first, NaN points / index -1 behind them
-// (the caller filled them with 0xFF bytes), *count_dev = V on the device only
+// (0xFF bytes, written by the first launch), *count_dev = V on the device only
 template <typename T>
 static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double voxel, long long* indices_dev,
                             T* points_dev, int* count_dev, int* count_host, bool padded = false) {
@@ -580,7 +587,12 @@ static int grid_sample_impl(icp_ctx* ctx, const T* xyz_dev, int64_t n, double vo
     int* vb = ctx->vals_b.as<int>();
     int* side = ctx->flags.as<int>();
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_dedupe_clear, dim3((tsize + 255) / 256), dim3(256), 0, ctx->stream, table, tsize, side);
+    // (padded: the outputs hold n rows — NaN points / index -1 behind the samples the sort below emits)
+    hipLaunchKernelGGL(k_dedupe_clear, dim3((tsize + 255) / 256), dim3(256), 0, ctx->stream, table, tsize, side,
+                       padded ? reinterpret_cast<unsigned*>(points_dev) : nullptr,
+                       padded && points_dev ? (unsigned long long)n * 3 * (sizeof(T) / 4) : 0ull,
+                       padded ? reinterpret_cast<unsigned*>(indices_dev) : nullptr,
+                       padded && indices_dev ? (unsigned long long)n * 2 : 0ull);
     hipLaunchKernelGGL(k_hash_dedupe<T>, dim3(nb), dim3(256), 0, ctx->stream, xyz_dev, (int)n, voxel, table, tsize - 1,
                        side);
     hipLaunchKernelGGL(k_hash_collect, dim3(COLLECT_BLOCKS), dim3(COLLECT_THREADS), 0, ctx->stream, table, tsize, side,
@@ -810,11 +822,9 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 __global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __restrict__ out, RegState* st, Pose16 init,
                                int keep_pose, unsigned long long* box, unsigned gen, float* hist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (st && i == 0) {
-        state_init(st, init.m, keep_pose);  // the registration state, by the same launch
-        box_publish_serial(box, gen, st->pose, 0, 0);  // ... and the initial guess as generation `gen` of the pose mailbox
-        for (int k = 0; k < 12; ++k) hist[k] = st->pose[k];  // ... and as entry 0 of the pose history
-    }
+    // the registration state, the initial guess as generation `gen` of the pose mailbox and as entry 0 of the pose history,
+    // by the first wave of the same launch
+    if (st && i < 64) state_init_wave(st, init.m, keep_pose, box, gen, hist, i);
     if (i >= n) return;
     out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }

@@ -158,6 +158,80 @@ int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ordered compaction of the VALID rows of an [n,3] cloud (no NaN; not null under skip_null) in two launches (round 5: the
+// generic form above — flags, three scan launches, scatter, count copy — was seven launches on the critical path of every
+// frame of the device-resident pipeline): tile counts, then every tile sums the counts of the tiles in front of it (a few
+// hundred integers), scans its own flags and scatters.  The last tile leaves the total in *count_dev and, when given, in
+// *count_host (pinned host memory mapped into the device: no copy launch).
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int CV_THREADS = 256, CV_ROUNDS = 4, CV_TILE = CV_THREADS * CV_ROUNDS;
+
+__device__ inline int row_is_valid(const float* __restrict__ xyz, long long i, long long n, int skip_null) {
+    if (i >= n) return 0;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(x == x && y == y && z == z)) return 0;
+    return (skip_null && x == 0.f && y == 0.f && z == 0.f) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(CV_THREADS) void k_valid_tile_counts(const float* __restrict__ xyz, long long n,
+                                                                  int skip_null, int* __restrict__ counts) {
+    __shared__ int lds[8];
+    const long long base = (long long)blockIdx.x * CV_TILE + threadIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < CV_ROUNDS; ++k) s += row_is_valid(xyz, base + (long long)k * CV_THREADS, n, skip_null);
+    int tot;
+    block_exclusive_scan(s, &tot, lds);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(CV_THREADS) void k_valid_compact(const float* __restrict__ xyz, long long n, int skip_null,
+                                                              const int* __restrict__ counts, float* __restrict__ out,
+                                                              long long cap, int* __restrict__ count_dev,
+                                                              int* __restrict__ count_host) {
+    __shared__ int lds[8];
+    int before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += CV_THREADS) before += counts[t];
+    int running;
+    block_exclusive_scan(before, &running, lds);  // (total of the tiles in front)
+    const long long base = (long long)blockIdx.x * CV_TILE + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < CV_ROUNDS; ++k) {  // rows base + k * 256 + thread: round by round in row order
+        const long long i = base + (long long)k * CV_THREADS;
+        const int f = row_is_valid(xyz, i, n, skip_null);
+        int tot;
+        const long long o = running + block_exclusive_scan(f, &tot, lds);
+        if (f && o < cap) {
+            out[3 * o] = xyz[3 * i];
+            out[3 * o + 1] = xyz[3 * i + 1];
+            out[3 * o + 2] = xyz[3 * i + 2];
+        }
+        running += tot;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (count_dev) *count_dev = running;
+        if (count_host) __hip_atomic_store(count_host, running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int compact_valid_rows(icp_ctx* ctx, const float* xyz, int64_t n, bool skip_null, float* out, int* count_dev,
+                       int64_t cap, int* count_host_mapped) {
+    if (n <= 0) {
+        if (count_dev) ICP_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(int), ctx->stream));
+        return ICP_OK;  // (*count_host: the caller's zero stands)
+    }
+    const int nb = (int)((n + CV_TILE - 1) / CV_TILE);
+    ICP_HIP(ctx, ctx->scan_tmp.reserve((size_t)nb * sizeof(int)));
+    int* counts = ctx->scan_tmp.as<int>();
+    hipLaunchKernelGGL(k_valid_tile_counts, dim3(nb), dim3(CV_THREADS), 0, ctx->stream, xyz, (long long)n,
+                       skip_null ? 1 : 0, counts);
+    hipLaunchKernelGGL(k_valid_compact, dim3(nb), dim3(CV_THREADS), 0, ctx->stream, xyz, (long long)n, skip_null ? 1 : 0,
+                       counts, out, (long long)(cap >= 0 ? cap : n), count_dev, count_host_mapped);
+    ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // grid build
 // ---------------------------------------------------------------------------------------------------------------------
 // + (seed_n > 0) the neighbours the last registration left in the NN cache -> original map indices, shifted by the

@@ -126,14 +126,6 @@ __device__ inline void box_store(unsigned long long* __restrict__ box, unsigned 
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// published by ONE thread (the state-initialising thread of a registration)
-__device__ inline void box_publish_serial(unsigned long long* __restrict__ box, unsigned gen, const float* pose, int done,
-                                          int iter) {
-    for (int k = 0; k < 12; ++k) box_store(box, gen, k, __float_as_uint(pose[k]));
-    box_store(box, gen, 12, (unsigned)done);
-    box_store(box, gen, 13, (unsigned)iter);
-}
-
 // what a fused iteration launch needs to know about the hand-off (box == nullptr: classic launch, pose from the RegState)
 struct LeadArgs {
     unsigned long long* box = nullptr;
@@ -148,19 +140,41 @@ struct LeadArgs {
     long long timeout_ticks = 0;     // 100 MHz wall clock
 };
 
+// The start of a registration by the 64 lanes of ONE wave (round 5: the serial form — state_init, then 224 mailbox stores
+// and 12 history stores by one thread, each behind the one before — was 5-6 us of every frame's critical path): the state
+// (state_init's fields, same values), generation `gen` of the pose mailbox = the initial guess, entry 0 of the pose history.
+// Call with all 64 lanes of a wave active; `lane` = lane index.
 // keep_pose: the initial guess is the pose the state already holds — the result of the previous registration, i.e. the
-// constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip
-__device__ inline void state_init(RegState* st, const float* init, int keep_pose) {
-    st->handoff_timeouts = 0;
-    for (int k = 0; k < 16; ++k) st->pose[k] = st->pose_prev[k] = keep_pose ? st->pose[k] : init[k];
-    for (int k = 0; k < 6; ++k) st->params[k] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
-    st->iter = 0;
-    st->done = 0;
-    st->converged = 0;
-    st->status = 0;
-    st->n_targets = 0;
-    st->n_worklist = 0;
-    st->normals_computed = 0;
+// constant-velocity initialisation (slam/initialization.py:103-119) without a host round trip.
+__device__ inline void state_init_wave(RegState* st, const float* init, int keep_pose, unsigned long long* __restrict__ box,
+                                       unsigned gen, float* __restrict__ hist, int lane) {
+    float p = 0.f;
+    if (lane < 16) {
+        p = keep_pose ? st->pose[lane] : init[lane];
+        st->pose[lane] = p;
+        st->pose_prev[lane] = p;
+    } else if (lane < 22) {
+        st->params[lane - 16] = 0.f;  // new_pose_params = zeros (icp_odometry.py:267)
+    } else if (lane == 22) {
+        st->handoff_timeouts = 0;
+        st->iter = 0;
+        st->done = 0;
+        st->converged = 0;
+        st->status = 0;
+        st->n_targets = 0;
+        st->n_worklist = 0;
+        st->normals_computed = 0;
+    }
+    if (hist && lane < 12) hist[lane] = p;
+    if (box) {
+        for (int idx = lane; idx < BOX_USED * BOX_REPLICAS; idx += 64) {
+            const int k = idx / BOX_REPLICAS, r = idx % BOX_REPLICAS;
+            const float v = __shfl(p, k < 12 ? k : 0, 64);  // (all lanes of the wave take part in the shuffle)
+            const unsigned bits = k < 12 ? __float_as_uint(v) : 0u;  // granule 12: done = 0, 13: iteration 0
+            __hip_atomic_store(const_cast<unsigned long long*>(box_granule(box, gen, r, k)),
+                               ((unsigned long long)gen << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 static constexpr size_t STATE_BLOCK = 256;  // bytes reserved for the RegState at the head of the state allocation
@@ -481,6 +495,10 @@ int exclusive_scan_i32(icp_ctx* ctx, const int* in, int* out, int64_t n, int* to
 // ordered compaction: copies rows (row_floats floats each) whose flag != 0; count to *count_dev
 int compact_rows(icp_ctx* ctx, const float* in, const int* flags, int64_t n, int row_floats, float* out,
                  int* count_dev, int64_t cap = -1);
+// the valid rows of an [n,3] cloud (no NaN; not null under skip_null), in order, in two launches; the count lands in
+// *count_dev and (when given) in *count_host_mapped — pinned host memory, device-visible address
+int compact_valid_rows(icp_ctx* ctx, const float* xyz, int64_t n, bool skip_null, float* out, int* count_dev, int64_t cap,
+                       int* count_host_mapped);
 
 // ---- search.hip
 int launch_search_raw(icp_ctx* ctx);  // 1-NN without the pose transform (LocalMap seam)
@@ -524,7 +542,9 @@ int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, con
                            const float* mu_tgt, const float* mu_ref, double* host_out);
 
 // ---- projection.hip
-int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys = false);  // keep_keys: the z-buffer keys stay for the caller
+// keep_keys: the z-buffer keys stay for the caller; rows_dev (optional): the same pixels as [H*W, 3] rows
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys = false,
+                   float* rows_dev = nullptr);
 int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
 int kitti_correct_device(icp_ctx* ctx, const float* scan_dev, int64_t n, int stride, double* out_dev);
 

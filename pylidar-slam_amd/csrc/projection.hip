@@ -55,7 +55,8 @@ __global__ void k_project(const float* __restrict__ xyz, int n, ProjParams pp, u
 }
 
 __global__ void k_project_resolve(const float* __restrict__ xyz, unsigned long long* __restrict__ zbuf, int npix,
-                                  float* __restrict__ vmap, int* __restrict__ index, int leave_clean) {
+                                  float* __restrict__ vmap, int* __restrict__ index, int leave_clean,
+                                  float* __restrict__ rows) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     const unsigned long long k = zbuf[p];
@@ -74,6 +75,11 @@ __global__ void k_project_resolve(const float* __restrict__ xyz, unsigned long l
         vmap[2 * npix + p] = z;
     }
     if (index) index[p] = idx;
+    if (rows) {  // the same pixels as [H*W, 3] rows (= vmap.permute(1, 2, 0).reshape(-1, 3): what sample_points reads)
+        rows[3 * p] = x;
+        rows[3 * p + 1] = y;
+        rows[3 * p + 2] = z;
+    }
 }
 
 __global__ void k_project_pixels(const float* __restrict__ xyz, int n, ProjParams pp, float* __restrict__ rows,
@@ -130,7 +136,8 @@ static ProjParams proj_params(const icp_ctx* ctx) {
     return pp;
 }
 
-int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys) {
+int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys,
+                   float* rows_dev) {
     const int npix = ctx->cfg.height * ctx->cfg.width;
     ICP_HIP(ctx, ctx->zbuf.reserve((size_t)npix * sizeof(unsigned long long)));
     unsigned long long* zb = ctx->zbuf.as<unsigned long long>();
@@ -144,7 +151,7 @@ int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_de
         hipLaunchKernelGGL(k_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n, pp,
                            zb);
     hipLaunchKernelGGL(k_project_resolve, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, xyz_dev, zb, npix,
-                       vmap_dev, index_dev, keep_keys ? 0 : 1);
+                       vmap_dev, index_dev, keep_keys ? 0 : 1, rows_dev);
     if (keep_keys) ctx->zbuf_clean = nullptr;  // the caller reads the (range, ~index) keys: cleared by the next projection
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;

@@ -505,7 +505,7 @@ __device__ __forceinline__ void walk_found_w(const GridView& lv, const int2 (&fo
             const int j = min(j0 + W * m + sub, T - 1);  // (a clamped tail re-reads the last candidate: harmless)
             int e = 0;
 #pragma unroll
-            for (int s2 = 64; s2 > 0; s2 >>= 1) {  // (C <= 7 W <= 112)
+            for (int s2 = (7 * W > 128 ? 256 : 64); s2 > 0; s2 >>= 1) {  // (C <= 7 W: 112 at W = 16, 448 at W = 64)
                 const int t = e + s2;
                 if (t < C && col0[(t / W) * stride + (t % W)].y <= j) e = t;
             }
@@ -587,6 +587,36 @@ __device__ __forceinline__ Best search_far_w(const GridView& g, float px, float 
         if (ok) return b;
     }
     // farther than COARSE_RINGS coarse cells from every map point: every point is seen, .second = the second nearest
+    b.d2 = INFINITY;
+    b.idx = 0x7fffffff;
+    b.pos = -1;
+    b.second = INFINITY;
+    for (int k = sub; k < g.m; k += W) consider(g.pts[k], k, px, py, pz, b);
+    group_min_w<W>(b);
+    return b;
+}
+
+// one query by its W lanes from the COARSE level on (rings 0 .. COARSE_RINGS of the 4x cells — every map point is in
+// them, so the level is exact by itself — then the exhaustive scan): for a query the fine rings have not settled.  Round 5:
+// a whole wave takes it (W = 64) where a workgroup has a handful of misses; the 4-lane group such a query used to fall
+// back to walked 27+ hashed probes and several hundred candidates of the coarse cells in ~100 us — the duration of the
+// launch, in every iteration of a frame with a dozen targets a metre away from the map (the published-configuration loop:
+// frames of 0.70 ms among frames of 0.33).
+template <int W>
+__device__ __forceinline__ Best search_coarse_w(const GridView& g, float px, float py, float pz, int sub,
+                                                int2* __restrict__ col0, int stride, float seed_d2, int seed_idx,
+                                                int seed_pos) {
+    Best b;
+    b.d2 = sub == 0 ? seed_d2 : INFINITY;
+    b.idx = sub == 0 ? seed_idx : 0x7fffffff;
+    b.pos = sub == 0 ? seed_pos : -1;
+    b.second = INFINITY;
+    if (g.ctable) {
+        // candidates of the coarse level carry positions of ITS point array: the winner is identified by its original index
+        const bool ok = far_rings_w<W>(coarse_view(g), px, py, pz, sub, 0, COARSE_RINGS, b, col0, stride);
+        if (b.idx != 0x7fffffff) b.pos = g.pos_of_orig[b.idx];
+        if (ok) return b;
+    }
     b.d2 = INFINITY;
     b.idx = 0x7fffffff;
     b.pos = -1;
@@ -1721,14 +1751,26 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // duration of the launch.  Whatever the wave path does not settle stays on the list for B2.
     if (nmiss > 0 && nmiss <= in.wave_misses) {  // block-uniform
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, listed = nmiss;
-        int* wl = reinterpret_cast<int*>(&cellstack[0][0]) + wave * 64;  // the cell stacks are idle until B2
+        // (the cell stacks are idle until B2: the wave's own 64 columns — row 0 for the ring-1 lists, all seven rows for a
+        // search that goes on to the coarse level)
+        int* wl = reinterpret_cast<int*>(&cellstack[0][wave * 64]);
         for (int m = wave; m < listed; m += THREADS / 64) {
             const float4 mp = miss_p[m];
             const int4 ms = miss_seed[m];
             Best b, r2, r3;
             if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b, &r2,
-                                  &r3))
-                continue;
+                                  &r3)) {
+                // not settled by the fine rings 1-2: the coarse level by the same wave (the resident tail leaves it to the
+                // 4-lane groups of B2: the 64-lane lists are not compiled into its loop)
+                if constexpr (TAIL) {
+                    continue;
+                } else {
+                    if (g.dbg && lane == 0) atomicAdd(&g.dbg[3], 1);
+                    b = search_coarse_w<64>(g, mp.x, mp.y, mp.z, lane, &cellstack[0][wave * 64], THREADS,
+                                            __int_as_float(ms.x), ms.y, ms.z);
+                    r2.pos = r3.pos = -1;
+                }
+            }
             if (lane == 0) {
                 const int lq = __float_as_int(mp.w);
                 // the runner-up and the third ride along: L then bounds everything but the set

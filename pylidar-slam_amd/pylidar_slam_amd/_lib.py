@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = {
     "icp_map_normals_owned": (_INT, [_P, C.c_int32, C.c_int32, _P]),
     "icp_map_normals_install": (_INT, [_P, _P]),
     "icp_project": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
+    "icp_project_rows": (_INT, [_P, _P, _I64, _P, _P]),
     "icp_project_pixels": (_INT, [_P, _P, _I64, _INT, _P, _P, _INT]),
     "icp_kitti_correct_scan": (_INT, [_P, _P, _I64, _INT, _INT, _P, _INT]),
     "icp_grid_sample": (_INT, [_P, _P, _I64, _INT, C.c_double, _P, _P, C.POINTER(_I64), _INT]),

@@ -165,6 +165,19 @@ class IcpContext:
                                               idx.ctypes.data if idx is not None else None, MEM_HOST))
         return (vmap, idx) if with_index else vmap
 
+    def project_rows(self, points: torch.Tensor):
+        """Device-resident projection: (vertex map [3, H, W], the same pixels as rows [H * W, 3]) from one launch — the rows
+        are `vmap.permute(1, 2, 0).reshape(-1, 3)` without the transposing copy."""
+        self._bind(points)
+        p, mem, keep = _ptr_mem(points)
+        if mem != MEM_DEVICE:
+            raise AssertionError("project_rows takes a device tensor")
+        h, w = self.config.height, self.config.width
+        vmap = torch.empty((3, h, w), dtype=torch.float32, device=keep.device)
+        rows = torch.empty((h * w, 3), dtype=torch.float32, device=keep.device)
+        self._check(self._lib.icp_project_rows(self._h, p, int(keep.shape[0]), vmap.data_ptr(), rows.data_ptr()))
+        return vmap, rows
+
     def project_pixels(self, points: np.ndarray):
         p, mem, keep = _ptr_mem(points)
         n = int(keep.shape[0])

@@ -782,6 +782,7 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self.last_result: Optional[RegisterResult] = None
         self._iter = 0
         self._tgt_vmap = None
+        self._tgt_rows = None
         self._tgt_pc = None
         self._delta_since_map_update = np.eye(4, dtype=np.float32)
         self._host_rows = None
@@ -814,6 +815,7 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         data = data_dict[key]
         self._tgt_vmap = None
         self._tgt_pc = None
+        self._tgt_rows = None
         self._host_rows = None
         self._staged = False
         if isinstance(data, np.ndarray):
@@ -836,7 +838,12 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             else:
                 assert_debug(data.ndim == 2)
                 pc = data.to(self.device, torch.float32).contiguous()
-                vmap = self.ctx.project(pc)
+                if not self._sample_pointcloud and pc.is_cuda and hasattr(self.ctx, "project_rows"):
+                    # the targets will be the pixels of this vertex map (sample_points): the projection writes them as
+                    # rows too, instead of a transposing copy per frame
+                    vmap, self._tgt_rows = self.ctx.project_rows(pc)
+                else:
+                    vmap = self.ctx.project(pc)
         else:
             raise RuntimeError(f"Could not interpret the data: {data} as a pointcloud tensor")
         # modify_nan_pmap (:356): a projected map never holds a NaN (NaN rows fail the pixel-validity test); a
@@ -848,7 +855,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
     def sample_points(self):  # :301-308 — returns (device rows, skip_null)
         if not self._sample_pointcloud:
             h, w = self._tgt_vmap.shape[-2:]
-            pixels = self._tgt_vmap.permute(1, 2, 0).reshape(h * w, 3).contiguous()
+            pixels = self._tgt_rows if self._tgt_rows is not None else \
+                self._tgt_vmap.permute(1, 2, 0).reshape(h * w, 3).contiguous()
             # the non-null pixels (:303-305).  A vertex map projected from N points has at most N of them: when that is
             # well below H * W (a grid-sampled frame: 6 000 of 131 072) they are compacted on the device, in pixel order,
             # so the registration walks N rows — and estimates normals lazily for what N rows touch — instead of H * W

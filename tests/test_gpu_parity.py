@@ -895,6 +895,55 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
     np.testing.assert_allclose(d_used ** 2, bd ** 2, rtol=4e-6, atol=1e-12)
 
 
+def test_targets_far_from_the_map_in_the_fused_kernel(torch_cuda):
+    """No distance cap (local_map.py:385-386) INSIDE the fused iteration kernel: a sparse frame (a few thousand targets over
+    131 072 pixels, a handful of cache misses per workgroup — the published configuration's shape) in which some targets sit
+    1-6 m away from every map point (own cell empty, fine rings 1-2 empty: the coarse level, searched by a whole wave since
+    round 5) and a few hundreds of metres away (the exhaustive scan).  The neighbour of every target after the last
+    iteration (icp_last_neighbors) is the kd-tree's; and the schedules that send those queries down other paths — 4-lane
+    groups only, 16 lanes, no ball search — give the same registration bit for bit."""
+    from scipy.spatial import cKDTree
+    scans, poses, model = _bench_workload()
+    rng = np.random.default_rng(3)
+    frame = np.full((131072, 3), np.nan, np.float32)
+    keep = rng.choice(131072, 6000, replace=False)
+    frame[keep] = scans[3][keep]
+    far = rng.choice(keep, 60, replace=False)
+    frame[far[:40], 2] += rng.uniform(1.5, 6.0, 40).astype(np.float32)       # above the scene: beyond the fine rings
+    frame[far[40:52]] += np.float32(40.0)                                    # beyond a few coarse rings
+    frame[far[52:]] = (rng.normal(size=(8, 3)) * 50 + 400).astype(np.float32)  # beyond every ring: exhaustive
+    variants = {"default": {}, "four_lanes_only": {"wave_misses": 0, "far_lanes": 0}, "no_ball_search": {"ball_search": 0},
+                "never_wide": {"wide_until": 0}, "far_lanes_from_1": {"far_min": 0}}
+    results = {}
+    for name, opts in variants.items():
+        ctx = _ctx(height=64, width=2048, max_num_alignments=4, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.map_set(model)
+        r = ctx.register(frame)
+        ix, pose12 = ctx.last_neighbors(frame.shape[0])
+        results[name] = (r, ix, pose12, ctx.map_points())
+        assert ctx.handoff_fallbacks() == 0, name
+        ctx.close()
+    ref = results["default"]
+    for name, (r, ix, pose12, _) in results.items():
+        assert r.iterations == 4
+        np.testing.assert_array_equal(r.pose, ref[0].pose, err_msg=name)
+        np.testing.assert_array_equal(r.losses, ref[0].losses, err_msg=name)
+        np.testing.assert_array_equal(ix, ref[1], err_msg=name)
+    r, ix, pose12, mp = ref
+    valid = ~np.isnan(frame).any(axis=1)
+    assert (ix[valid] >= 0).all() and (ix[~valid] < 0).all()
+    t = pose12.astype(np.float64)
+    p = frame[valid].astype(np.float64) @ t[:, :3].T + t[:, 3]
+    cur = mp.astype(np.float64)
+    bd, bi = cKDTree(cur).query(p)
+    d_used = np.linalg.norm(p - cur[ix[valid]], axis=1)
+    assert (ix[valid] == bi).mean() > 0.999
+    np.testing.assert_allclose(d_used, bd, rtol=1e-5, atol=1e-5)  # (the device transforms in float32)
+    assert (bd > 1.0).sum() >= 50  # the far targets really are far
+
+
 def test_c2_full_size_properties(torch_cuda, O):
     """Size-independent properties at the headline size (131072-point scan, 100k-point map, 20 iterations), where the
     oracle is too slow to be run case by case:

@@ -496,8 +496,8 @@ def test_masked_sparse_vertex_map_equals_the_compacted_one(torch_cuda):
     scans, _ = _scans(32, 1024, 5)
     runs = {}
     for compact in (True, False):
-        cfg = our.MI355XICPConfig(sample_pointcloud=False, compact_sparse_vertex_map=compact, max_num_alignments=10,
-                                  threshold_delta_pose=1e-4)
+        cfg = our.MI355XICPConfig(compact_sparse_vertex_map=compact, max_num_alignments=10, data_key="input_data",
+                                  threshold_delta_pose=1e-4)  # (tensor rows in: the targets are the vertex map's pixels)
         odo = our.MI355XICPFrameToModel(cfg, projector=our.SphericalProjector(32, 1024), device=torch.device("cuda:0"))
         odo.init()
         poses, iters = [], []
@@ -513,3 +513,23 @@ def test_masked_sparse_vertex_map_equals_the_compacted_one(torch_cuda):
         assert odo.ctx.handoff_fallbacks() == 0
     assert runs[True][1] == runs[False][1]
     np.testing.assert_allclose(runs[True][0], runs[False][0], atol=2e-6, rtol=0)
+
+
+def test_project_rows_equals_the_transposed_vertex_map(torch_cuda):
+    """`icp_project_rows`: the vertex map of `icp_project` and, from the same launch, its pixels as [H*W, 3] rows
+    (`vmap.permute(1, 2, 0).reshape(-1, 3)`, what sample_points of icp_odometry.py:301-308 indexes) — bit for bit, NaN rows
+    of a padded frame skipped, a second call on the same context clean."""
+    torch = torch_cuda
+    from pylidar_slam_amd.engine import IcpContext
+    scans, _ = _scans(32, 512, 2)
+    ctx = IcpContext(height=32, width=512)
+    for s in scans:
+        rows_in = s.copy()
+        rows_in[::7] = np.nan
+        pc = torch.from_numpy(rows_in).cuda()
+        vmap, rows = ctx.project_rows(pc)
+        ref = ctx.project(pc)
+        assert torch.equal(vmap, ref)
+        assert torch.equal(rows, ref.permute(1, 2, 0).reshape(-1, 3))
+        assert rows.shape == (32 * 512, 3) and int((rows.abs().sum(dim=1) > 0).sum()) > 1000
+    ctx.close()
