@@ -1488,11 +1488,11 @@ static size_t state_bytes(const icp_ctx* ctx) {
     return STATE_BLOCK + (size_t)ctx->hist_cap * (sizeof(double) + 6 * sizeof(float));
 }
 
-// refresh = true: the newest pending slot is copied again (a further chunk of its registration has been enqueued)
-static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
+// the pinned slot the result of the registration being enqueued will land in (refresh = true: the newest pending one again)
+static int result_slot(icp_ctx* ctx, bool refresh, icp_ctx::ResultSlot** out) {
     if (!refresh && ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
     icp_ctx::ResultSlot& r = ctx->rslot[(ctx->r_head + ctx->r_count - (refresh ? 1 : 0)) & 1];
-    const size_t sb = state_bytes(ctx), need = sb;
+    const size_t need = state_bytes(ctx);
     if (need > r.bytes) {
         if (r.host) (void)hipHostFree(r.host);
         r.host = nullptr;
@@ -1501,8 +1501,37 @@ static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
         r.bytes = need;
     }
     if (!r.event) ICP_HIP(ctx, hipEventCreateWithFlags(&r.event, hipEventDisableTiming));
+    *out = &r;
+    return ICP_OK;
+}
+
+// call before enqueue_iterations: the last solving launch may then write the result block into the slot itself
+static int result_fold_begin(icp_ctx* ctx, bool refresh) {
+    ctx->result_fold_to = nullptr;
+    ctx->result_folded = false;
+    icp_ctx::ResultSlot* r = nullptr;
+    const int rc = result_slot(ctx, refresh, &r);
+    if (rc) return rc;
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, r->host, 0) == hipSuccess && mapped) {
+        ctx->result_fold_to = (char*)mapped;
+        ctx->result_fold_bytes = state_bytes(ctx);
+    }
+    return ICP_OK;
+}
+
+// refresh = true: the newest pending slot is copied again (a further chunk of its registration has been enqueued)
+static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
+    icp_ctx::ResultSlot* rp = nullptr;
+    const int rc_slot = result_slot(ctx, refresh, &rp);
+    if (rc_slot) return rc_slot;
+    icp_ctx::ResultSlot& r = *rp;
+    const size_t sb = state_bytes(ctx);
     char* h = (char*)r.host;
-    ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));  // state + histories
+    // state + histories (unless the last solving launch has written them there already)
+    if (!ctx->result_folded) ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->result_folded = false;
+    ctx->result_fold_to = nullptr;
     ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
     if (refresh) return ICP_OK;
     // the grid statistics about to be read back belong to the current build; a later build starts a new pending set
@@ -1521,11 +1550,14 @@ static int continue_launch(icp_ctx* ctx, int count) {
     if (ctx->launch_remaining <= 0) return ICP_OK;
     if (count < 0 || count > ctx->launch_remaining) count = ctx->launch_remaining;
     ctx->in_registration = true;
-    int rc = enqueue_iterations(ctx, false, ctx->launch_enqueued, count);
+    int rc = result_fold_begin(ctx, true);
+    if (!rc) rc = enqueue_iterations(ctx, false, ctx->launch_enqueued, count);
     ctx->in_registration = false;
     ctx->launch_enqueued += count;
     ctx->launch_remaining -= count;
     if (!rc) rc = enqueue_result_copy(ctx, true);
+    ctx->result_fold_to = nullptr;
+    ctx->result_folded = false;
     return rc;
 }
 
@@ -1803,13 +1835,13 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
                 // the rows of this launch: the parity it has just written
                 rc = launch_sum_solve(ctx, rows, quad, (const double*)(ctx->partials.as<char>() +
                                                                        (size_t)(ctx->partials_parity ^ 1) * ctx->partials_half),
-                                      true);
+                                      true, it + 1 == iters);
                 prev_rows = 0;
             }
         } else if (fused_path(ctx)) {
             int rows = 0, quad = 1;
             rc = launch_iterate_fused(ctx, &rows, &quad);
-            if (!rc) rc = launch_sum_solve(ctx, rows, quad);
+            if (!rc) rc = launch_sum_solve(ctx, rows, quad, nullptr, false, it + 1 == iters && poll == 0);
         } else if (ctx->cost == ICP_COST_POINT_TO_POINT) {
             (rc = launch_search(ctx)) || (rc = launch_reduce_p2p(ctx, true));
             ctx->iter_in_registration += 1;  // (the fused launch counts itself)
@@ -1852,10 +1884,13 @@ static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, i
         first_chunk = (ctx->last_iterations > 0 ? ctx->last_iterations : 3) + 1;
         if (first_chunk > iters) first_chunk = iters;
     }
-    rc = enqueue_iterations(ctx, false, 0, first_chunk);
+    rc = result_fold_begin(ctx, false);  // (the last solving launch of the chunk delivers the result block itself)
+    if (!rc) rc = enqueue_iterations(ctx, false, 0, first_chunk);
     ctx->launch_enqueued = first_chunk;
     ctx->launch_remaining = iters - first_chunk;
     if (!rc) rc = enqueue_result_copy(ctx);
+    ctx->result_fold_to = nullptr;
+    ctx->result_folded = false;
     ctx->in_registration = false;  // the result waits in its slot
     return rc;
 }

@@ -283,7 +283,12 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
                                                     RegState* __restrict__ st, AlignParams ap,
                                                     double* __restrict__ neq, double* __restrict__ loss_hist,
                                                     float* __restrict__ dx_hist, int hist_cap,
-                                                    unsigned long long* __restrict__ box, unsigned gen) {
+                                                    unsigned long long* __restrict__ box, unsigned gen,
+                                                    const unsigned* __restrict__ result_src, unsigned* __restrict__ result_dst,
+                                                    int result_words) {
+    // result_dst (the last solving launch of an enqueued registration): the state allocation — RegState and histories, the
+    // block icp_register_end reads — goes to the pinned result slot (mapped into the device) by this launch instead of a
+    // copy launch of its own behind it
     // the state words are requested first and consumed last: their latency hides behind the partial-row loads
     // (a hand-off that timed out in an earlier launch of this registration — handoff_timeouts — left incomplete rows behind:
     // nothing is solved from them; icp_register_end re-runs the rest of the loop from the iteration the state holds)
@@ -306,10 +311,16 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
             const int k = threadIdx.x;
             box_store(box, gen, k, k < 12 ? __float_as_uint(st->pose[k]) : (k == 12 ? 1u : (unsigned)st->iter));
         }
-        return;
+    } else {
+        if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
+        if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in, box, gen);
     }
-    if (threadIdx.x < NEQ) neq[threadIdx.x] = total[threadIdx.x];
-    if (threadIdx.x < 64) solve_and_update(st, total, ap, loss_hist, dx_hist, hist_cap, it, pose_in, params_in, box, gen);
+    if (result_dst) {  // (block-uniform)
+        __syncthreads();  // the solving wave's stores to the state and the histories: visible to the workgroup
+        for (int w = threadIdx.x; w < result_words; w += blockDim.x)
+            __hip_atomic_store(result_dst + w, __hip_atomic_load(result_src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -448,8 +459,11 @@ int launch_reduce(icp_ctx* ctx) {
 }
 
 // final sum + solve over partial rows produced by the fused iteration kernel (search.hip::launch_iterate_fused)
-int launch_sum_solve(icp_ctx* ctx, int blocks, int quad, const double* partials, bool publish) {
+int launch_sum_solve(icp_ctx* ctx, int blocks, int quad, const double* partials, bool publish, bool last) {
     if (!partials) partials = ctx->partials.as<double>();
+    // the last solving launch of an enqueued registration delivers the result block itself (api.hip::enqueue_result_copy)
+    unsigned* fold = (last && !ctx->exchange_on) ? reinterpret_cast<unsigned*>(ctx->result_fold_to) : nullptr;
+    if (fold) ctx->result_folded = true;
     if (ctx->exchange_on) {
         ExchangeView x = ctx->xview;
         x.timeout_ticks = (long long)(ctx->exchange_timeout_ms * 1.0e5);  // 100 MHz
@@ -460,7 +474,8 @@ int launch_sum_solve(icp_ctx* ctx, int blocks, int quad, const double* partials,
         hipLaunchKernelGGL(k_sum_solve, dim3(1), dim3(1024), 0, ctx->stream, partials, blocks, quad,
                            reg_state(ctx), make_align_params(ctx), ctx->neq, ctx->loss_hist, ctx->dx_hist,
                            ctx->hist_cap, publish ? pose_box(ctx) : (unsigned long long*)nullptr,
-                           publish ? next_box_generation(ctx) : 0u);
+                           publish ? next_box_generation(ctx) : 0u, ctx->state.as<unsigned>(), fold,
+                           fold ? (int)(ctx->result_fold_bytes / 4) : 0);
     }
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;

@@ -435,6 +435,11 @@ struct icp_ctx {
         float stats_h = 0.f;
         int64_t eager_normals = 0;   // normals estimated eagerly for this registration
     } rslot[2];
+    // the pinned slot (device-visible address, bytes) the LAST solving launch of the registration being enqueued writes the
+    // result block into itself (launch_sum_solve); result_folded: it has done so — no copy launch behind it
+    char* result_fold_to = nullptr;
+    size_t result_fold_bytes = 0;
+    bool result_folded = false;
     // a launched registration with a live stop threshold is enqueued in CHUNKS (as many iterations as the previous frame
     // needed, plus one): icp_register_end looks at the result and enqueues the next chunk only if the loop is still
     // running, instead of paying for max_num_alignments launches of which most find `done` set.  launch_remaining =
@@ -519,7 +524,8 @@ int run_seed_job(icp_ctx* ctx);
 AlignParams make_align_params(const icp_ctx* ctx);
 int launch_reduce(icp_ctx* ctx);    // residual / Jacobian rows -> packed normal equations (ctx->neq)
 int launch_solve(icp_ctx* ctx);     // 6x6 solve + pose update on the device
-int launch_sum_solve(icp_ctx* ctx, int rows, int quad = 1, const double* partials = nullptr, bool publish = false);  // (with an exchange connected: + the all-reduce over the ranks; partials: ctx->partials unless given)
+int launch_sum_solve(icp_ctx* ctx, int rows, int quad = 1, const double* partials = nullptr, bool publish = false,
+                     bool last = false);  // (with an exchange connected: + the all-reduce over the ranks; partials: ctx->partials unless given)
 int launch_sum_partials(icp_ctx* ctx, int rows, int quad = 1);
 // fused search + point-to-plane rows + per-block partial sums (needs every touched normal ready); *blocks_out = rows
 // rows written; quad: base rows (1) or super-rows (0).  lead: the launch takes its pose from the mailbox; with prev_rows > 0
