@@ -16,6 +16,7 @@ from ._lib import (COSTS, IcpConfig, IcpLibraryError, IcpRegisterResult, MEM_DEV
                    STATUS_MESSAGES, TARGETS_ALL, TARGETS_SKIP_NULL)
 
 Array = Union[np.ndarray, torch.Tensor]
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (device index) -> raw hipStream_t of torch's current stream
 
 
 class InvalidJacobianError(RuntimeError):
@@ -81,6 +82,7 @@ class IcpContext:
             int(poll_every)
         self.config = cfg
         self.device = torch.device("cuda", int(device))
+        self._device_index = int(device)
         handle = C.c_void_p()
         rc = self._lib.icp_create(C.byref(cfg), C.byref(handle))
         if rc != 0:
@@ -115,7 +117,10 @@ class IcpContext:
     def use_torch_stream(self):
         """Enqueue on torch's current HIP stream of this device (the library orders a switch of streams against the work
         it enqueued on the previous one)."""
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # (the raw handle straight from torch's bookkeeping where the build exposes it: the public query builds a Stream
+        # object, 3-10 us a call — and every call that takes a device tensor asks)
+        stream = _RAW_STREAM(self._device_index) if _RAW_STREAM is not None else \
+            torch.cuda.current_stream(self.device).cuda_stream
         if stream != getattr(self, "_bound_stream", None):
             self._check(self._lib.icp_set_stream(self._h, C.c_void_p(stream)))
             self._bound_stream = stream

@@ -824,7 +824,9 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             self._host_rows = data if data.dtype == np.float32 and data.flags.c_contiguous else \
                 np.ascontiguousarray(data, dtype=np.float32)
             pc = self._upload(self._host_rows)
-            vmap = self.ctx.project(pc)
+            # the vertex map of a frame whose POINTS are registered and inserted (kd-tree style map) is not read before the
+            # registration: projected behind its launch (do_process_next_frame), while the GPU iterates
+            vmap = None if self._defer_projection() else self.ctx.project(pc)
         elif isinstance(data, torch.Tensor):
             if data.ndim in (3, 4):
                 vmap = data.to(self.device, torch.float32)
@@ -851,6 +853,9 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
         self._tgt_vmap = vmap
         self._tgt_pc = pc
         self._pc_is_pixels = isinstance(data, torch.Tensor) and data.ndim in (3, 4)
+
+    def _defer_projection(self) -> bool:
+        return self._iter > 0 and not self._projective and self.device.type == "cuda"
 
     def sample_points(self):  # :301-308 — returns (device rows, skip_null)
         if not self._sample_pointcloud:
@@ -911,6 +916,8 @@ class MI355XICPFrameToModel(OdometryAlgorithm):
             if self._staged:
                 self.local_map.stage(self._tgt_pc, skip_null=self._pc_is_pixels)
             self.ctx.register_launch(targets, initial_estimate, skip_null=skip_null)
+            if self._tgt_vmap is None:  # (deferred in _read_input: enqueued behind the registration, off its critical path)
+                self._tgt_vmap = self.ctx.project(self._tgt_pc)
             tgt_np_pc = self._rows_to_host(rows_ready) if want_rows else data_dict["distorted"]  # GPU busy meanwhile
             res = self.ctx.register_end()  # raises before the map is touched (:286)
             self.last_result = res

@@ -13,6 +13,7 @@ CMD="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --loop-steps 0 --pl
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o t -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --loop-steps 0 --plugin-steps 0 --odometry-loop 0 --throughput-leg 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err )
 python tools/rocprof_iterate_summary.py $OUT/prof $OUT/rocprof_iterate_kernel.json $HEAD_SHA "rocprofv3 --kernel-trace --stats -- $CMD" > /dev/null && cp $OUT/rocprof_iterate_kernel.json profiles/rocprof_iterate_kernel.json
 cp $(ls $OUT/prof/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null
+python tools/dev/r5_timeline.py $(ls $OUT/prof/*kernel_trace.csv | head -1) k_pack_targets > $OUT/headline_timeline.txt 2>&1
 # the reference's schedule (normals cleared and re-estimated behind every map update): same trace
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_ref -o t -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --loop-steps 0 --plugin-steps 0 --odometry-loop 0 --throughput-leg 0 --no-profile --option carry_normals=0 > $R/$OUT/prof_ref_bench.json 2> $R/$OUT/prof_ref_bench.err )
 cp $(ls $OUT/prof_ref/*kernel_stats.csv | head -1) $OUT/reference_schedule_kernel_stats.csv 2>/dev/null
@@ -39,7 +40,9 @@ except Exception as e: print("FAILED", e)
 PY
 timeout 600 python bench.py --workload c4 --steps 6 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 rc=$?"; tail -c 400 $OUT/bench_c4.json; echo
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/odo -o t -- python $R/bench.py --leg odometry_loop --no-cpu-baseline > $R/$OUT/odo.json 2> $R/$OUT/odo.err )
-cp $(ls $OUT/odo/*kernel_stats.csv | head -1) $OUT/odometry_loop_kernel_stats.csv 2>/dev/null; rm -rf $OUT/odo
+cp $(ls $OUT/odo/*kernel_stats.csv | head -1) $OUT/odometry_loop_kernel_stats.csv 2>/dev/null
+python tools/dev/r5_timeline.py $(ls $OUT/odo/*kernel_trace.csv | head -1) k_dedupe_clear > $OUT/odometry_loop_timeline.txt 2>&1
+rm -rf $OUT/odo
 python - $OUT/odometry_loop_kernel_stats.csv <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
@@ -48,3 +51,4 @@ print(f"odometry_loop: total kernel time {tot/72e3:.1f} us per frame; rocprim/at
 PY
 timeout 100 python bench.py --steps 14 --warmup 6 --no-cpu-baseline --loop-steps 0 --no-profile --plugin-steps 0 --odometry-loop 0 --throughput-leg 0 --option search_stats=2 > $OUT/stamps.json 2> $OUT/stamps.err; grep -c "icp phases" $OUT/stamps.err
 timeout 100 python bench.py --steps 14 --warmup 6 --no-cpu-baseline --loop-steps 0 --no-profile --plugin-steps 0 --odometry-loop 0 --throughput-leg 0 --option search_stats=2 --option resident_tail=3 > $OUT/stamps_tail.json 2> $OUT/stamps_tail.err; grep -c "icp phases" $OUT/stamps_tail.err
+[ -x tools/dev/t/stale_poll.bin ] && timeout 60 tools/dev/t/stale_poll.bin > $OUT/stale_poll.txt 2>&1; tail -3 $OUT/stale_poll.txt
