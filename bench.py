@@ -12,6 +12,10 @@ One step = one frame of the hot path, everything the reference does per frame on
   spherical projection of the scan (icp_odometry.py:333) -> 20 x [transform, exact 1-NN, lazy kNN normals,
   residual/Jacobian reduction, 6x6 solve, pose update] (:274-297) -> pose read back to the host -> local-map update
   (re-express the 100k map by inv(T), rebuild the search structure, clear the normal cache; local_map.py:346-369).
+Since round 5 the library's default carries the map normals through such a POSE-ONLY update (rotated with the points,
+option carry_normals = 1) instead of clearing and re-estimating them: less work per frame than the reference does.  The
+line says so (config.workload, config.carry_normals) and carries "reference_schedule": the same loop with
+carry_normals = 0 (every normal cleared and estimated again per frame, the reference's amount of work), 40 steps.
 The map is the union of 8 EARLIER scans, none of which is ever tracked ("union of the previous >= 5
 scans"): a straight drive is sampled every 0.2 m / 0.005 rad (16 poses); the 8 even poses (0.4 m apart) are the mapping
 pass, the 8 odd poses (0.4 m apart, 0.2 m from the nearest map scan) are tracked back and forth (3,5,..,15,13,..,1,..),
@@ -40,6 +44,7 @@ single-GPU run reports such a leg next to the headline (`"throughput"`: 4 sequen
 timing; `--throughput-leg 0` skips it).
 
 Legs reported next to the headline in the same JSON line (each outside the headline's timed region):
+  "reference_schedule"  the headline loop with `carry_normals=0` (see above), 40 steps after 5 untimed ones;
   "headline_60"   when --steps < 50: the same loop re-timed over 60 steps, so the figure does not rest on a 13 ms window;
   "plugin"        the SAME workload through the drop-in plugin, as the reference's SLAM loop calls it
                   (slam/odometry/odometry.py:37-46 -> icp_odometry.py:157-246): `MI355XICPFrameToModel.process_next_frame`
@@ -48,8 +53,11 @@ Legs reported next to the headline in the same JSON line (each outside the headl
                   `local_map.set_map_pointcloud` and `threshold_trans / threshold_rot` keep it fixed (pose-only updates);
   "odometry_loop" the reference's PUBLISHED configuration (docs/results/KITTI/kitti_benchmark.md:10,19: CV + kd-tree F2M,
                   neighborhood sigma 0.2, 20 iterations, threshold 1e-4, map of 30 key frames, grid sample 0.4 m) on
-                  synthetic 64x2048 frames: grid sample -> registration -> sliding-window map with inserts / evictions;
-  "loop", "throughput" (rounds 1-2);
+                  synthetic 64x2048 frames: grid sample -> registration -> sliding-window map with inserts / evictions
+                  (device-resident preprocessing, padded grid sample: one host synchronisation per frame); per-frame times,
+                  iteration counts and the frames that stop after another number of iterations than the reference's run;
+  "loop" (closed circuit), "throughput" (4 sequences on 4 streams, >= 60 steps each after >= 10 warm-up steps, options
+                  lead_solve=0 + wide_until=0, per-sequence spread);
   N > 1 (replicas headline): "sharded" = ONE sequence split over the N ranks, with the in-library exchange
                   (icp_exchange_*) and with the RCCL all-reduce per iteration; "c4" = BASELINE configs[3], a 128-beam
                   200k-point scan against a 1M-point map, scan-sharded registration + map-sharded normals (16 MB
