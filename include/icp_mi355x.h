@@ -204,6 +204,14 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   other entry point first orders the caller's stream behind the update.  Off by default:
  *                                   measured, the two event hand-offs between the streams cost more than the overlap returns
  *                                   (headline loop 2549 vs 2840 scans/s; published-configuration loop unchanged)
+ *   "normals_tail_stream" 0 | 1 (0) the eager kNN normals behind a map update finish their stragglers (the ~0.2 % of the map
+ *                                   points whose k-th neighbour ring 1 does not certify: a ~30 us chain of dependent probes
+ *                                   each) on that stream of the context's own instead of inside the estimating launch: they run
+ *                                   beside the next frame's preprocessing, and the next entry point that touches the map or a
+ *                                   registration orders the caller's stream behind them.  Same normals, bit for bit.  Off by
+ *                                   default: measured, neither the published-configuration loop (0.354-0.382 vs 0.360-0.366 ms
+ *                                   per frame) nor the headline loop under the reference's schedule (2365-2374 vs 2370 scans/s)
+ *                                   moves — behind a map update the GPU waits for the host's next upload, not the reverse
  *   "eager_normals_limit" m (2^20)  maps of up to m points get all their normals in one launch behind every map update (and
  *                                   the fused iteration kernel) whatever the scan size; larger maps only when m <= 2 n
  *   "profile_rotate" 0 | 1 (0)      icp_profile_enable brackets one iteration launch per registration (see icp_profile_read_iterations)

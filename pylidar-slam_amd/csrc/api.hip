@@ -347,7 +347,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
-                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows};
+                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows, &ctx->normals_tail};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -422,6 +422,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "far_lanes") ctx->far_lanes = iv >= 16 ? 16 : 0;
     else if (k == "far_min") ctx->far_min = iv < 0 ? 0 : (int)iv;
     else if (k == "far_max") ctx->far_max = iv < 0 ? 0 : (iv > 512 ? 512 : (int)iv);
+    else if (k == "normals_tail_stream") ctx->normals_tail_stream = iv != 0 ? 1 : 0;
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);
     else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 1.0e-5 ? value : 1.0e-5;  // (>= one tick of the 100 MHz clock: tests go there)
@@ -866,7 +867,7 @@ static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* 
     // the next registration will want every normal at once (same rule as register_begin, with the size of the scan just
     // registered standing in for the next one): estimate them NOW, behind the rebuild, so that the GPU works through the
     // caller's preparation of the next frame (host staging, upload) instead of starting on them when that frame arrives
-    if (ctx->have_device_pose && ctx->tgt_n > 0 && wants_eager_normals(ctx, ctx->tgt_n)) rc = launch_normals_all(ctx);
+    if (ctx->have_device_pose && ctx->tgt_n > 0 && wants_eager_normals(ctx, ctx->tgt_n)) rc = launch_normals_all(ctx, true);
     return rc;
 }
 

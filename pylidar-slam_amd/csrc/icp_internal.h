@@ -464,6 +464,9 @@ struct icp_ctx {
     // headline loop 2549 vs 2840 scans/s (its next frame has 9 us of projection to overlap), the published configuration's
     // loop 0.44-0.48 vs 0.44-0.46 ms per frame
     int overlap_map_update = 0;
+    int normals_tail_stream = 0;        // "normals_tail_stream": the stragglers of the eager kNN normals behind a map update run on the map stream (measured: no gain, off)
+    icp::DeviceBuffer normals_tail;     // [1 + M] int: count, positions of the stragglers
+    int* normals_tail_list = nullptr;   // (argument of the launch in flight)
     hipStream_t map_stream = nullptr;
     hipEvent_t map_done_event = nullptr, map_start_event = nullptr;
     bool map_stream_busy = false;
@@ -509,7 +512,9 @@ int compact_valid_rows(icp_ctx* ctx, const float* xyz, int64_t n, bool skip_null
 int launch_search_raw(icp_ctx* ctx);  // 1-NN without the pose transform (LocalMap seam)
 int launch_search(icp_ctx* ctx);    // 1-NN of the current targets -> nn_pos, queues missing normals
 int launch_normals(icp_ctx* ctx);   // kNN normals for the worklist
-int launch_normals_all(icp_ctx* ctx);  // kNN normals of every map point (eager mode)
+// kNN normals of every map point (eager mode); tail_may_overlap: called at the end of a map update — the stragglers of the
+// estimation may run on the map stream (option "normals_tail_stream")
+int launch_normals_all(icp_ctx* ctx, bool tail_may_overlap = false);
 int launch_gather_neighbors(icp_ctx* ctx, int64_t n, float* pts_out, float* nrm_out, int32_t* idx_out);
 int launch_last_neighbors(icp_ctx* ctx, int iteration, int* out_dev);  // NN cache -> matched map point per target (tests)
 // map-sharded normals: the owned share by original index (zeros elsewhere) / install the all-reduced array

@@ -2800,9 +2800,44 @@ __device__ inline bool cov_hood_pair(const GridView& g, int s, int sub, float* _
     return true;
 }
 
+// one straggler of the pair pass by a whole wave: the merged list of ring 1 from the cell's neighbourhood list, then
+// finish_cov_wave (fine ring 2, coarse level, exhaustive) and the eigen-solve; `wcov` / `wl` = the wave's LDS scratch
+template <int KN, bool OWNED>
+__device__ inline void normal_of_straggler(const GridView& g, int ps, int lane, int max_rings, float* __restrict__ wcov,
+                                           int* __restrict__ wl, float4* __restrict__ out, int* __restrict__ nflag) {
+    const float4 P = g.pts[ps];
+    const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
+    TopK<KN> t, m;
+    t.init();
+    for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
+    merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
+    finish_cov_wave<KN>(g, ps, lane, max_rings, m, wcov, wl);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+        float nx, ny, nz;
+        smallest_eigenvector(wcov[0], wcov[1], wcov[2], wcov[3], wcov[4], wcov[5], nx, ny, nz);
+        if (OWNED) {
+            out[__float_as_int(P.w)] = make_float4(nx, ny, nz, 1.f);
+        } else {
+            out[ps] = make_float4(nx, ny, nz, 1.f);
+            nflag[ps] = 1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the next point overwrites the wave's scratch)
+}
+
+// `tail` (round 5, "normals_tail_stream"): the stragglers are not finished here but appended to a chip-wide list —
+// tail[0] = their count, tail[1..] = their positions — which k_normals_tail works through on the context's map stream, beside
+// the next frame's preprocessing on the caller's stream (api.hip: DeviceGuard's join orders every reader of the normals behind
+// it).  A launch of its own behind this one on the SAME stream was tried in round 4 (+31 us: the 30 us chain per straggler sets
+// the duration of whatever launch runs it); on a stream of its own that chain has ~50 us of independent work to hide behind.
 template <int KN, bool OWNED>
 __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int max_rings, int rank, int world,
-                                                                float4* __restrict__ out, int* __restrict__ nflag) {
+                                                                float4* __restrict__ out, int* __restrict__ nflag,
+                                                                int* __restrict__ tail) {
     constexpr int PTS = NRM2_THREADS / 2;
     __shared__ float covs[PTS][7];
     __shared__ int settled[PTS];
@@ -2838,34 +2873,31 @@ __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int 
             nflag[s2] = 1;
         }
     }
+    if (tail) {  // (kernel argument: uniform) the stragglers go to the chip-wide list
+        if (npend > 0) {
+            __shared__ int tail_base;
+            if (threadIdx.x == 0) tail_base = atomicAdd(&tail[0], npend);
+            __syncthreads();
+            if ((int)threadIdx.x < npend) tail[1 + tail_base + threadIdx.x] = pend_s[threadIdx.x];
+        }
+        return;
+    }
     // ---- the stragglers of this workgroup, a wave per point
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = wave; k < npend; k += NRM2_THREADS / 64) {  // wave-uniform
-        const int ps = pend_s[k];
-        const float4 P = g.pts[ps];
-        const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
-        TopK<KN> t, m;
-        t.init();
-        for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
-        merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
-        finish_cov_wave<KN>(g, ps, lane, max_rings, m, wcov[wave], wl[wave]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == 0) {
-            float nx, ny, nz;
-            const float* c = wcov[wave];
-            smallest_eigenvector(c[0], c[1], c[2], c[3], c[4], c[5], nx, ny, nz);
-            if (OWNED) {
-                out[__float_as_int(P.w)] = make_float4(nx, ny, nz, 1.f);
-            } else {
-                out[ps] = make_float4(nx, ny, nz, 1.f);
-                nflag[ps] = 1;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // (the next point overwrites the wave's scratch)
-    }
+    for (int k = wave; k < npend; k += NRM2_THREADS / 64)  // wave-uniform
+        normal_of_straggler<KN, OWNED>(g, pend_s[k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
+}
+
+// the stragglers of k_normals_hood2 (`tail` list), a wave per point, on a stream of their own
+template <int KN>
+__global__ __launch_bounds__(NRM2_THREADS) void k_normals_tail(GridView g, int max_rings, const int* __restrict__ tail,
+                                                               float4* __restrict__ out, int* __restrict__ nflag) {
+    __shared__ int wl[NRM2_THREADS / 64][128];
+    __shared__ float wcov[NRM2_THREADS / 64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int count = tail[0], waves = gridDim.x * (NRM2_THREADS / 64);
+    for (int k = blockIdx.x * (NRM2_THREADS / 64) + wave; k < count; k += waves)  // wave-uniform
+        normal_of_straggler<KN, false>(g, tail[1 + k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
 }
 
 template <int KN, int NL>
@@ -3099,12 +3131,26 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     int* nf = ctx->nflag.as<int>();
     if (NL == 4 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {  // two lanes per point, one pass over the list
         const int b2 = (int)((ctx->map_m + NRM2_THREADS / 2 - 1) / (NRM2_THREADS / 2));
+        int* tail = ctx->normals_tail_list;  // (set by launch_normals_all when the stragglers go to the map stream)
         if (kn == 11)
             hipLaunchKernelGGL((k_normals_hood2<11, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
-                               nf);
+                               nf, tail);
         else
             hipLaunchKernelGGL((k_normals_hood2<6, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
-                               nf);
+                               nf, tail);
+        if (tail) {  // the stragglers: on `tail_stream`, behind the launch above
+            (void)hipEventRecord(ctx->map_start_event, ctx->stream);
+            (void)hipStreamWaitEvent(ctx->map_stream, ctx->map_start_event, 0);
+            int tb = b2 / 2;  // (a sparse map is all stragglers: as many waves as the pair pass had workgroups; at least 64)
+            if (tb < 64) tb = 64;
+            if (tb > 1024) tb = 1024;
+            if (kn == 11)
+                hipLaunchKernelGGL((k_normals_tail<11>), dim3(tb), dim3(NRM2_THREADS), 0, ctx->map_stream, g, rings, tail, nrm, nf);
+            else
+                hipLaunchKernelGGL((k_normals_tail<6>), dim3(tb), dim3(NRM2_THREADS), 0, ctx->map_stream, g, rings, tail, nrm, nf);
+            (void)hipEventRecord(ctx->map_done_event, ctx->map_stream);
+            ctx->map_stream_busy = true;
+        }
         return;
     }
     if (NL == 4 && g.hood && (kn == 11 || kn == 6)) {  // through the neighbourhood lists, four lanes per point (round 3)
@@ -3124,17 +3170,32 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
         hipLaunchKernelGGL((k_normals_all<21, NL>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, nrm, nf);
 }
 
-int launch_normals_all(icp_ctx* ctx) {
+int launch_normals_all(icp_ctx* ctx, bool tail_may_overlap) {
     const int kn = ctx->cfg.num_neighbors_normals + 1;
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
     GridView g = make_view(ctx);
+    // "normals_tail_stream": behind a map update (nothing reads a normal before the next entry point that joins the map
+    // stream) the stragglers of the two-lane kernel run on that stream, beside the next frame's preprocessing
+    ctx->normals_tail_list = nullptr;
+    if (tail_may_overlap && ctx->normals_tail_stream && ctx->knn_lanes != 2 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6) &&
+        !ctx->exchange_on && !ctx->prof.enabled && !ctx->search_stats && ctx->stream != ctx->map_stream) {
+        if (!ctx->map_stream) {
+            ICP_HIP(ctx, hipStreamCreateWithFlags(&ctx->map_stream, hipStreamNonBlocking));
+            ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_done_event, hipEventDisableTiming));
+            ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_start_event, hipEventDisableTiming));
+        }
+        ICP_HIP(ctx, ctx->normals_tail.reserve(((size_t)ctx->map_m + 1) * sizeof(int)));
+        ICP_HIP(ctx, hipMemsetAsync(ctx->normals_tail.ptr, 0, sizeof(int), ctx->stream));
+        ctx->normals_tail_list = ctx->normals_tail.as<int>();
+    }
     const int tok = prof_begin(ctx, 2);
     if (ctx->knn_lanes == 2)
         launch_normals_all_t<2>(ctx, kn, g);
     else
         launch_normals_all_t<4>(ctx, kn, g);
     prof_end(ctx, tok);
+    ctx->normals_tail_list = nullptr;
     ICP_HIP(ctx, hipGetLastError());
     ctx->normals_ready = true;
     ctx->normals_eager_count += ctx->map_m;
@@ -3158,10 +3219,10 @@ int launch_normals_owned(icp_ctx* ctx, int rank, int world, float* by_index_dev)
         const int b2 = (int)((m + NRM2_THREADS / 2 - 1) / (NRM2_THREADS / 2));
         if (kn == 11)
             hipLaunchKernelGGL((k_normals_hood2<11, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, rank, world,
-                               out, (int*)nullptr);
+                               out, (int*)nullptr, (int*)nullptr);
         else
             hipLaunchKernelGGL((k_normals_hood2<6, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, rank, world,
-                               out, (int*)nullptr);
+                               out, (int*)nullptr, (int*)nullptr);
     } else if (g.hood && kn == 11)
         hipLaunchKernelGGL((k_normals_hood<11, true>), dim3(blocks), dim3(NRM_THREADS), 0, ctx->stream, g, rings, rank,
                            world, out, (int*)nullptr);
