@@ -204,6 +204,9 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   other entry point first orders the caller's stream behind the update.  Off by default:
  *                                   measured, the two event hand-offs between the streams cost more than the overlap returns
  *                                   (headline loop 2549 vs 2840 scans/s; published-configuration loop unchanged)
+ *   "insert_by_cell" 0 | 1 (1)      behind a map update the points claim their cells of the new grid in the cell order of the
+ *                                   previous grid (a rigid step leaves the points of an old cell in one or two new ones: the lanes
+ *                                   of a wave share their claims) instead of in insertion order
  *   "normals_tail_stream" 0 | 1 (0) the eager kNN normals behind a map update finish their stragglers (the ~0.2 % of the map
  *                                   points whose k-th neighbour ring 1 does not certify: a ~30 us chain of dependent probes
  *                                   each) on that stream of the context's own instead of inside the estimating launch: they run

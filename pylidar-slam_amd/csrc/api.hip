@@ -422,6 +422,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "far_lanes") ctx->far_lanes = iv >= 16 ? 16 : 0;
     else if (k == "far_min") ctx->far_min = iv < 0 ? 0 : (int)iv;
     else if (k == "far_max") ctx->far_max = iv < 0 ? 0 : (iv > 512 ? 512 : (int)iv);
+    else if (k == "insert_by_cell") ctx->insert_by_cell = iv != 0 ? 1 : 0;
     else if (k == "normals_tail_stream") ctx->normals_tail_stream = iv != 0 ? 1 : 0;
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);
@@ -743,6 +744,7 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
                                     ctx->stream));
     ctx->map_m = m;
     int rc = stash_frame_seeds(ctx, 0, false);  // a new map: the old neighbours mean nothing
+    ctx->order_job = false;  // (a new map: the previous grid says nothing about it)
     if (!rc) rc = build_grid(ctx);
     if (rc) return rc;
     if (mem == ICP_MEM_HOST) ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -788,6 +790,7 @@ static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* 
                            int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count) {
     int rc = ICP_OK;
     ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
+    ctx->order_job = false;
     ctx->carry_job = false;
     int64_t inserted = 0;
     int64_t evicted = 0;
@@ -828,6 +831,10 @@ static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* 
         ctx->carry_job = ctx->carry_normals && !has_cloud && evict == 0 && keep > 0 && ctx->grid_valid &&
                          ctx->cost == ICP_COST_POINT_TO_PLANE;
         ctx->carry_m = keep;
+        ctx->order_job = ctx->grid_valid && keep > 0;
+        ctx->order_old_m = ctx->map_m;
+        ctx->order_evicted = evict;
+        ctx->order_kept = keep;
         if (keep > 0) {  // the re-expression rides in the first launch of the grid build below
             MapMoveJob& job = ctx->move_job;
             job.in = src;

@@ -368,11 +368,31 @@ __device__ inline void wave_group_by_key(unsigned long long key, bool active, in
 // coarse level, one or two: every point claiming its cell and bumping the cell's counter by itself put hundreds of
 // same-address atomics in a row (31 us for 100 000 points).  One claim and one counter update per (wave, cell) instead:
 // the group leader adds the group's size and every lane takes base + its rank.
+// Round 5 ("insert_by_cell"): the points of a map that has just been re-expressed are claimed in the order of the PREVIOUS
+// grid (`old_pts`: its cell-sorted points, .w = original index; kept points have the index minus `evicted`, the inserted ones
+// follow in their own order): a rigid step of a few centimetres leaves the points of an old cell in one or two new cells, so
+// the lanes of a wave share a handful of keys again — in insertion order a map merged from many grid-sampled clouds has 64
+// different cells per wave (64 trips of the grouping loop, 64 claims, 64 counter updates: 16.9 us at C2, 24 us at 181 695
+// points).  Which thread claims a point does not matter: ranks inside a cell come from atomics either way.
 __global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h, float inv_hc,
                                GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
-                               int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < m;
+                               int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
+                               const float4* __restrict__ old_pts, int old_m, int evicted, int kept,
+                               int* __restrict__ visit) {
+    // (with `old_pts` the four outputs are indexed by THREAD and visit[thread] names the point, -1: none — the scatter walks
+    // the same order, so that its stores by new position are clustered as well)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = t;
+    bool active = t < m;
+    if (old_pts) {
+        if (t < old_m) {
+            i = __float_as_int(old_pts[t].w) - evicted;
+            active = i >= 0 && i < kept;
+        } else {
+            i = kept + (t - old_m);
+            active = i < m;
+        }
+    }
     float x = 0.f, y = 0.f, z = 0.f;
     if (active) {
         x = xyz[3 * i + 0];
@@ -394,6 +414,16 @@ __global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h
     base = __shfl(base, leader, 64);
     cslot = __shfl(cslot, cleader, 64);
     cbase = __shfl(cbase, cleader, 64);
+    if (visit) {
+        const int total = old_m + (m - kept);
+        if (t < total) visit[t] = active ? i : -1;
+        if (!active) return;
+        slot_of[t] = slot;
+        rank_of[t] = base + rank;
+        cslot_of[t] = cslot;
+        crank_of[t] = cbase + crank;
+        return;
+    }
     if (!active) return;
     slot_of[i] = slot;
     rank_of[i] = base + rank;
@@ -565,20 +595,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
     }
 }
 
-__device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
+// `visit` (k_grid_insert2's order, "insert_by_cell"): thread t handles point visit[t] (-1: none), its claims are filed by t
+__device__ inline void grid_scatter_part(int t, const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
                                 const int* __restrict__ slot_of, const int* __restrict__ rank_of,
                                 const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
                                 float4* __restrict__ sorted,
                                 float4* __restrict__ csorted, float4* __restrict__ normals, int* __restrict__ nflag,
                                 int* __restrict__ row_of_pos, int* __restrict__ pos_of_orig,
-                                const float4* __restrict__ carry, int carry_m) {
-    if (i >= m) return;
+                                const float4* __restrict__ carry, int carry_m, const int* __restrict__ visit,
+                                int visit_n) {
     // four +inf pads behind the last point: search_ball_lane reads cells in whole groups of four
-    if (i == 0)
+    if (t == 0)
         for (int k = 0; k < SORTED_PAD; ++k) sorted[m + k] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
-    const int slot = slot_of[i];
-    const int pos = table[slot].start + rank_of[i];
-    const int cpos = table[cslot_of[i]].start + crank_of[i];
+    int i = t;
+    if (visit) {
+        if (t >= visit_n) return;
+        i = visit[t];
+        if (i < 0) return;
+    } else if (i >= m) {
+        return;
+    }
+    const int slot = slot_of[t];
+    const int pos = table[slot].start + rank_of[t];
+    const int cpos = table[cslot_of[t]].start + crank_of[t];
     const float4 p = make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
     row_of_pos[pos] = slot;  // rows are indexed by slot
     pos_of_orig[i] = pos;
@@ -590,9 +629,9 @@ __device__ inline void grid_scatter_part(int i, const float* __restrict__ xyz, i
         const float4 c = i < carry_m ? carry[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         normals[pos] = c;
         nflag[pos] = c.w == 1.f ? 1 : 0;
-    } else {
-        normals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        nflag[i] = 0;
+    } else {  // (indexed by position: every position is some point's)
+        normals[pos] = make_float4(0.f, 0.f, 0.f, 0.f);
+        nflag[pos] = 0;
     }
 }
 
@@ -606,13 +645,14 @@ __global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const 
                                     const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
                                     float4* __restrict__ sorted, float4* __restrict__ csorted,
                                     float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
-                                    int* __restrict__ pos_of_orig, const float4* __restrict__ carry, int carry_m) {
+                                    int* __restrict__ pos_of_orig, const float4* __restrict__ carry, int carry_m,
+                                    const int* __restrict__ visit, int visit_n) {
     if ((int)blockIdx.x < row_blocks) {  // block-uniform
         build_rows_part(table, mask, slot_of_cell, ncells_dev, rows, blockIdx.x, row_blocks);
         return;
     }
     grid_scatter_part((blockIdx.x - row_blocks) * blockDim.x + threadIdx.x, xyz, m, table, slot_of, rank_of, cslot_of,
-                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m);
+                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m, visit, visit_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -715,17 +755,22 @@ int build_grid(icp_ctx* ctx) {
     // the load stays below 0.8 whatever the cloud (linear probing: a handful of probes even there); a LiDAR map with its
     // ~16 points per cell fills 5 % — and the clearing launch, the one-launch scan and the sparse row array all walk or
     // reserve the WHOLE table every build (8 MB cleared and scanned for 6 000 cells at the headline sizes)
+    // (claims filed by thread under "insert_by_cell": one thread per point of the OLD grid and per inserted point)
+    int64_t claim_n = m;
+    if (ctx->order_job && ctx->insert_by_cell && ctx->order_old_m + (m - ctx->order_kept) > claim_n)
+        claim_n = ctx->order_old_m + (m - ctx->order_kept);
     const unsigned int tsize = next_pow2((unsigned int)(m + m / 4));
     ICP_HIP(ctx, ctx->table.reserve((size_t)2 * tsize * sizeof(GridEntry)));  // fine level, then the coarse level
     ICP_HIP(ctx, ctx->csorted.reserve((size_t)m * sizeof(float4)));
-    ICP_HIP(ctx, ctx->cslot_of.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->crank_of.reserve((size_t)m * sizeof(int)));
+    ICP_HIP(ctx, ctx->cslot_of.reserve((size_t)claim_n * sizeof(int)));
+    ICP_HIP(ctx, ctx->crank_of.reserve((size_t)claim_n * sizeof(int)));
+    const bool sorted_in_place = ctx->sorted_pts.ptr && ctx->sorted_pts.bytes >= (size_t)(m + SORTED_PAD) * sizeof(float4);
     ICP_HIP(ctx, ctx->sorted_pts.reserve((size_t)(m + SORTED_PAD) * sizeof(float4)));
     ICP_HIP(ctx, ctx->normals.reserve((size_t)m * sizeof(float4)));
     ICP_HIP(ctx, ctx->nflag.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->slot_of.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->rank_of.reserve((size_t)m * sizeof(int)));
-    ICP_HIP(ctx, ctx->worklist.reserve((size_t)m * sizeof(int)));
+    ICP_HIP(ctx, ctx->slot_of.reserve((size_t)claim_n * sizeof(int)));
+    ICP_HIP(ctx, ctx->rank_of.reserve((size_t)claim_n * sizeof(int)));
+    ICP_HIP(ctx, ctx->worklist.reserve((size_t)claim_n * sizeof(int)));
     ICP_HIP(ctx, ctx->slot_of_cell.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->row_of_pos.reserve((size_t)m * sizeof(int)));
     ICP_HIP(ctx, ctx->pos_of_orig.reserve((size_t)m * sizeof(int)));
@@ -762,7 +807,10 @@ int build_grid(icp_ctx* ctx) {
     ctx->stats_pending = true;
     ctx->stats_m_pending = m;
     ctx->stats_h_pending = ctx->cell_h;
-    const unsigned mb = (unsigned)((m + 255) / 256);
+    // (the order of the previous grid for the claims of this one: its cell-sorted points must still be where they were)
+    const bool by_cell = ctx->order_job && ctx->insert_by_cell && sorted_in_place && ctx->order_kept <= m &&
+                         ctx->order_old_m > 0 && ctx->order_old_m + (m - ctx->order_kept) < (1ll << 30);
+    ctx->order_job = false;
     const long long n2 = 2ll * tsize;  // both levels
     const int nb = (int)((n2 + SCAN_TILE - 1) / SCAN_TILE);
     // descriptors of the one-launch scan: [nb] point-count words, then [nb] cell-count words; a fresh allocation is
@@ -816,20 +864,24 @@ int build_grid(icp_ctx* ctx) {
                            ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket, hood_used,
                            ctx->normals.as<float4>(), ctx->nflag.as<int>(), carry_m, ctx->normals_carry.as<float4>());
     }
-    hipLaunchKernelGGL(k_grid_insert2, dim3(mb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR,
-                       table, tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                       ctx->crank_of.as<int>());
+    const long long visit_n = by_cell ? ctx->order_old_m + (m - ctx->order_kept) : 0;
+    const unsigned vb = (unsigned)(((by_cell ? visit_n : m) + 255) / 256);  // workgroups of the claiming / scattering threads
+    int* visit = by_cell ? ctx->worklist.as<int>() : (int*)nullptr;  // (the lazy-normal worklist is idle during a build)
+    hipLaunchKernelGGL(k_grid_insert2, dim3(vb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR, table,
+                       tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
+                       ctx->crank_of.as<int>(), by_cell ? (const float4*)ctx->sorted_pts.as<float4>() : (const float4*)nullptr,
+                       (int)ctx->order_old_m, (int)ctx->order_evicted, (int)ctx->order_kept, visit);
     hipLaunchKernelGGL(k_grid_scan, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, desc,
                        desc + nb, scan_gen, ctx->scan_poll_limit, ctx->slot_of_cell.as<int>(), ncells_dev, scan_ticket);
     {
         long long want = ((long long)m * 27 + 255) / 256;
         const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
-        hipLaunchKernelGGL(k_grid_rows_scatter, dim3(rb + mb), dim3(256), 0, ctx->stream, xyz, (int)m, table, tsize - 1,
+        hipLaunchKernelGGL(k_grid_rows_scatter, dim3(rb + vb), dim3(256), 0, ctx->stream, xyz, (int)m, table, tsize - 1,
                            ctx->slot_of_cell.as<int>(), ncells_dev, ctx->rows.as<int2>(), (int)rb,
                            ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
                            ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(), ctx->csorted.as<float4>(),
                            ctx->normals.as<float4>(), ctx->nflag.as<int>(), ctx->row_of_pos.as<int>(),
-                           ctx->pos_of_orig.as<int>(), ctx->normals_carry.as<float4>(), carry_m);
+                           ctx->pos_of_orig.as<int>(), ctx->normals_carry.as<float4>(), carry_m, visit, (int)visit_n);
     }
     // neighbourhood lists for the kNN normals (option "hoods"; maps beyond 2^22 points keep the row walk: 27 x 16 B per
     // point would be gigabytes).  The start of a run is an int: 27 M < 2^31 holds for every map that gets here

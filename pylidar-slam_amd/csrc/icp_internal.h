@@ -472,6 +472,11 @@ struct icp_ctx {
     bool map_stream_busy = false;
     hipEvent_t switch_event = nullptr;  // orders a change of stream (icp_set_stream) behind the work of the old one
     // ---- scratch for projection / sampling / io
+    // the map update in front of the coming grid build kept `order_kept` points of the `order_old_m` the current grid holds
+    // (the oldest `order_evicted` dropped): k_grid_insert2 may claim in the old grid's cell order (option "insert_by_cell")
+    bool order_job = false;
+    int64_t order_old_m = 0, order_evicted = 0, order_kept = 0;
+    int insert_by_cell = 1;
     int seed_job_n = 0, seed_job_m = 0, seed_job_evicted = 0;  // NN cache -> frame seeds, pending for the next grid build
     const void* zbuf_clean = nullptr;  // the z-buffer allocation the resolve kernel has left all-clear, and its size
     int zbuf_clean_pixels = 0;
