@@ -48,7 +48,12 @@ int prof_begin(icp_ctx* ctx, int kind, int iter) {
     const int ev = (int)p.pending.size();
     if (ev >= (int)p.pool.size()) {
         hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        // (timing events only: no system-scope fence when they are recorded — the cache write-back and invalidation of the
+        // default flavour is charged to the work behind the event, hip_runtime_api.h; they are read after the registration's
+        // own result event has been waited for)
+        if (hipEventCreateWithFlags(&a, hipEventDisableSystemFence) != hipSuccess ||
+            hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess)
+            return -1;
         p.pool.push_back({a, b});
     }
     (void)hipEventRecord(p.pool[ev].first, ctx->stream);
@@ -2065,8 +2070,8 @@ int icp_profile_event_floor(icp_ctx* ctx, int32_t samples, double* median_us_out
     DeviceGuard device_guard(ctx);
     if (!ctx || !median_us_out || samples < 1 || samples > 4096) return ICP_ERR_INVALID_ARGUMENT;
     hipEvent_t a, b;
-    ICP_HIP(ctx, hipEventCreate(&a));
-    ICP_HIP(ctx, hipEventCreate(&b));
+    ICP_HIP(ctx, hipEventCreateWithFlags(&a, hipEventDisableSystemFence));  // (the flavour prof_begin uses)
+    ICP_HIP(ctx, hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
     std::vector<float> us;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < samples + 8; ++k) {
