@@ -152,3 +152,31 @@ def test_bench_gpus_n_without_gpus_reports_instead_of_asking_for_a_launcher():
     assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and "needs 2 visible GPUs" in d["error"]
+
+
+def test_bench_sequence_threads_get_their_inputs_from_the_constructing_thread():
+    """bench.py's throughput arrangement (S sequences on S host threads): the scans and the map of every sequence are
+    generated when its `SequenceThread` is CONSTRUCTED — one after the other on the caller's thread — not inside the
+    threads: generated concurrently on the GPU box's 256-thread host they came out different in one run in four (numpy /
+    BLAS rounding under concurrency; a ray that grazes a box edge then lands metres away), and the thread-driven sequences
+    returned other poses than in the other runs (round 5).  Same generator, same seed -> the same bytes."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        import bench
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    t = bench.SequenceThread(args, 101, 0, frames=4)
+    assert not t.is_alive()  # (constructed, not started: nothing here needs a GPU)
+    scans, poses, model, order, start = t.workload
+    again = bench.make_workload(101, args.trajectory, 4)
+    assert sorted(scans) == sorted(again[0])
+    for f in scans:
+        np.testing.assert_array_equal(scans[f], again[0][f])
+    np.testing.assert_array_equal(model, again[2])
+    assert order == again[3] and start == again[4]
