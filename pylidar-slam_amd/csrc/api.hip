@@ -176,6 +176,17 @@ static bool device_shared_with_another_registration(const icp_ctx* ctx) {
     return g_registering[d].load() > (ctx->counted_registering ? 1 : 0);
 }
 
+// An entry point of the registration that leaves on an error must not leave its context counted among the registering ones
+// (every other context of the device then ran without lead launches for the life of the process): on scope exit,
+// a context with no registration in progress and no result pending leaves the count.
+struct RegisteringGuard {
+    icp_ctx* ctx;
+    explicit RegisteringGuard(icp_ctx* c) : ctx(c) {}
+    ~RegisteringGuard() {
+        if (ctx && !ctx->in_registration && ctx->r_count == 0) registering_leave(ctx);
+    }
+};
+
 static int fail(icp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->error = msg;
     return code;
@@ -380,7 +391,9 @@ int icp_set_stream(icp_ctx* ctx, void* hip_stream) {
     DeviceGuard device_guard(ctx, false);  // (callers re-announce their stream before every call: no join for the same stream)
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
     hipStream_t next = (hipStream_t)hip_stream;
-    if (next == ctx->stream) return ICP_OK;
+    // (the same stream re-announced: nothing to order — but iterations a chunked launch holds back still go first, as the
+    // header promises for every entry point behind which the caller may enqueue work of its own)
+    if (next == ctx->stream && ctx->launch_remaining <= 0) return ICP_OK;
     { DeviceGuard join_map_stream(ctx); }  // a new stream: the old one first takes in the map stream, the new one follows it
     {   // iterations a chunked launch still holds back run against the map / configuration they were launched with
         const int rc_held = continue_launch(ctx, -1);
@@ -419,7 +432,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "knn_lanes") ctx->knn_lanes = iv == 2 ? 2 : 4;
     else if (k == "scan_poll_limit") ctx->scan_poll_limit = iv < 0 ? 0 : iv;
     else if (k == "exchange_timeout_ms") ctx->exchange_timeout_ms = value > 1.0 ? value : 1.0;
-    else if (k == "lead_solve") { ctx->lead_solve = value != 0.0 ? 1 : 0; if (ctx->lead_solve) ctx->tail_disabled = false; }
+    else if (k == "lead_solve") { ctx->lead_solve = value != 0.0 ? 1 : 0; if (ctx->lead_solve) ctx->tail_disabled = ctx->handoff_disabled = false; }
     else if (k == "resident_tail") { ctx->resident_tail = iv < 0 ? 0 : (int)iv; ctx->tail_disabled = false; }
     else if (k == "resident_tail_max_blocks") ctx->resident_tail_max_blocks = iv < 0 ? 0 : (int)iv;
     else if (k == "ball_search") ctx->ball_search = value != 0.0 ? 1 : 0;
@@ -1454,6 +1467,10 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     // ... or on demand inside the fused iteration kernel, where the scan touches a small part of the map ("lazy_fused")
     ctx->lazy_now = !ctx->normals_ready && wants_lazy_fused(ctx, n);
     registering_enter(ctx);
+    // lead launches or not: decided ONCE per registration (another context of the process starting or ending a
+    // registration between two chunks of this one flipped the answer — a chunk without a lead publishes no pose, the next
+    // lead chunk then took a stale one from the mailbox)
+    ctx->lead_latched = ctx->lead_solve && !ctx->handoff_disabled && !device_shared_with_another_registration(ctx);
     ctx->in_registration = true;
     ctx->iter_in_registration = 0;
     ctx->cache_fresh = false;
@@ -1584,7 +1601,8 @@ static int continue_launch(icp_ctx* ctx, int count) {
 static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block) {
     { DeviceGuard join_map_stream(ctx); }  // (a map update on its own stream: everything below follows it)
     ctx->tail_disabled = true;
-    ctx->lead_solve = 0;
+    ctx->handoff_disabled = true;  // (the user's "lead_solve" stays as set; setting it again re-arms the hand-offs)
+    ctx->lead_latched = false;
     ctx->handoff_fallbacks += 1;
     ctx->launch_remaining = 0;
     ICP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1615,6 +1633,7 @@ static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block)
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx, false);  // (the pose arrives while the map update runs)
     if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
+    RegisteringGuard leave_on_exit(ctx);
     RegState st;
     const bool async = ctx->result_pending();
     bool had_stats;
@@ -1658,10 +1677,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         if (rc_rec) return rc_rec;
         if (async) pinned = recovered.data();
     }
-    if (ctx->r_count == 0) {
-        ctx->update_behind_registration = false;
-        registering_leave(ctx);
-    }
+    if (ctx->r_count == 0) ctx->update_behind_registration = false;  // (the guard above leaves the count of registering contexts)
     if (had_stats && st.grid_cells > 0) {
         ctx->occupied_cells = st.grid_cells;
         ctx->stats_m = stats_m;
@@ -1692,6 +1708,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
                 for (int i = 0; i < nb; ++i) {
                     const long long* q = t + 4 * i;
                     if (q[0] == 0) continue;  // the 512-queries-per-block shape launches a quarter of the blocks
+                    if ((q[3] & MASK) == 0) continue;  // (slot 1023 of a lead launch: the LEAD's three stamps, no end stamp — not a workgroup of the iteration)
                     ++seen;
                     const long long t0 = q[0] & MASK, t1 = q[1] & MASK, t2 = q[2] & MASK, t3 = q[3] & MASK;
                     const int miss = (int)(q[1] >> 48);
@@ -1821,8 +1838,7 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
     // lead launches: the solve of iteration k rides in the head of launch k + 1 (LeadArgs, icp_internal.h); one summing /
     // solving launch remains, behind the last iteration.  Not with the host polling in between (it reads the RegState,
     // which would lag one iteration) and not with the in-library exchange (its solve waits for the peers)
-    const bool lead = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && poll == 0 &&
-                      !device_shared_with_another_registration(ctx);
+    const bool lead = ctx->lead_latched && fused_path(ctx) && !ctx->exchange_on && poll == 0;
     int prev_rows = 0, prev_quad = 1;  // rows a lead launch still has to solve
     for (int it = first; it < iters; ++it) {
         if (lead && fused_tail_possible(ctx, prev_rows, iters - it)) {
@@ -1879,6 +1895,7 @@ static int enqueue_iterations(icp_ctx* ctx, bool poll_allowed, int first, int co
 static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
                            const float init_pose[16], bool from_last) {
     if (!ctx) return ICP_ERR_INVALID_ARGUMENT;
+    RegisteringGuard leave_on_error(ctx);
     if (ctx->r_count >= 2) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
     int rc = continue_launch(ctx, -1);  // (an older launch still holding iterations back: they come first on the stream)
     if (rc) return rc;
@@ -1891,8 +1908,7 @@ static int register_launch(icp_ctx* ctx, const float* xyz, int64_t n, int mem, i
     const int iters = ctx->cfg.max_num_alignments;
     int first_chunk = iters;
     // (lead launches that end in a resident tail run to the end of the loop on the device: nothing to chunk)
-    const bool tail = ctx->lead_solve && fused_path(ctx) && !ctx->exchange_on && fused_tail_planned(ctx, iters) &&
-                      !device_shared_with_another_registration(ctx);
+    const bool tail = ctx->lead_latched && fused_path(ctx) && !ctx->exchange_on && fused_tail_planned(ctx, iters);
     if (ctx->cfg.threshold_delta_pose > 0.f && ctx->chunked_launch && !tail) {
         first_chunk = (ctx->last_iterations > 0 ? ctx->last_iterations : 3) + 1;
         if (first_chunk > iters) first_chunk = iters;
@@ -1922,6 +1938,7 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
                  icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !result) return ICP_ERR_INVALID_ARGUMENT;
+    RegisteringGuard leave_on_error(ctx);
     int rc = icp_register_begin(ctx, xyz, n, mem, target_mode, init_pose);
     if (rc) return rc;
     if ((rc = enqueue_iterations(ctx, true))) return rc;

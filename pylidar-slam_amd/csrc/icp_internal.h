@@ -405,6 +405,8 @@ struct icp_ctx {
     int resident_tail = 0;
     int resident_tail_max_blocks = 4096;  // "resident_tail_max_blocks": ... for scans of up to that many 512-query workgroups
     bool tail_disabled = false;        // a hand-off of this context timed out once (a GPU shared with foreign work): per-iteration launches from then on
+    bool handoff_disabled = false;     // ... and no lead launches either (the user's "lead_solve" is left as set; setting it again re-arms them)
+    bool lead_latched = false;         // lead launches for the registration in progress: decided once, in register_begin
     int tail_capacity = -1;            // workgroups of the tail's shape the device holds at once (-1: not asked yet)
     int handoff_fallbacks = 0;         // registrations finished on per-iteration launches behind a timed-out hand-off
     bool counted_registering = false;  // this context is counted among the registering contexts of its device (api.hip)

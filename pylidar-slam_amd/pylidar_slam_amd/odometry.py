@@ -274,7 +274,7 @@ class ToDevice:
         slot = self._slots.get(key)
         if slot is None or slot["pin"].numel() < t.numel() or slot["pin"].dtype != t.dtype:
             slot = self._slots[key] = {"pin": torch.empty(t.numel(), dtype=t.dtype, pin_memory=True), "free": None,
-                                       "dev": [None, None], "which": 0}
+                                       "dev": [None, None], "which": 0, "used": [None, None]}
         if slot["free"] is not None:
             slot["free"].synchronize()  # the previous frame's DMA has left the staging buffer (long done in practice)
         stage = slot["pin"][:t.numel()].view(t.shape)
@@ -284,12 +284,23 @@ class ToDevice:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
+        # the device slot handed out by the PREVIOUS call: whatever read it has been enqueued on the caller's stream by now —
+        # an event there, which the DMA that overwrites that slot (the call after this one) waits for.  (the
+        # upload stream never waited for the consumers; safe only behind the odometry's per-frame synchronisation.  The
+        # wait is for work enqueued a whole frame ago, so the upload still overlaps the map update of the frame in between.)
+        prev = slot["which"]
+        if slot["dev"][prev] is not None:
+            if slot["used"][prev] is None:
+                slot["used"][prev] = torch.cuda.Event()
+            slot["used"][prev].record(main)
         slot["which"] ^= 1
         dev = slot["dev"][slot["which"]]
         if dev is None or dev.numel() < t.numel() or dev.dtype != t.dtype:
             dev = slot["dev"][slot["which"]] = torch.empty(t.numel(), dtype=t.dtype, device=self.device)
         out = dev[:t.numel()].view(t.shape)
         with torch.cuda.stream(self._stream):
+            if slot["used"][slot["which"]] is not None:
+                self._stream.wait_event(slot["used"][slot["which"]])
             out.copy_(stage, non_blocking=True)
             slot["free"] = torch.cuda.Event()
             slot["free"].record(self._stream)

@@ -13,7 +13,56 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 __all__ = ["SceneConfig", "ray_directions", "pose_matrix", "trajectory", "render_scan", "make_sequence",
-           "make_fixed_map"]
+           "make_fixed_map", "rotate_rows"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# rows @ R.T without BLAS.  The generator's bits must not depend on how a BLAS library partitions a 131072 x 3 product
+# among its threads (round 5: `dirs @ R.T` called from several Python threads at once rounded differently from run to
+# run on a 256-thread host — a ray that grazes a box edge then lands metres away, and the golden fixtures, which hold the
+# sha1 of the generated inputs, no longer match).  What OpenBLAS computes for such a row is the fused chain
+# fma(x2, r2, fma(x1, r1, x0 * r0)); that chain is evaluated here with error-free transformations (Dekker's product,
+# Knuth's sum) and ONE rounding to odd in front of the final addition (Boldo & Melquiond, "Emulation of FMA and correctly
+# rounded sums: proved algorithms using rounding to odd", IEEE TC 2008): the correctly rounded a * b + c in float64, element
+# by element, in a fixed order — the same bits as the BLAS product the fixtures were generated with, on every host.
+# ----------------------------------------------------------------------------------------------------------------------
+_SPLIT = 134217729.0  # 2^27 + 1 (Veltkamp)
+
+
+def _two_sum(a, b):
+    s = a + b
+    bb = s - a
+    return s, (a - (s - bb)) + (b - bb)
+
+
+def _two_prod(a, b):
+    p = a * b
+    ca = _SPLIT * a
+    ah = ca - (ca - a)
+    al = a - ah
+    cb = _SPLIT * b
+    bh = cb - (cb - b)
+    bl = b - bh
+    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
+
+
+def _fma(a, b, c):
+    """Correctly rounded a * b + c (float64 arrays / scalars; no overflow or underflow in the products)."""
+    uh, ul = _two_prod(a, b)
+    th, tl = _two_sum(c, uh)
+    s, e = _two_sum(tl, ul)  # v = round-to-odd(tl + ul): RN, then one step towards the exact sum where RN came out even
+    s = np.asarray(s, dtype=np.float64)
+    even = (s.view(np.int64) & 1) == 0
+    v = np.where((e != 0.0) & even, np.nextafter(s, np.where(e > 0.0, np.inf, -np.inf)), s)
+    return th + v
+
+
+def rotate_rows(rows: np.ndarray, rot: np.ndarray) -> np.ndarray:
+    """`rows @ rot.T` for [N,3] float64 rows and a 3x3 matrix: column j = fma(x2, r_j2, fma(x1, r_j1, x0 * r_j0))."""
+    rows = np.asarray(rows, dtype=np.float64)
+    rot = np.asarray(rot, dtype=np.float64)
+    x0, x1, x2 = (np.ascontiguousarray(rows[:, k]) for k in range(3))
+    return np.stack([_fma(x2, rot[j, 2], _fma(x1, rot[j, 1], x0 * rot[j, 0])) for j in range(3)], axis=1)
 
 
 @dataclass
@@ -132,7 +181,7 @@ def render_scan(cfg: SceneConfig, pose: np.ndarray, frame: int, dirs: Optional[n
     if dirs is None:
         dirs = ray_directions(cfg)
     o = pose[:3, 3]
-    dw = dirs @ pose[:3, :3].T
+    dw = rotate_rows(dirs, pose[:3, :3])  # (not `dirs @ R.T`: see rotate_rows)
     t = _ray_box_exit(o, dw, cfg.room)
     for b in cfg.boxes:
         t = np.minimum(t, _ray_box_entry(o, dw, b))
@@ -161,7 +210,7 @@ def make_fixed_map(cfg: SceneConfig, scans, poses, ref_frame: int, num_points: i
     clouds = []
     for s, p in zip(scans, poses):
         rel = inv_ref @ p
-        pts = s.astype(np.float64) @ rel[:3, :3].T + rel[:3, 3]
+        pts = rotate_rows(s.astype(np.float64), rel[:3, :3]) + rel[:3, 3]
         keys = np.round(pts / voxel).astype(np.int64)
         _, first = np.unique(keys, axis=0, return_index=True)
         clouds.append(pts[np.sort(first)])

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--no-save", action="store_true", help="print the JSON line only (bench.py's cpu_baseline calls it so)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from slam.common.pose import Pose
@@ -60,7 +61,7 @@ def main():
         gt = np.linalg.inv(poses[prev]) @ poses[f]
         errs.append(float(np.linalg.norm(gt[:3, 3] - mat[0].numpy()[:3, 3])))
         last, prev = mat, f
-        print(f"frame {i}: {times[-1]:.2f} s, |t - t_gt| = {errs[-1]:.2e} m", flush=True)
+        print(f"frame {i}: {times[-1]:.2f} s, |t - t_gt| = {errs[-1]:.2e} m", file=sys.stderr, flush=True)
     timed = sorted(times[args.warmup:])
     med = timed[len(timed) // 2]
     out = {"kind": "reference", "what": "slam.odometry.icp_odometry.ICPFrameToModel (unmodified) through oracle/shims: "
@@ -69,9 +70,10 @@ def main():
            "value": 1.0 / med, "unit": "scans/s", "frame_s": {"min": timed[0], "median": med, "max": timed[-1]},
            "frames": args.frames, "warmup": args.warmup, "torch_threads": torch.get_num_threads(),
            "cores": os.cpu_count(), "kd_tree": "scipy cKDTree standing in for pykdtree", "tree_build_s": build_s,
-           "max_pose_error_vs_ground_truth_m": max(errs[args.warmup:]), "where": "build container (no GPU)"}
-    path = os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json")
-    json.dump(out, open(path, "w"), indent=1)
+           "max_pose_error_vs_ground_truth_m": max(errs[args.warmup:]),
+           "where": "the host cores of the box bench.py runs on" if args.no_save else "build container (no GPU)"}
+    if not args.no_save:
+        json.dump(out, open(os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
