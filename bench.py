@@ -138,6 +138,10 @@ def parse():
                     help="after the headline (single process, --sequences-per-gpu 1 only): S independent sequences on S "
                          "streams of this GPU for the same number of steps, reported as `throughput` in the JSON line "
                          "(0: skip; also skipped with --no-cpu-baseline, the switch of the developer A/B runs)")
+    ap.add_argument("--batched-leg", default="4,8,16", metavar="B[,B..]",
+                    help="after the headline (single process, one sequence): `throughput_batched` — B sequences per launch "
+                         "(icp_batch_*) for each listed B, 200 timed steps per sequence in three windows (empty string: skip; "
+                         "also skipped with --no-cpu-baseline)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (icp_set_option), repeatable — for A/B runs")
     ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
@@ -145,7 +149,7 @@ def parse():
                          "200k-point scan against a 1M-point map with map-sharded normals — timed on its own (one GPU: "
                          "the single-device figure; N GPUs: scan- and map-sharded) and printed as the line's value with "
                          "`config.workload` saying so")
-    ap.add_argument("--leg", choices=["plugin", "odometry_loop"], default=None,
+    ap.add_argument("--leg", choices=["plugin", "odometry_loop", "throughput_batched"], default=None,
                     help="developer switch (profiling): run ONLY that leg and print its object")
     ap.add_argument("--plugin-steps", type=int, default=60,
                     help="timed frames of the plugin leg (the workload through MI355XICPFrameToModel.process_next_frame "
@@ -310,7 +314,7 @@ class Tracker:
 class SequenceThread(threading.Thread):
     """Throughput mode: one more sequence on its own context / HIP stream / host thread."""
 
-    def __init__(self, args, seq, device_index, frames=None):
+    def __init__(self, args, seq, device_index, frames=None, workload=None):
         super().__init__(daemon=True)
         self.args, self.seq, self.device_index = args, seq, device_index
         self.frames = frames if frames is not None else args.warmup + args.steps
@@ -319,7 +323,7 @@ class SequenceThread(threading.Thread):
         # box's 256-thread host (tools/dev/r5_wl_det.py: numpy / BLAS work of several threads at once does not round alike
         # from run to run, and a ray that grazes a box edge lands metres away when its direction moves by an ulp) — the
         # thread-driven sequences then returned other poses (1e-4 .. 1e-3 m) than in the other runs: inputs, not the library
-        self.workload = make_workload(seq, args.trajectory, self.frames)
+        self.workload = workload if workload is not None else make_workload(seq, args.trajectory, self.frames)
         self.go, self.done, self.ready = threading.Event(), threading.Event(), threading.Event()
         self.phase = 0
         self.max_err = 0.0
@@ -349,7 +353,7 @@ class SequenceThread(threading.Thread):
         self.go.set()
 
 
-def throughput_leg(args, S, device_index, main_tr):
+def throughput_leg(args, S, device_index, main_tr, workloads=None):
     """S independent sequences on S contexts / streams / host threads of this GPU, outside the headline timing: what the
     chip delivers when it is not waiting on one sequence's chain of dependent kernels.  Same arrangement as
     `--sequences-per-gpu S`: the headline's tracker carries on as one of them on the main thread (a process has four
@@ -365,7 +369,8 @@ def throughput_leg(args, S, device_index, main_tr):
     # by three freshly started Python threads: 3212-3872 scans/s where 60 steps of the same build gave 4330 — VERDICT r4)
     steps = max(60, args.steps)
     warm = max(10, args.warmup)
-    threads = [SequenceThread(args, 100 + j, device_index, frames=warm + steps) for j in range(1, S)]
+    threads = [SequenceThread(args, 100 + j, device_index, frames=warm + steps, workload=workloads[j - 1] if workloads else None)
+               for j in range(1, S)]
     for t_ in threads:
         t_.start()
     for t_ in threads:
@@ -405,6 +410,73 @@ def throughput_leg(args, S, device_index, main_tr):
             "whole_path_algorithmic_GBps": frame_bytes * value / 1e9,
             "whole_path_frac_of_hbm_peak": frame_bytes * value / HBM_PEAK, "options": ["lead_solve=0", "wide_until=0"],
             "max_pose_error_vs_ground_truth_m": err, "max_pose_error_by_sequence_m": err_by_sequence}
+
+
+def batched_leg(args, device_index, workloads, sizes=(4, 8, 16), steps=200, warm=20, windows=3):
+    """B independent sequences advanced by ONE launch per ICP iteration (`icp_batch_*`: the members' arguments in a
+    descriptor table in device memory, a lead workgroup per sequence, one host thread, one stream) — SURVEY §8(d): "HBM-bound
+    operation is only approachable by batching many independent registrations per launch".  Every sequence is the headline's
+    workload on data of its own (other seeds: other scans, other maps) with the headline's per-frame work: projection,
+    20-iteration registration from the constant-velocity guess, pose back to the host, pose-only map update + grid rebuild.
+    For each B: `warm` untimed steps, then `windows` timed windows of `steps` steps per sequence (one step = one frame of
+    every sequence); value = the median window's B * steps / elapsed.  Per-sequence poses are those of the single-sequence
+    run bit for bit (tests/test_gpu_batch.py)."""
+    from pylidar_slam_amd.engine import IcpBatch
+    trackers = [Tracker(args, 100 + j, args.trajectory, warm + steps, device_index, workload=w)
+                for j, w in enumerate(workloads)]
+    for opt in [o for o in os.environ.get("BENCH_BATCH_OPTIONS", "").split(",") if o]:  # (developer A/B runs of this leg only)
+        for t in trackers:
+            t.ctx.set_option(opt.split("=")[0], float(opt.split("=")[1]))
+    carried = not any(o.replace(" ", "") in ("carry_normals=0", "carry_normals=0.0") for o in args.option)
+    frame_bytes = args.iters * BYTES_PER_POINT_ITER * 131072 + 28 * 131072 + (48 + 28 + (0 if carried else 132)) * 100_000
+    out = {"unit": "scans/s", "steps_per_sequence_per_window": steps, "windows": windows, "warmup_steps": warm,
+           "frame": "projection + 20-iteration registration (constant-velocity guess) + pose to the host + pose-only map "
+                    "update / grid rebuild, per sequence; one launch per ICP iteration for all B sequences", "by_B": {}}
+    best = None
+    for B in sizes:
+        if B > len(trackers):
+            continue
+        trs = trackers[:B]
+        batch = IcpBatch([t.ctx for t in trs])
+
+        def run(k):
+            for _ in range(k):
+                scans, frames = [], []
+                for t in trs:
+                    f = t.order[t.cursor % len(t.order)]
+                    t.ctx.project(t.scans[f], out=t.vmap)
+                    scans.append(t.scans[f])
+                    frames.append(f)
+                batch.register_launch(scans, [t.last for t in trs] if args.init == "cv" else None)
+                batch.map_update()
+                for t, f, r in zip(trs, frames, batch.register_end()):
+                    t._account(r, f, t.prev)
+                    t.prev = f
+                    t.cursor += 1
+
+        run(warm)
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(windows):
+            t0 = time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            rates.append(B * steps / (time.perf_counter() - t0))
+        batch.close()
+        med = sorted(rates)[len(rates) // 2]
+        rec = {"value": med, "windows_scans_per_s": rates, "ms_per_step": B * 1e3 / med, "ms_per_frame_amortised": 1e3 / med,
+               "whole_path_algorithmic_GBps": frame_bytes * med / 1e9, "whole_path_frac_of_hbm_peak": frame_bytes * med / HBM_PEAK,
+               "max_pose_error_by_sequence_m": [t.max_err for t in trs],
+               "handoff_fallbacks": sum(t.ctx.handoff_fallbacks() for t in trs)}
+        out["by_B"][str(B)] = rec
+        if best is None or med > best[1]:
+            best = (B, med, rec)
+    for t in trackers:
+        t.close()
+    if best is not None:
+        out.update({"value": best[1], "sequences_per_launch": best[0],
+                    "whole_path_frac_of_hbm_peak": best[2]["whole_path_frac_of_hbm_peak"]})
+    return out
 
 
 def plugin_leg(args, tracker, device_index, steps, warmup):
@@ -872,6 +944,12 @@ def main():
     if args.leg == "odometry_loop":
         print(json.dumps({"odometry_loop": odometry_loop_leg(args, local_rank)}))
         return
+    if args.leg == "throughput_batched":
+        sizes = tuple(int(v) for v in args.batched_leg.split(",") if v.strip())
+        shared = [make_workload(101 + j, args.trajectory, 300) for j in range(max(sizes))]
+        print(json.dumps({"throughput_batched": batched_leg(args, local_rank, shared, sizes=sizes,
+                                                            steps=max(20, args.steps), warm=max(5, args.warmup))}))
+        return
     if args.leg == "plugin":
         tr = Tracker(args, 0, args.trajectory, args.warmup + args.steps, local_rank)
         print(json.dumps({"plugin": plugin_leg(args, tr, local_rank, args.plugin_steps, max(3, args.warmup))}))
@@ -981,9 +1059,21 @@ def main():
     # the 4-sequence leg BEFORE the legs that open further HIP streams (the plugin uploads and copies on side streams):
     # a process has four hardware queues, and a stream more than the sequences need makes two of them share one
     # (2470 instead of 3430 scans/s, measured)
-    through = None
-    if rank == 0 and world == 1 and S == 1 and args.throughput_leg > 1 and not sharded and not args.no_cpu_baseline:
-        through = throughput_leg(args, args.throughput_leg, local_rank, main_tr)
+    through = batched = None
+    if rank == 0 and world == 1 and S == 1 and not sharded and not args.no_cpu_baseline:
+        sizes = tuple(int(v) for v in args.batched_leg.split(",") if v.strip())
+        want = max([args.throughput_leg - 1 if args.throughput_leg > 1 else 0] + list(sizes))
+        # the sequences of both throughput legs: generated here, on the main thread, one after the other (see SequenceThread)
+        shared = [make_workload(101 + j, args.trajectory, 300) for j in range(want)]
+        if args.throughput_leg > 1:
+            through = throughput_leg(args, args.throughput_leg, local_rank, main_tr, workloads=shared)
+            main_tr.ctx.set_option("lead_solve", 1)  # (the leg's schedule knobs: back to the defaults)
+            main_tr.ctx.set_option("wide_until", 3)
+        if sizes:
+            try:
+                batched = batched_leg(args, local_rank, shared, sizes=sizes)
+            except Exception as e:  # a failed leg must not cost the line its headline
+                batched = {"error": repr(e)}
     plugin = odo_loop = None
     if rank == 0 and not sharded and S == 1 and not args.no_cpu_baseline:
         if args.plugin_steps > 0:
@@ -1059,6 +1149,8 @@ def main():
             out["loop"] = loop
         if through is not None:
             out["throughput"] = through
+        if batched is not None:
+            out["throughput_batched"] = batched
         if prof and prof["search_launches"] > 0:
             # launch-weighted mean = mean over the iteration indices of the per-index means (every index weighs one launch
             # per frame whatever the number of samples it got)

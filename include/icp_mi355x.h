@@ -421,6 +421,41 @@ void* icp_normal_equations_ptr(icp_ctx* ctx); /* device pointer, 32 doubles */
 /* use caller-owned device memory (e.g. a torch tensor RCCL can reduce in place) for the 32-double vector */
 int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
 
+/* ---- B sequences per launch: batched registration ------------------------------------------------------------------
+ * The reference registers ONE sequence, one frame at a time (ICPFrameToModel.register_new_frame,
+ * slam/odometry/icp_odometry.py:248-299; one `SLAM` object per process, slam/slam.py:84-163): a chain of dependent,
+ * latency-bound iterations that leaves most of an MI355X idle.  A batch ties B contexts of ONE device — B independent
+ * sequences, each with its own local map, scan and registration state — together so that iteration k of all B
+ * registrations is ONE kernel launch ("HBM-bound operation is only approachable by batching many
+ * independent registrations per launch"): the per-sequence arguments sit in a descriptor table in device memory, every
+ * sequence has a lead workgroup of its own, and one host thread enqueues the launches of all B.  Per sequence the
+ * arithmetic is that of icp_register_launch on the same context with the same options: the same poses, bit for bit.
+ *   icp_batch_create           ties `count` contexts (1..ICP_BATCH_MAX_SEQUENCES, same device, same alignment configuration
+ *                              — max_num_alignments, scheme, sigma — and same schedule options) together; they stay usable on
+ *                              their own between batched calls and must outlive the batch;
+ *   icp_batch_set_stream       icp_set_stream on every member (a batch enqueues everything on ONE stream);
+ *   icp_batch_register_launch  icp_register_launch (from_last = 0; init_poses = count x 16 floats or NULL: identity) or
+ *                              icp_register_launch_from_last (from_last = 1) on every member: xyz[b] / n[b] = member b's
+ *                              scan.  Every iteration is enqueued (no chunking: a member whose loop has ended costs
+ *                              nothing on the device).  Point-to-plane registrations on the fused path only (eager
+ *                              normals, no exchange, no profiling): ICP_ERR_INVALID_ARGUMENT otherwise;
+ *   icp_batch_map_update       icp_map_update(member, NULL, NULL, ...) for every member: the pose-only update by the
+ *                              device-resident pose of the registration just launched (icp_odometry.py:379);
+ *   icp_batch_register_end     icp_register_end for every member (results[b]; loss_per_iter_out / dx_per_iter_out:
+ *                              count x max_num_alignments (x 6) entries or NULL): ONE wait for all of them.  Returns the
+ *                              first member's non-zero status, every member's own in results[b].status. */
+#define ICP_BATCH_MAX_SEQUENCES 32
+typedef struct icp_batch icp_batch;
+int icp_batch_create(icp_ctx* const* ctxs, int32_t count, icp_batch** out);
+void icp_batch_destroy(icp_batch* batch);
+const char* icp_batch_last_error(const icp_batch* batch);
+int icp_batch_set_stream(icp_batch* batch, void* hip_stream);
+int icp_batch_register_launch(icp_batch* batch, const float* const* xyz, const int64_t* n, int mem, int target_mode,
+                              const float* init_poses, int from_last);
+int icp_batch_map_update(icp_batch* batch);
+int icp_batch_register_end(icp_batch* batch, icp_register_result* results, double* loss_per_iter_out,
+                           float* dx_per_iter_out);
+
 /* ---- multi-GPU exchange inside the library ("one-shot P2P write+flag all-reduce") -----------------
  * The per-iteration exchange of the scan-sharded registration without leaving the library: after these three calls
  * icp_register / icp_register_launch on every rank enqueue, per ICP iteration, the iteration kernel and ONE kernel that

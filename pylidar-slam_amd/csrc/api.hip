@@ -1551,7 +1551,7 @@ static int result_fold_begin(icp_ctx* ctx, bool refresh) {
 }
 
 // refresh = true: the newest pending slot is copied again (a further chunk of its registration has been enqueued)
-static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
+static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false, hipEvent_t shared_event = nullptr) {
     icp_ctx::ResultSlot* rp = nullptr;
     const int rc_slot = result_slot(ctx, refresh, &rp);
     if (rc_slot) return rc_slot;
@@ -1562,7 +1562,9 @@ static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false) {
     if (!ctx->result_folded) ICP_HIP(ctx, hipMemcpyAsync(h, ctx->state.ptr, sb, hipMemcpyDeviceToHost, ctx->stream));
     ctx->result_folded = false;
     ctx->result_fold_to = nullptr;
-    ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
+    // (a batched registration: ONE event behind the results of all its members, recorded by the batch — icp_batch_*)
+    r.wait = shared_event ? shared_event : r.event;
+    if (!shared_event) ICP_HIP(ctx, hipEventRecord(r.event, ctx->stream));
     if (refresh) return ICP_OK;
     // the grid statistics about to be read back belong to the current build; a later build starts a new pending set
     r.stats = ctx->stats_pending;
@@ -1642,7 +1644,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
     const char* pinned = nullptr;
     if (async) {  // copies were enqueued right behind the last iteration: wait for those only (the OLDEST result)
         icp_ctx::ResultSlot& r = ctx->rslot[ctx->r_head];
-        ICP_HIP(ctx, hipEventSynchronize(r.event));
+        ICP_HIP(ctx, hipEventSynchronize(r.wait));
         pinned = (const char*)r.host;
         memcpy(&st, pinned, sizeof(st));
         // a chunked launch (only ever the newest pending registration, here also the oldest): still running and
@@ -1650,7 +1652,7 @@ int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per
         while (ctx->r_count == 1 && ctx->launch_remaining > 0 && !st.done && st.status == ICP_OK) {
             const int rc2 = continue_launch(ctx, 4);
             if (rc2) return rc2;
-            ICP_HIP(ctx, hipEventSynchronize(r.event));
+            ICP_HIP(ctx, hipEventSynchronize(r.wait));
             memcpy(&st, pinned, sizeof(st));
         }
         if (ctx->r_count == 1) ctx->launch_remaining = 0;  // (finished early: the rest is never enqueued)
@@ -1943,6 +1945,233 @@ int icp_register(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_
     if (rc) return rc;
     if ((rc = enqueue_iterations(ctx, true))) return rc;
     return icp_register_end(ctx, result, loss_per_iter_out, dx_per_iter_out);
+}
+
+// ---- B sequences per launch (include/icp_mi355x.h: icp_batch_*) ----------------------------------------------------------
+// The descriptor tables of ONE frame — iteration launch after iteration launch, [count] entries each, the summing / solving
+// launches in between — are filled in pinned host memory while the frame's launches are PREPARED (all host bookkeeping of
+// all iterations of all members first: nothing in it depends on a launch having been issued), travel to the device in one
+// copy, and the launches follow.  Three slots in rotation: a slot is rewritten when the registration two frames back has been
+// collected (at most two registrations are ever pending per member), so its launches have long finished.
+struct icp_batch {
+    std::vector<icp_ctx*> members;
+    std::string error;
+    int device = 0;
+    static constexpr int SLOTS = 3;
+    char* host[SLOTS] = {nullptr, nullptr, nullptr};  // pinned
+    size_t host_bytes[SLOTS] = {0, 0, 0};
+    DeviceBuffer dev[SLOTS];
+    hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr};  // the slot's copy has left the pinned buffer
+    hipEvent_t done[2] = {nullptr, nullptr};                  // ONE event behind the results of a batched registration
+    int slot = 0, done_next = 0;
+};
+
+static int batch_fail(icp_batch* b, int code, const std::string& msg) {
+    if (b) b->error = msg;
+    return code;
+}
+
+int icp_batch_create(icp_ctx* const* ctxs, int32_t count, icp_batch** out) {
+    if (!ctxs || !out || count < 1 || count > ICP_BATCH_MAX_SEQUENCES) return ICP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    for (int i = 0; i < count; ++i) {
+        if (!ctxs[i] || ctxs[i]->cfg.device != ctxs[0]->cfg.device) return ICP_ERR_INVALID_ARGUMENT;
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return ICP_ERR_INVALID_ARGUMENT;
+    }
+    icp_batch* b = new icp_batch();
+    b->members.assign(ctxs, ctxs + count);
+    b->device = ctxs[0]->cfg.device;
+    *out = b;
+    return ICP_OK;
+}
+
+void icp_batch_destroy(icp_batch* b) {
+    if (!b) return;
+    DeviceGuard device_guard(b->device);
+    (void)hipDeviceSynchronize();  // (launches that read the tables; members whose result slots wait for the batch's events)
+    for (icp_ctx* ctx : b->members)
+        for (auto& r : ctx->rslot)
+            if (r.wait == b->done[0] || r.wait == b->done[1]) r.wait = r.event;
+    for (int k = 0; k < icp_batch::SLOTS; ++k) {
+        if (b->host[k]) (void)hipHostFree(b->host[k]);
+        b->dev[k].release();
+        if (b->copied[k]) (void)hipEventDestroy(b->copied[k]);
+    }
+    for (auto& e : b->done)
+        if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+const char* icp_batch_last_error(const icp_batch* b) { return b ? b->error.c_str() : "null batch"; }
+
+int icp_batch_set_stream(icp_batch* b, void* hip_stream) {
+    if (!b) return ICP_ERR_INVALID_ARGUMENT;
+    for (icp_ctx* ctx : b->members) {
+        const int rc = icp_set_stream(ctx, hip_stream);
+        if (rc) return batch_fail(b, rc, ctx->error);
+    }
+    return ICP_OK;
+}
+
+int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64_t* n, int mem, int target_mode,
+                              const float* init_poses, int from_last) {
+    if (!b || !xyz || !n) return ICP_ERR_INVALID_ARGUMENT;
+    DeviceGuard device_guard(b->device);
+    const int count = (int)b->members.size();
+    icp_ctx* const* ctxs = b->members.data();
+    icp_ctx* first = ctxs[0];
+    const int iters = first->cfg.max_num_alignments;
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = ctxs[i];
+        { DeviceGuard join_map_stream(ctx); }
+        if (ctx->stream != first->stream)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched registration: the members must enqueue on one stream (icp_batch_set_stream)");
+        if (ctx->cfg.max_num_alignments != iters || ctx->cfg.scheme != first->cfg.scheme || ctx->cfg.sigma != first->cfg.sigma)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched registration: the members must share max_num_alignments, scheme and sigma");
+        if (ctx->r_count >= 2) return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "two results are already pending");
+        if (ctx->exchange_on || ctx->prof.enabled || ctx->search_stats || ctx->cost != ICP_COST_POINT_TO_PLANE)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched registration: point-to-plane registrations without exchange, "
+                                                          "profiling or search statistics only");
+    }
+    struct Unwind {  // an error below leaves no member "in registration" (and none counted among the registering contexts)
+        icp_batch* b;
+        bool armed = true;
+        ~Unwind() {
+            if (!armed) return;
+            for (icp_ctx* ctx : b->members) {
+                ctx->in_registration = false;
+                ctx->result_fold_to = nullptr;
+                ctx->result_folded = false;
+                if (ctx->r_count == 0) registering_leave(ctx);
+            }
+        }
+    } unwind{b};
+    int rc = ICP_OK;
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = ctxs[i];
+        if ((rc = continue_launch(ctx, -1))) return batch_fail(b, rc, ctx->error);  // (an older chunked launch of this member goes first)
+        if ((rc = register_begin(ctx, xyz[i], n[i], mem, target_mode, (init_poses && !from_last) ? init_poses + 16 * i : nullptr,
+                                 from_last != 0)))
+            return batch_fail(b, rc, ctx->error);
+        if (!fused_path(ctx) || ctx->lazy_now)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched registration: the fused iteration path with eagerly estimated "
+                                                          "normals only (see icp_set_option: fuse_iteration, lazy_fused, eager_normals_limit)");
+    }
+    // lead launches (every member's solve in the head of the next launch, by a lead workgroup of its own) unless a context
+    // OUTSIDE the batch is registering on the device: the members themselves are counted, and are no strangers
+    const int d = b->device >= 0 && b->device < 64 ? b->device : 0;
+    int counted = 0;
+    bool lead = true;
+    for (int i = 0; i < count; ++i) {
+        counted += ctxs[i]->counted_registering ? 1 : 0;
+        lead = lead && ctxs[i]->lead_solve && !ctxs[i]->handoff_disabled;
+    }
+    lead = lead && g_registering[d].load() <= counted;
+    for (int i = 0; i < count; ++i) ctxs[i]->lead_latched = lead;
+    // ---- the frame's launches, prepared: descriptors into the pinned slot
+    const int slot = b->slot;
+    b->slot = (slot + 1) % icp_batch::SLOTS;
+    const size_t it_bytes = iterate_desc_bytes() * (size_t)count, ss_bytes = sum_solve_desc_bytes() * (size_t)count;
+    const size_t need = (size_t)iters * (it_bytes + ss_bytes);
+    if (b->host_bytes[slot] < need) {
+        if (b->copied[slot]) ICP_HIP(first, hipEventSynchronize(b->copied[slot]));
+        if (b->host[slot]) (void)hipHostFree(b->host[slot]);
+        b->host[slot] = nullptr;
+        b->host_bytes[slot] = 0;
+        ICP_HIP(first, hipHostMalloc((void**)&b->host[slot], need, hipHostMallocDefault));
+        b->host_bytes[slot] = need;
+    }
+    ICP_HIP(first, b->dev[slot].reserve(need));
+    if (!b->copied[slot]) ICP_HIP(first, hipEventCreateWithFlags(&b->copied[slot], hipEventDisableTiming));
+    else ICP_HIP(first, hipEventSynchronize(b->copied[slot]));  // (three frames ago: long past)
+    for (int i = 0; i < count; ++i)
+        if ((rc = result_fold_begin(ctxs[i], false))) return batch_fail(b, rc, ctxs[i]->error);
+    struct Op {
+        int kind;  // 0: fused iteration, 1: sum + solve
+        size_t offset;
+        BatchedIteration it;
+    };
+    std::vector<Op> ops;
+    ops.reserve(2 * (size_t)iters);
+    size_t used = 0;
+    int prev_rows[ICP_BATCH_MAX_SEQUENCES] = {}, prev_quad[ICP_BATCH_MAX_SEQUENCES];
+    for (int i = 0; i < count; ++i) prev_quad[i] = 1;
+    for (int it = 0; it < iters; ++it) {
+        Op op{0, used, BatchedIteration()};
+        if ((rc = prepare_iterate_batch(ctxs, count, lead, prev_rows, prev_quad, b->host[slot] + used, &op.it))) {
+            for (int i = 0; i < count; ++i)
+                if (!ctxs[i]->error.empty()) b->error = ctxs[i]->error;
+            return rc;
+        }
+        used += it_bytes;
+        ops.push_back(op);
+        bool solve = true;
+        if (lead) {  // (as enqueue_iterations: the narrow launches solve the iteration before them themselves)
+            for (int i = 0; i < count; ++i) {
+                prev_rows[i] = op.it.rows[i];
+                prev_quad[i] = op.it.quad[i];
+            }
+            solve = it + 1 == iters || !next_fused_launch_is_narrow(first) || (op.it.quad[0] && !first->lead_after_dense);
+        }
+        if (solve) {
+            Op so{1, used, BatchedIteration()};
+            if ((rc = prepare_sum_solve_batch(ctxs, count, op.it.rows, op.it.quad, lead, it + 1 == iters, b->host[slot] + used)))
+                return batch_fail(b, rc, "batched registration: sum + solve");
+            used += ss_bytes;
+            ops.push_back(so);
+            for (int i = 0; i < count; ++i) prev_rows[i] = 0;
+        }
+    }
+    // ---- one copy, then the launches
+    ICP_HIP(first, hipMemcpyAsync(b->dev[slot].ptr, b->host[slot], used, hipMemcpyHostToDevice, first->stream));
+    ICP_HIP(first, hipEventRecord(b->copied[slot], first->stream));
+    for (const Op& op : ops) {
+        const char* table = b->dev[slot].as<char>() + op.offset;
+        rc = op.kind == 0 ? launch_iterate_batch(first, op.it, table) : launch_sum_solve_batch(first, count, table);
+        if (rc) return batch_fail(b, rc, first->error);
+    }
+    // ---- the results: every member's block lands in its own pinned slot (written by the last solving launch), ONE event
+    hipEvent_t& done = b->done[b->done_next];
+    b->done_next ^= 1;
+    if (!done) ICP_HIP(first, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = ctxs[i];
+        ctx->launch_enqueued = iters;
+        ctx->launch_remaining = 0;
+        if ((rc = enqueue_result_copy(ctx, false, done))) return batch_fail(b, rc, ctx->error);
+        ctx->result_fold_to = nullptr;
+        ctx->result_folded = false;
+        ctx->in_registration = false;  // the result waits in its slot
+    }
+    ICP_HIP(first, hipEventRecord(done, first->stream));
+    unwind.armed = false;
+    return ICP_OK;
+}
+
+int icp_batch_map_update(icp_batch* b) {
+    if (!b) return ICP_ERR_INVALID_ARGUMENT;
+    for (icp_ctx* ctx : b->members) {
+        const int rc = icp_map_update(ctx, nullptr, nullptr, 0, ICP_MEM_DEVICE, ICP_TARGETS_ALL, nullptr);
+        if (rc) return batch_fail(b, rc, ctx->error);
+    }
+    return ICP_OK;
+}
+
+int icp_batch_register_end(icp_batch* b, icp_register_result* results, double* loss_per_iter_out, float* dx_per_iter_out) {
+    if (!b || !results) return ICP_ERR_INVALID_ARGUMENT;
+    int first_rc = ICP_OK;
+    const size_t cap = (size_t)b->members[0]->cfg.max_num_alignments;
+    for (size_t i = 0; i < b->members.size(); ++i) {
+        icp_ctx* ctx = b->members[i];
+        const int rc = icp_register_end(ctx, &results[i], loss_per_iter_out ? loss_per_iter_out + i * cap : nullptr,
+                                        dx_per_iter_out ? dx_per_iter_out + i * cap * 6 : nullptr);
+        if (rc && !first_rc) {
+            first_rc = rc;
+            b->error = ctx->error;
+        }
+    }
+    return first_rc;
 }
 
 void* icp_normal_equations_ptr(icp_ctx* ctx) {

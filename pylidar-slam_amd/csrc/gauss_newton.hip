@@ -279,13 +279,13 @@ __global__ __launch_bounds__(64) void k_solve(RegState* __restrict__ st, const d
 }
 
 // single-GPU path: final sum of the partial rows + solve + pose update in one launch
-__global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks, int quad,
-                                                    RegState* __restrict__ st, AlignParams ap,
-                                                    double* __restrict__ neq, double* __restrict__ loss_hist,
-                                                    float* __restrict__ dx_hist, int hist_cap,
-                                                    unsigned long long* __restrict__ box, unsigned gen,
-                                                    const unsigned* __restrict__ result_src, unsigned* __restrict__ result_dst,
-                                                    int result_words) {
+__device__ __forceinline__ void sum_solve_body(const double* __restrict__ partials, int nblocks, int quad,
+                                               RegState* __restrict__ st, AlignParams ap,
+                                               double* __restrict__ neq, double* __restrict__ loss_hist,
+                                               float* __restrict__ dx_hist, int hist_cap,
+                                               unsigned long long* __restrict__ box, unsigned gen,
+                                               const unsigned* __restrict__ result_src, unsigned* __restrict__ result_dst,
+                                               int result_words) {
     // result_dst (the last solving launch of an enqueued registration): the state allocation — RegState and histories, the
     // block icp_register_end reads — goes to the pinned result slot (mapped into the device) by this launch instead of a
     // copy launch of its own behind it
@@ -321,6 +321,39 @@ __global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ p
             __hip_atomic_store(result_dst + w, __hip_atomic_load(result_src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_solve(const double* __restrict__ partials, int nblocks, int quad,
+                                                    RegState* __restrict__ st, AlignParams ap,
+                                                    double* __restrict__ neq, double* __restrict__ loss_hist,
+                                                    float* __restrict__ dx_hist, int hist_cap,
+                                                    unsigned long long* __restrict__ box, unsigned gen,
+                                                    const unsigned* __restrict__ result_src, unsigned* __restrict__ result_dst,
+                                                    int result_words) {
+    sum_solve_body(partials, nblocks, quad, st, ap, neq, loss_hist, dx_hist, hist_cap, box, gen, result_src, result_dst,
+                   result_words);
+}
+
+// ... of B sequences in one launch (icp_batch_*, api.hip): workgroup b sums and solves sequence b from its descriptor
+struct SumSolveDesc {
+    const double* partials;
+    RegState* st;
+    AlignParams ap;
+    double* neq;
+    double* loss_hist;
+    float* dx_hist;
+    unsigned long long* box;
+    const unsigned* result_src;
+    unsigned* result_dst;
+    int nblocks, quad, hist_cap, result_words;
+    unsigned gen;
+    int pad[3];
+};
+
+__global__ __launch_bounds__(1024) void k_sum_solve_batch(const SumSolveDesc* __restrict__ table) {
+    const SumSolveDesc d = table[blockIdx.x];
+    sum_solve_body(d.partials, d.nblocks, d.quad, d.st, d.ap, d.neq, d.loss_hist, d.dx_hist, d.hist_cap, d.box, d.gen,
+                   d.result_src, d.result_dst, d.result_words);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -480,6 +513,44 @@ int launch_sum_solve(icp_ctx* ctx, int blocks, int quad, const double* partials,
     ICP_HIP(ctx, hipGetLastError());
     return ICP_OK;
 }
+
+// the batched form of launch_sum_solve (no exchange): member b's descriptor into table_host[b]
+int prepare_sum_solve_batch(icp_ctx* const* ctxs, int count, const int* rows, const int* quad, bool publish, bool last,
+                            void* table_host) {
+    SumSolveDesc* table = reinterpret_cast<SumSolveDesc*>(table_host);
+    for (int b = 0; b < count; ++b) {
+        icp_ctx* ctx = ctxs[b];
+        SumSolveDesc d{};
+        // the rows of the launch just prepared: the parity it has written (lead launches alternate; classic ones write parity 0)
+        d.partials = publish ? (const double*)(ctx->partials.as<char>() + (size_t)(ctx->partials_parity ^ 1) * ctx->partials_half)
+                             : ctx->partials.as<double>();
+        d.st = reg_state(ctx);
+        d.ap = make_align_params(ctx);
+        d.neq = ctx->neq;
+        d.loss_hist = ctx->loss_hist;
+        d.dx_hist = ctx->dx_hist;
+        d.hist_cap = ctx->hist_cap;
+        d.nblocks = rows[b];
+        d.quad = quad[b];
+        d.box = publish ? pose_box(ctx) : nullptr;
+        d.gen = publish ? next_box_generation(ctx) : 0u;
+        d.result_src = ctx->state.as<unsigned>();
+        d.result_dst = last ? reinterpret_cast<unsigned*>(ctx->result_fold_to) : nullptr;
+        d.result_words = d.result_dst ? (int)(ctx->result_fold_bytes / 4) : 0;
+        if (d.result_dst) ctx->result_folded = true;
+        table[b] = d;
+    }
+    return ICP_OK;
+}
+
+int launch_sum_solve_batch(icp_ctx* first, int count, const void* table_dev) {
+    hipLaunchKernelGGL(k_sum_solve_batch, dim3(count), dim3(1024), 0, first->stream,
+                       reinterpret_cast<const SumSolveDesc*>(table_dev));
+    ICP_HIP(first, hipGetLastError());
+    return ICP_OK;
+}
+
+size_t sum_solve_desc_bytes() { return sizeof(SumSolveDesc); }
 
 int launch_sum_partials(icp_ctx* ctx, int blocks, int quad) {
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, quad,

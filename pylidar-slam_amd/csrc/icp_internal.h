@@ -432,6 +432,7 @@ struct icp_ctx {
         void* host = nullptr;
         size_t bytes = 0;
         hipEvent_t event = nullptr;
+        hipEvent_t wait = nullptr;   // what icp_register_end waits for: `event`, or the one event of a batched registration
         bool stats = false;          // a grid-stats copy travels with this result
         int64_t stats_m = 0;
         float stats_h = 0.f;
@@ -545,6 +546,21 @@ int launch_sum_partials(icp_ctx* ctx, int rows, int quad = 1);
 // parity of ctx->partials)
 int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead = false, int prev_rows = 0, int prev_quad = 1,
                          int tail_iters = 0);  // tail_iters > 0: a resident tail over that many iterations (ask fused_tail_possible first)
+// ---- B sequences per launch (icp_batch_*): one fused iteration / one sum + solve of every member in ONE launch, the
+// members' arguments in descriptor tables (pinned host memory -> device memory, copied once per frame by the caller)
+struct BatchedIteration {
+    int count = 0, per_seq = 0, shape = 0;
+    int rows[ICP_BATCH_MAX_SEQUENCES] = {};
+    int quad[ICP_BATCH_MAX_SEQUENCES] = {};
+};
+size_t iterate_desc_bytes();
+size_t sum_solve_desc_bytes();
+int prepare_iterate_batch(icp_ctx* const* ctxs, int count, bool lead_mode, const int* prev_rows, const int* prev_quad,
+                          void* table_host, BatchedIteration* out);
+int launch_iterate_batch(icp_ctx* first, const BatchedIteration& it, const void* table_dev);
+int prepare_sum_solve_batch(icp_ctx* const* ctxs, int count, const int* rows, const int* quad, bool publish, bool last,
+                            void* table_host);
+int launch_sum_solve_batch(icp_ctx* first, int count, const void* table_dev);
 bool fused_tail_possible(icp_ctx* ctx, int prev_rows, int tail_iters);
 bool fused_tail_planned(icp_ctx* ctx, int iters);
 unsigned long long* pose_box(icp_ctx* ctx);   // device pointer of the mailbox (allocated by ensure_state)

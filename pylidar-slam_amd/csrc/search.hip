@@ -1229,6 +1229,20 @@ __device__ inline int logical_block(const IterInputs& in, int p, int off) {
            (sector << in.swz_bpr_shift) + (j & ((1 << in.swz_bpr_shift) - 1));
 }
 
+// One sequence's arguments of a fused iteration launch, as the batched launch reads them from device memory
+// (k_iterate_batch): exactly what k_iterate_compact takes by value.
+struct alignas(16) IterateDesc {
+    GridView g;
+    IterInputs in;
+    RegState* st;
+    AlignParams ap;
+    LeadArgs lead;
+    int blocks;  // workgroups of this sequence's share of the launch (its lead not counted)
+    int pad[3];
+};
+static constexpr int BATCH_LEAD_SLOTS = 32;  // lead workgroups at the head of a batched launch = the most sequences of a batch
+static_assert(BATCH_LEAD_SLOTS % 8 == 0 && BATCH_LEAD_SLOTS == ICP_BATCH_MAX_SEQUENCES, "XCD alignment of the work workgroups");
+
 // cache entry .x = cell-sorted position of the neighbour | iteration of the search << 24 (-1: no neighbour); a position
 // needs 24 bits (maps of up to 16.7 M points use the cache), iterations wrap into 7 bits — harmlessly: an entry older
 // than CACHE_HIST launches is a miss
@@ -1401,10 +1415,15 @@ __device__ inline bool lazy_cov_group(const GridView& g, int s, int sub, float* 
 __device__ inline void normal_from_cov(const float* __restrict__ cov, int s, float4* __restrict__ normals,
                                        int* __restrict__ nflag);
 
-template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false, int LAZY_KN = 0>
-__global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
-                                                                   RegState* __restrict__ st, AlignParams ap,
-                                                                   LeadArgs lead) {
+// The body of the launch, shared by the kernel with by-value arguments (one sequence: k_iterate_compact) and the kernel
+// that takes them from a descriptor table in device memory (B sequences per launch: k_iterate_batch).  `is_lead`: this
+// workgroup is the lead of its sequence (block-uniform); `pb` / `off`: its physical number among the workgroups of the
+// sequence and the number of lead workgroups in front of them (logical_block); `bx` / `gx`: blockIdx.x / gridDim.x of a
+// launch that holds ONE sequence (the resident tail, the dev stamps).
+template <int THREADS, int Q, bool STATS, bool TAIL, int LAZY_KN>
+__device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState* __restrict__ st, AlignParams ap,
+                                             LeadArgs lead, const bool is_lead, const int pb, const int off, const int bx,
+                                             const int gx) {
     if (!STATS) {  // (constant-folds every `if (g.dbg)` / `if (stamps)` below and inside the inlined searches)
         g.dbg = nullptr;
         g.stamps = nullptr;
@@ -1431,9 +1450,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // placed before it (a role ticket drawn from a counter would make that independent of the dispatch order — and costs
     // a thousand same-address device-scope atomics per launch, ~10 us: measured); should the order ever differ, the
     // wall-clock bound of the poll turns the wait into ICP_ERR_HIP instead of a hang.
-    const int lead_blocks = (lead.box && !TAIL) ? lead.solve : 0;
     if (lead.box) {
-        if ((int)blockIdx.x < lead_blocks) {  // block-uniform
+        if (is_lead) {  // block-uniform
             lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]),
                                 (g.stamps && in.iter < 24) ? g.stamps + 4 * ((size_t)in.iter * 1024 + 1023) : nullptr);
             return;
@@ -1442,7 +1460,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
         return;  // classic launch behind the end of the loop (block-uniform)
     }
     long long t_entry = g.stamps ? wall_clock64() : 0;
-    const int vb = logical_block(in, (int)blockIdx.x, lead_blocks);  // which queries, which partial row
+    const int vb = logical_block(in, pb, off);  // which queries, which partial row
     // which query a local slot stands for: the 128-query shape takes consecutive queries (one BASE row of the canonical sum,
     // solve_device.h); the 512-query shape takes FOUR base rows a quarter of the scan apart — base rows vb, vb + S, vb + 2S,
     // vb + 3S, exactly the four that form super-row vb — so a workgroup mixes four regions of the scan (the rings near the
@@ -1517,9 +1535,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
     if (dbg_global && threadIdx.x < 16) dbg_s[threadIdx.x] = 0;
     __syncthreads();
-    if (TAIL && blockIdx.x == 0) {  // (block-uniform) the lead: solve tj, published as generation gen_now, in front of its own share
+    if (TAIL && bx == 0) {  // (block-uniform) the lead: solve tj, published as generation gen_now, in front of its own share
         if (!tail_lead_step<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]), carry_s, tj, gen_now, in.tail_rows,
-                                     (int)gridDim.x,
+                                     gx,
                                      (g.stamps && iter_now < 24) ? g.stamps + 4 * ((size_t)iter_now * 1024 + 1023) : nullptr))
             return;
     }
@@ -1559,7 +1577,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     // dev-only phase timestamps ("search_stats"): 4 x wall_clock64 (100 MHz) per block and iteration behind the 16 path
     // counters
     long long* stamps = nullptr;
-    if (g.stamps && gridDim.x <= 1025 && vb < 1024 && iter_now < 24)
+    if (g.stamps && gx <= 1025 && vb < 1024 && iter_now < 24)
         stamps = g.stamps + 4 * ((size_t)iter_now * 1024 + vb);
     if (stamps && threadIdx.x == 0) stamps[0] = t_entry;
     // ---- phase A, second half: one lane per query
@@ -1879,10 +1897,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     }
     if (!TAIL) break;
     if (tj + 1 >= in.tail_iters) {  // behind the last iteration: the solve a k_sum_solve launch used to carry out
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             __syncthreads();
             tail_lead_step<THREADS>(lead, st, ap, reinterpret_cast<double*>(&cellstack[0][0]), carry_s, tj + 1, gen_now + 1u,
-                                    in.tail_rows, (int)gridDim.x,
+                                    in.tail_rows, gx,
                                     (g.stamps && iter_now + 1 < 24) ? g.stamps + 4 * ((size_t)(iter_now + 1) * 1024 + 1023) : nullptr);
         }
         break;
@@ -1893,6 +1911,64 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, I
     if (g.stamps) t_entry = wall_clock64();
     __syncthreads();  // (pose_s, ctl_s, rowbuf, part: read above, rewritten by the next trip)
     }
+}
+
+template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false, int LAZY_KN = 0>
+__global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
+                                                                   RegState* __restrict__ st, AlignParams ap,
+                                                                   LeadArgs lead) {
+    // In a lead launch (LeadArgs) workgroup 0 is the lead (the resident tail's lead is its workgroup 0 too, but takes its
+    // share of the queries as well: tail_lead_step inside the body)
+    const int lead_blocks = (lead.box && !TAIL) ? lead.solve : 0;
+    iterate_body<THREADS, Q, STATS, TAIL, LAZY_KN>(g, in, st, ap, lead, (int)blockIdx.x < lead_blocks, (int)blockIdx.x,
+                                                   lead_blocks, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// B sequences per launch ("a batched registration").  One sequence is a chain of dependent, latency-bound
+// launches: a late iteration streams 4.7 MB in ~3 us of work behind ~5 us of the lead's sum -> solve -> publish.  Here B
+// independent registrations (B contexts: B maps, B scans, B states) advance by one iteration in ONE launch: the arguments
+// of every sequence — the very structs the single launch takes by value — sit in a descriptor table in device memory
+// (IterateDesc[B], written by the host once per frame for all its launches), a workgroup finds its sequence from its number
+// and reads its descriptor with scalar loads.  Layout of the grid: LEAD_SLOTS lead workgroups first (lead b solves the
+// previous iteration of sequence b and publishes its pose; slots beyond B return at once: the region is a multiple of 8
+// so that the XCD of a work workgroup stays its number mod 8, logical_block), then per_seq workgroups per sequence,
+// sequence after sequence.  The hardware dispatches in ascending order: every lead is placed before any workgroup that
+// polls for it, B solves overlap, and the streaming of sequence b runs beside the solve of sequence b + 1.
+// Per sequence the body is the single launch's, same arguments, same order of every sum: the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T load_descriptor(const T* table, int index) {
+    // through the CONSTANT address space: the table is not written while the launch runs, so every word may be fetched by
+    // a scalar load wherever the body first needs it (and fetched again instead of being kept in registers)
+    static_assert(sizeof(T) % 4 == 0, "descriptor words");
+    typedef const int __attribute__((address_space(4))) * cwords;
+    cwords p = (cwords)(const void*)(table + index);
+    int w[sizeof(T) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = p[i];
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+
+template <int MINW, int THREADS, int Q>
+__global__ __launch_bounds__(THREADS, MINW) void k_iterate_batch(const IterateDesc* __restrict__ table, int nseq, int per_seq) {
+    const int p = (int)blockIdx.x;
+    int seq, pb;
+    bool is_lead = false;
+    if (p < BATCH_LEAD_SLOTS) {  // block-uniform
+        if (p >= nseq) return;
+        seq = p;
+        pb = 0;
+        is_lead = true;
+    } else {
+        seq = (p - BATCH_LEAD_SLOTS) / per_seq;
+        pb = (p - BATCH_LEAD_SLOTS) - seq * per_seq;
+    }
+    const IterateDesc d = load_descriptor(table, seq);
+    if (is_lead ? !(d.lead.box && d.lead.solve) : pb >= d.blocks) return;  // (no solve pending for this sequence / a shorter scan)
+    iterate_body<THREADS, Q, false, false, 0>(d.g, d.in, d.st, d.ap, d.lead, is_lead, pb, 0, pb, d.blocks);
 }
 
 // nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
@@ -3311,8 +3387,21 @@ bool fused_tail_planned(icp_ctx* ctx, int iters) {
     return blocks <= tail_capacity(ctx) && blocks <= ctx->resident_tail_max_blocks;
 }
 
-int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad,
-                         int tail_iters) {
+// what launch_iterate_fused has decided about the next fused launch of a context, before anything is launched: the
+// arguments, the grid and the instantiation.  prepare_iterate_fused updates the context's bookkeeping (iteration count,
+// parity, mailbox generation, cache state) as if the launch had happened: the caller launches — alone, or as one sequence
+// of a batched launch.
+enum FusedShape { SHAPE_LAZY11, SHAPE_LAZY6, SHAPE_TAIL, SHAPE_WIDE, SHAPE_NARROW, SHAPE_DENSE8, SHAPE_DENSE6 };
+struct FusedLaunch {
+    IterateDesc d;
+    int grid = 0;       // workgroups of the single launch (the lead included)
+    FusedShape shape = SHAPE_NARROW;
+    bool stats = false;
+    int rows = 0, quad = 1;
+    int iter = 0;       // (profiling: index of the iteration)
+};
+
+static int prepare_iterate_fused(icp_ctx* ctx, bool lead_mode, int prev_rows, int prev_quad, int tail_iters, FusedLaunch& fl) {
     const int n = (int)ctx->tgt_n;
     const int use_cache = fused_cache_mode(ctx);
     const bool narrow = next_fused_launch_is_narrow(ctx);
@@ -3327,7 +3416,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
         }
     }
     ICP_HIP(ctx, ctx->nn_cache.reserve((size_t)(n > 0 ? n : 1) * sizeof(int4)));
-    const int tok = prof_begin(ctx, 0, ctx->iter_in_registration);
+    fl.iter = ctx->iter_in_registration;
     IterInputs in;
     in.tgt = ctx->tgt4.as<float4>();
     in.normals = ctx->normals.as<float4>();
@@ -3424,47 +3513,129 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
     // dense cell alone); same super-rows, same bits
     const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search && !ctx->lazy_now;
     const int kn_lazy = ctx->lazy_now ? ctx->cfg.num_neighbors_normals + 1 : 0;
-    if (kn_lazy == 11)  // (normals on demand: the 512-query shape from the first iteration on, built for 256 registers)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 11>), dim3(grid), dim3(IT_THREADS), 0,
-                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (kn_lazy == 6)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 6>), dim3(grid), dim3(IT_THREADS), 0,
-                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (tail && ctx->search_stats)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, true, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (tail)
-        hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (wide && ctx->search_stats)  // (dev: the instrumented instantiations exist for the two default shapes only)
-        hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, true>), dim3(grid), dim3(2 * IT_THREADS), 0,
-                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (narrow && ctx->search_stats)
-        hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS, true>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (wide)
-        hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS>), dim3(grid), dim3(2 * IT_THREADS), 0,
-                           ctx->stream, make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (narrow)
-        hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else if (ctx->iterate_dense)
-        hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    else
-        hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), dim3(grid), dim3(IT_THREADS), 0, ctx->stream,
-                           make_view(ctx), in, reg_state(ctx), make_align_params(ctx), lead);
-    prof_end(ctx, tok);
-    ICP_HIP(ctx, hipGetLastError());
+    fl.shape = kn_lazy == 11 ? SHAPE_LAZY11  // (normals on demand: the 512-query shape from the first iteration on, built for 256 registers)
+               : kn_lazy == 6 ? SHAPE_LAZY6
+               : tail         ? SHAPE_TAIL
+               : wide         ? SHAPE_WIDE
+               : narrow       ? SHAPE_NARROW
+               : ctx->iterate_dense ? SHAPE_DENSE8 : SHAPE_DENSE6;
+    fl.stats = ctx->search_stats != 0;  // (dev: the instrumented instantiations exist for the tail and the two default shapes only)
+    fl.d.g = make_view(ctx);
+    fl.d.in = in;
+    fl.d.st = reg_state(ctx);
+    fl.d.ap = make_align_params(ctx);
+    fl.d.lead = lead;
+    fl.d.blocks = blocks;
+    fl.d.pad[0] = fl.d.pad[1] = fl.d.pad[2] = 0;
+    fl.grid = grid;
+    fl.rows = blocks;
+    fl.quad = narrow ? 0 : 1;  // base rows (summed four by four first) or super-rows already
     ctx->iter_in_registration += tail ? tail_iters : 1;
     ctx->cache_fresh = true;
     ctx->cache_n = n;  // nn_cache now describes these targets against the current grid
     ctx->cache_m = ctx->map_m;
     ctx->cache_gen = ctx->grid_gen;
-    *rows_out = blocks;
-    *quad_out = narrow ? 0 : 1;  // base rows (summed four by four first) or super-rows already
     return ICP_OK;
 }
+
+int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_mode, int prev_rows, int prev_quad,
+                         int tail_iters) {
+    FusedLaunch fl;
+    const int rc = prepare_iterate_fused(ctx, lead_mode, prev_rows, prev_quad, tail_iters, fl);
+    if (rc) return rc;
+    const IterateDesc& d = fl.d;
+    const dim3 grid(fl.grid);
+    const int tok = prof_begin(ctx, 0, fl.iter);
+    switch (fl.shape) {
+        case SHAPE_LAZY11:
+            hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 11>), grid, dim3(IT_THREADS), 0,
+                               ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_LAZY6:
+            hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, false, 6>), grid, dim3(IT_THREADS), 0,
+                               ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_TAIL:
+            if (fl.stats)
+                hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, true, true>), grid, dim3(IT_THREADS), 0,
+                                   ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            else
+                hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, true>), grid, dim3(IT_THREADS), 0,
+                                   ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_WIDE:
+            if (fl.stats)
+                hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, true>), grid, dim3(2 * IT_THREADS), 0,
+                                   ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            else
+                hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS>), grid, dim3(2 * IT_THREADS), 0,
+                                   ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_NARROW:
+            if (fl.stats)
+                hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS, true>), grid, dim3(IT_THREADS), 0, ctx->stream,
+                                   d.g, d.in, d.st, d.ap, d.lead);
+            else
+                hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), grid, dim3(IT_THREADS), 0, ctx->stream,
+                                   d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_DENSE8:
+            hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), grid, dim3(IT_THREADS), 0, ctx->stream,
+                               d.g, d.in, d.st, d.ap, d.lead);
+            break;
+        case SHAPE_DENSE6:
+            hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), grid, dim3(IT_THREADS), 0, ctx->stream,
+                               d.g, d.in, d.st, d.ap, d.lead);
+            break;
+    }
+    prof_end(ctx, tok);
+    ICP_HIP(ctx, hipGetLastError());
+    *rows_out = fl.rows;
+    *quad_out = fl.quad;
+    return ICP_OK;
+}
+
+// ---- the batched launch: one fused iteration of every member's registration (api.hip: icp_batch_*) ---------------------
+// `table_host` / `table_dev`: room for `count` descriptors (pinned host memory the caller copies to the device in front of
+// the launches of the frame; the launch reads table_dev).  All members must come out with the same instantiation (same
+// options, same iteration index): anything else is refused — the caller then falls back to one launch per member.
+int prepare_iterate_batch(icp_ctx* const* ctxs, int count, bool lead_mode, const int* prev_rows, const int* prev_quad,
+                          void* table_host, BatchedIteration* out) {
+    IterateDesc* table = reinterpret_cast<IterateDesc*>(table_host);
+    int per_seq = 0;
+    for (int b = 0; b < count; ++b) {
+        FusedLaunch fl;
+        const int rc = prepare_iterate_fused(ctxs[b], lead_mode, prev_rows[b], prev_quad[b], 0, fl);
+        if (rc) return rc;
+        if (fl.stats || (fl.shape != SHAPE_WIDE && fl.shape != SHAPE_NARROW) || (b > 0 && (int)fl.shape != out->shape)) {
+            ctxs[b]->error = "batched registration: the members must run the same fused shape (narrow / wide; same options)";
+            return ICP_ERR_INVALID_ARGUMENT;
+        }
+        out->shape = (int)fl.shape;
+        out->rows[b] = fl.rows;
+        out->quad[b] = fl.quad;
+        table[b] = fl.d;
+        if (fl.d.blocks > per_seq) per_seq = fl.d.blocks;
+    }
+    out->per_seq = per_seq;
+    out->count = count;
+    return ICP_OK;
+}
+
+int launch_iterate_batch(icp_ctx* first, const BatchedIteration& it, const void* table_dev) {
+    const IterateDesc* table = reinterpret_cast<const IterateDesc*>(table_dev);
+    const dim3 grid((unsigned)(BATCH_LEAD_SLOTS + it.count * it.per_seq));
+    if (it.shape == (int)SHAPE_WIDE)
+        hipLaunchKernelGGL((k_iterate_batch<4, 2 * IT_THREADS, IT_THREADS>), grid, dim3(2 * IT_THREADS), 0, first->stream, table,
+                           it.count, it.per_seq);
+    else
+        hipLaunchKernelGGL((k_iterate_batch<4, IT_THREADS, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table,
+                           it.count, it.per_seq);
+    ICP_HIP(first, hipGetLastError());
+    return ICP_OK;
+}
+
+size_t iterate_desc_bytes() { return sizeof(IterateDesc); }
 
 // Called by the grid build before it overwrites the cell-sorted points: the neighbours the last registration left in
 // nn_cache become the seeds of the next frame's first iteration.  `evicted` = oldest map points about to be dropped.

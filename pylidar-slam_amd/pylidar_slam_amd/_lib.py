@@ -24,6 +24,7 @@ ICP_ERR_INVALID_JACOBIAN = -3
 ICP_ERR_EMPTY_MAP = -4
 ICP_ERR_NO_DEVICE = -5
 ICP_ERR_EXCHANGE = -6
+BATCH_MAX_SEQUENCES = 32  # ICP_BATCH_MAX_SEQUENCES
 
 STATUS_MESSAGES = {
     ICP_ERR_INVALID_ARGUMENT: "invalid argument",
@@ -119,6 +120,13 @@ EXPORTED_SYMBOLS = {
     "icp_iteration_accumulate": (_INT, [_P]),
     "icp_iteration_solve": (_INT, [_P]),
     "icp_register_end": (_INT, [_P, C.POINTER(IcpRegisterResult), _P, _P]),
+    "icp_batch_create": (_INT, [_P, C.c_int32, C.POINTER(_P)]),
+    "icp_batch_destroy": (None, [_P]),
+    "icp_batch_last_error": (C.c_char_p, [_P]),
+    "icp_batch_set_stream": (_INT, [_P, _P]),
+    "icp_batch_register_launch": (_INT, [_P, _P, _P, _INT, _INT, _P, _INT]),
+    "icp_batch_map_update": (_INT, [_P]),
+    "icp_batch_register_end": (_INT, [_P, _P, _P, _P]),
     "icp_normal_equations_ptr": (_P, [_P]),
     "icp_set_normal_equations_buffer": (_INT, [_P, _P]),
     "icp_profile_enable": (_INT, [_P, _INT]),

@@ -703,6 +703,10 @@ class IcpContext:
         self._check(self._lib.icp_register_end(self._h, C.byref(res), losses, dxs))
         return self._result(res, losses, dxs)
 
+    def raise_for_status(self, rc: int):
+        """Maps a status code of the C ABI to the exception the reference raises (public form of the internal check)."""
+        self._check(rc)
+
     # ---- profiling ---------------------------------------------------------------------------------------------------
     def profile_enable(self, mask: int = 1):
         """bit mask of the kernels timed with HIP events: 1 search, 2 reduction, 4 normals (0 = off)."""
@@ -726,3 +730,121 @@ class IcpContext:
         v = C.c_double(0)
         self._check(self._lib.icp_profile_event_floor(self._h, int(samples), C.byref(v)))
         return float(v.value)
+
+
+class IcpBatch:
+    """B independent sequences advanced by ONE launch per ICP iteration (`icp_batch_*`, include/icp_mi355x.h): B
+    `IcpContext`s of one device — each with its own local map, scan and registration state, i.e. B instances of the
+    reference's `ICPFrameToModel` (slam/odometry/icp_odometry.py:248-299 registers one sequence, one frame at a time) —
+    whose registrations are enqueued together by one host thread.  Per sequence the same poses, bit for bit, as
+    `IcpContext.register_launch` / `map_update(None)` / `register_end` on that context alone."""
+
+    def __init__(self, contexts):
+        self.contexts = list(contexts)
+        if not self.contexts:
+            raise AssertionError("a batch needs at least one context")
+        self._lib = self.contexts[0]._lib
+        arr = (C.c_void_p * len(self.contexts))(*[c._h for c in self.contexts])
+        handle = C.c_void_p()
+        rc = self._lib.icp_batch_create(arr, len(self.contexts), C.byref(handle))
+        if rc != 0:
+            raise AssertionError(f"icp_batch_create failed ({STATUS_MESSAGES.get(rc, rc)}): 1..{_lib.BATCH_MAX_SEQUENCES} distinct "
+                                 "contexts of one device")
+        self._h = handle
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icp_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        msg = self._lib.icp_batch_last_error(self._h).decode() or STATUS_MESSAGES.get(rc, str(rc))
+        if rc == _lib.ICP_ERR_INVALID_JACOBIAN:
+            raise InvalidJacobianError("Invalid Jacobian in Gauss Newton minimization")
+        if rc == _lib.ICP_ERR_INVALID_ARGUMENT:
+            raise AssertionError(msg)
+        raise RuntimeError(f"libicp_mi355x: {msg} ({rc})")
+
+    def use_torch_stream(self):
+        """Every member enqueues on torch's current stream of the batch's device."""
+        c0 = self.contexts[0]
+        stream = _RAW_STREAM(c0._device_index) if _RAW_STREAM is not None else \
+            torch.cuda.current_stream(c0.device).cuda_stream
+        if stream != getattr(self, "_bound_stream", None) or any(getattr(c, "_bound_stream", None) != stream
+                                                                 for c in self.contexts):
+            self._check(self._lib.icp_batch_set_stream(self._h, C.c_void_p(stream)))
+            self._bound_stream = stream
+            for c in self.contexts:
+                c._bound_stream = stream
+
+    def register_launch(self, scans, init_poses=None, skip_null: bool = False):
+        """`scans[b]`: member b's scan ([n_b, 3] float32; all cuda tensors or all host arrays).  `init_poses`: a list of
+        4x4 matrices (None entries: identity), None (identity for all) or "last" (every member starts from the device-resident
+        pose of its previous registration: constant-velocity initialisation without a host round trip)."""
+        if len(scans) != len(self.contexts):
+            raise AssertionError(f"expected {len(self.contexts)} scans, got {len(scans)}")
+        if _on_device(*scans):
+            self.use_torch_stream()
+        ptrs, ns, keep, mems = [], [], [], set()
+        for a in scans:
+            p, mem, k = _ptr_mem(a)
+            ptrs.append(p)
+            ns.append(int(k.shape[0]))
+            keep.append(k)
+            mems.add(mem)
+        if len(mems) != 1:
+            raise AssertionError("the scans of a batch must live in one memory space")
+        mem = mems.pop()
+        self._keep = (getattr(self, "_keep", None) or [])[-1:] + [keep]
+        xyz = (C.c_void_p * len(ptrs))(*ptrs)
+        n = (C.c_int64 * len(ns))(*ns)
+        mode = TARGETS_SKIP_NULL if skip_null else TARGETS_ALL
+        if isinstance(init_poses, str):
+            if init_poses != "last":
+                raise AssertionError(f"unknown initial pose {init_poses!r}")
+            self._check(self._lib.icp_batch_register_launch(self._h, xyz, n, mem, mode, None, 1))
+            return
+        init = None
+        if init_poses is not None:
+            flat = np.stack([np.asarray(m if m is not None else np.eye(4), dtype=np.float32).reshape(16)
+                             for m in init_poses])
+            if flat.shape[0] != len(self.contexts):
+                raise AssertionError("one initial pose per member")
+            init = np.ascontiguousarray(flat)
+        self._check(self._lib.icp_batch_register_launch(self._h, xyz, n, mem, mode,
+                                                        init.ctypes.data if init is not None else None, 0))
+
+    def map_update(self):
+        """`map_update(None)` on every member: the pose-only update by the device-resident pose of its registration."""
+        self._check(self._lib.icp_batch_map_update(self._h))
+
+    def register_end(self):
+        """One wait for all members; a list of `RegisterResult`s (raises what the first failing member would raise)."""
+        b = len(self.contexts)
+        cap = max(1, int(self.contexts[0].config.max_num_alignments))
+        res = (IcpRegisterResult * b)()
+        losses = (C.c_double * (cap * b))()
+        dxs = (C.c_float * (6 * cap * b))()
+        rc = self._lib.icp_batch_register_end(self._h, res, losses, dxs)
+        self._check(rc)
+        la = np.array(losses, np.float64).reshape(b, cap)
+        da = np.array(dxs, np.float32).reshape(b, cap, 6)
+        out = []
+        for i in range(b):
+            k = int(res[i].iterations)
+            out.append(RegisterResult(np.array(res[i].pose, np.float32).reshape(4, 4), np.array(res[i].params, np.float32), k,
+                                      bool(res[i].converged), int(res[i].num_targets), int(res[i].normals_computed),
+                                      la[i, :k].copy(), da[i, :k].copy()))
+        return out
