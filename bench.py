@@ -441,12 +441,9 @@ def batched_leg(args, device_index, workloads, sizes=(4, 8, 16), steps=200, warm
 
         def run(k):
             for _ in range(k):
-                scans, frames = [], []
-                for t in trs:
-                    f = t.order[t.cursor % len(t.order)]
-                    t.ctx.project(t.scans[f], out=t.vmap)
-                    scans.append(t.scans[f])
-                    frames.append(f)
+                frames = [t.order[t.cursor % len(t.order)] for t in trs]
+                scans = [t.scans[f] for t, f in zip(trs, frames)]
+                batch.project(scans, [t.vmap for t in trs])
                 batch.register_launch(scans, [t.last for t in trs] if args.init == "cv" else None)
                 batch.map_update()
                 for t, f, r in zip(trs, frames, batch.register_end()):

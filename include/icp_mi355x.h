@@ -109,6 +109,15 @@ int icp_synchronize(icp_ctx* ctx);
 /* MI355X-side tuning options by name (no reference counterpart; none of them changes a result, only the schedule — with ONE
  * exception, "carry_normals", which changes results by float32 rounding and says so):
  *   "nn_cache" 0 | 1 | 2 (2)        exact nearest-neighbour cache across ICP iterations (2: a missed entry seeds the search)
+ *   "hit_records" 0 | 1 (0)         the first cache hit behind a search leaves a record — the winner's point, its normal and a
+ *                                   bound on every OTHER map point — from which later iterations decide the hit with 48 coalesced
+ *                                   bytes and no gather (the entry's candidate set only where the record does not certify);
+ *                                   measured slower than the speculative gathers it replaces: off by default
+ *   "late_from" n (-1: never)       fused launches from ICP iteration n on run the LATE kernel: the same iteration built for
+ *                                   launches the hit records settle (64 registers, 33 KB of LDS: four workgroups per CU instead
+ *                                   of two; the few queries left are searched by a wave each); needs "hit_records"; same bits;
+ *                                   off by default: a frame whose queries still miss in those launches pays 20x
+ *   "late_waves" 8 | 6 (8)          ... its build: 64 registers (four workgroups per CU) or 80 (three)
  *   "fuse_iteration" 0 | 1 (1)      search + rows + partial sums in one kernel when every normal is ready
  *   "iterate_dense" 0 | 1 (1)       64-register build of that kernel (the whole scan resident in one round of workgroups)
  *   "wave_misses" n (48)            workgroups with up to n cache misses search each of them with a whole wave
@@ -439,8 +448,12 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
  *                              scan.  Every iteration is enqueued (no chunking: a member whose loop has ended costs
  *                              nothing on the device).  Point-to-plane registrations on the fused path only (eager
  *                              normals, no exchange, no profiling): ICP_ERR_INVALID_ARGUMENT otherwise;
+ *   icp_batch_project          icp_project for every member in two launches: xyz[b] [n[b],3] -> vmap_out[b] [3,H,W] of member b
+ *                              (Projector.build_projection_map, slam/common/projection.py:331-418, as ICPFrameToModel._read_input
+ *                              calls it per frame, icp_odometry.py:333); DEVICE pointers only;
  *   icp_batch_map_update       icp_map_update(member, NULL, NULL, ...) for every member: the pose-only update by the
- *                              device-resident pose of the registration just launched (icp_odometry.py:379);
+ *                              device-resident pose of the registration just launched (icp_odometry.py:379) — the B grid
+ *                              rebuilds in four launches;
  *   icp_batch_register_end     icp_register_end for every member (results[b]; loss_per_iter_out / dx_per_iter_out:
  *                              count x max_num_alignments (x 6) entries or NULL): ONE wait for all of them.  Returns the
  *                              first member's non-zero status, every member's own in results[b].status. */
@@ -452,6 +465,7 @@ const char* icp_batch_last_error(const icp_batch* batch);
 int icp_batch_set_stream(icp_batch* batch, void* hip_stream);
 int icp_batch_register_launch(icp_batch* batch, const float* const* xyz, const int64_t* n, int mem, int target_mode,
                               const float* init_poses, int from_last);
+int icp_batch_project(icp_batch* batch, const float* const* xyz, const int64_t* n, float* const* vmap_out);
 int icp_batch_map_update(icp_batch* batch);
 int icp_batch_register_end(icp_batch* batch, icp_register_result* results, double* loss_per_iter_out,
                            float* dx_per_iter_out);

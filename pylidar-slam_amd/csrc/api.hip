@@ -269,9 +269,11 @@ static Pose16 pose_or_identity(const float* init_pose) {
 }
 
 // targets packed and the state initialised by one launch (a launch of its own only when there are no targets)
-static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_pose, bool keep_pose = false) {
+static int prepare_targets_and_state(icp_ctx* ctx, int64_t n, const float* init_pose, bool keep_pose = false,
+                                     PackDesc* defer = nullptr) {
     const Pose16 p = pose_or_identity(init_pose);
-    if (n > 0) return prepare_targets(ctx, ctx->tgt_ptr, n, &p, keep_pose);
+    if (defer) memset(defer, 0, sizeof(*defer));
+    if (n > 0) return prepare_targets(ctx, ctx->tgt_ptr, n, &p, keep_pose, defer);
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, reg_state(ctx), p, keep_pose ? 1 : 0,
                        pose_box(ctx), next_box_generation(ctx), ctx->pose_hist);
     ICP_HIP(ctx, hipGetLastError());
@@ -363,7 +365,7 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
-                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows, &ctx->normals_tail};
+                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows, &ctx->normals_tail, &ctx->nn_rec};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -420,6 +422,9 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     const std::string k(name);
     const int iv = (int)value;
     if (k == "nn_cache") ctx->use_nn_cache = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
+    else if (k == "hit_records") ctx->hit_records = iv != 0 ? 1 : 0;
+    else if (k == "late_from") ctx->late_from = iv < 0 ? -1 : (int)iv;
+    else if (k == "late_waves") ctx->late_waves = iv >= 8 ? 8 : 6;
     else if (k == "fuse_iteration") ctx->fuse_iteration = iv != 0;
     else if (k == "iterate_dense") ctx->iterate_dense = iv != 0;
     else if (k == "narrow_from") ctx->narrow_from = (int)iv;
@@ -773,7 +778,8 @@ int icp_map_set(icp_ctx* ctx, const float* xyz, int64_t m, int mem) {
 // `known_count` >= 0: `new_dev` holds exactly that many valid rows, already in order (a staged cloud) — copied, not compacted,
 // and nothing is read back
 static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
-                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count);
+                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count,
+                           GridBuildDesc* defer = nullptr);
 
 // The update on the context's MAP STREAM where nothing it does needs the context's scratch buffers (a pose-only update, or
 // a cloud whose valid rows have been compacted and counted already: the staged insertion): ordered behind everything the
@@ -804,8 +810,18 @@ static int map_update_impl(icp_ctx* ctx, const float rel_pose[16], const float* 
     return rc;
 }
 
+// defer: the launches of the grid build are left to the caller (*defer receives their arguments: icp_batch_map_update runs them
+// for B maps at once), and so is what follows them — build_grid_finish and the eager normals (map_update_finish)
+static int map_update_finish(icp_ctx* ctx) {
+    // the next registration will want every normal at once (same rule as register_begin, with the size of the scan just
+    // registered standing in for the next one): estimate them NOW, behind the rebuild, so that the GPU works through the
+    // caller's preparation of the next frame (host staging, upload) instead of starting on them when that frame arrives
+    if (ctx->have_device_pose && ctx->tgt_n > 0 && wants_eager_normals(ctx, ctx->tgt_n)) return launch_normals_all(ctx, true);
+    return ICP_OK;
+}
+
 static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* new_dev, const int* flags_dev,
-                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count) {
+                           int64_t n, bool has_cloud, int64_t* inserted_out, int64_t known_count, GridBuildDesc* defer) {
     int rc = ICP_OK;
     ctx->move_job = MapMoveJob();  // (a job left behind by an update that failed half-way)
     ctx->order_job = false;
@@ -888,12 +904,9 @@ static int map_update_body(icp_ctx* ctx, const float rel_pose[16], const float* 
     }
     if (inserted_out) *inserted_out = inserted;
     if ((rc = stash_frame_seeds(ctx, evicted, true))) return rc;  // kept points keep their order: index - evicted
-    if ((rc = build_grid(ctx))) return rc;
-    // the next registration will want every normal at once (same rule as register_begin, with the size of the scan just
-    // registered standing in for the next one): estimate them NOW, behind the rebuild, so that the GPU works through the
-    // caller's preparation of the next frame (host staging, upload) instead of starting on them when that frame arrives
-    if (ctx->have_device_pose && ctx->tgt_n > 0 && wants_eager_normals(ctx, ctx->tgt_n)) rc = launch_normals_all(ctx, true);
-    return rc;
+    if (defer) memset(defer, 0, sizeof(*defer));  // (an empty map builds nothing: a descriptor of zero workgroups)
+    if ((rc = build_grid(ctx, defer))) return rc;
+    return defer ? ICP_OK : map_update_finish(ctx);
 }
 
 int icp_map_update(icp_ctx* ctx, const float rel_pose[16], const float* new_xyz, int64_t n, int mem, int row_mode,
@@ -1439,8 +1452,10 @@ int icp_weighted_procrustes(icp_ctx* ctx, const float* tgt_points, const float* 
 }
 
 // ---- registration ---------------------------------------------------------------------------------------------------
+// defer_pack: the launch that packs the targets and initialises the state is left to the caller (a batched registration runs
+// it for all its members at once)
 static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, int target_mode,
-                          const float init_pose[16], bool from_last) {
+                          const float init_pose[16], bool from_last, PackDesc* defer_pack = nullptr) {
     if (!ctx || n < 0 || (n > 0 && !xyz)) return ICP_ERR_INVALID_ARGUMENT;
     if (ctx->map_m <= 0 || !ctx->grid_valid) return fail(ctx, ICP_ERR_EMPTY_MAP, "the local map is empty");
     if (ctx->in_registration) return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "registration in progress");
@@ -1454,7 +1469,7 @@ static int register_begin(icp_ctx* ctx, const float* xyz, int64_t n, int mem, in
     ctx->tgt_n = n;
     ctx->tgt_mode = target_mode;
     ICP_HIP(ctx, ctx->nn_pos.reserve((size_t)(n > 0 ? n : 1) * 4));
-    if ((rc = prepare_targets_and_state(ctx, n, init_pose, from_last))) return rc;
+    if ((rc = prepare_targets_and_state(ctx, n, init_pose, from_last, defer_pack))) return rc;
     ctx->have_device_pose = true;
     // event pairs around the kernels of every `every`-th registration only: a pair costs ~2 us of stream time
     ctx->prof.sample_now = ctx->prof.every <= 1 || (ctx->prof.registrations % ctx->prof.every) == 0;
@@ -1964,6 +1979,11 @@ struct icp_batch {
     hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr};  // the slot's copy has left the pinned buffer
     hipEvent_t done[2] = {nullptr, nullptr};                  // ONE event behind the results of a batched registration
     int slot = 0, done_next = 0;
+    // ... and of the batched grid build behind a map update: [count] GridBuildDesc per slot
+    GridBuildDesc* grid_host[SLOTS] = {nullptr, nullptr, nullptr};
+    DeviceBuffer grid_dev[SLOTS];
+    hipEvent_t grid_copied[SLOTS] = {nullptr, nullptr, nullptr};
+    int grid_slot = 0;
 };
 
 static int batch_fail(icp_batch* b, int code, const std::string& msg) {
@@ -1997,6 +2017,9 @@ void icp_batch_destroy(icp_batch* b) {
         if (b->host[k]) (void)hipHostFree(b->host[k]);
         b->dev[k].release();
         if (b->copied[k]) (void)hipEventDestroy(b->copied[k]);
+        if (b->grid_host[k]) (void)hipHostFree(b->grid_host[k]);
+        b->grid_dev[k].release();
+        if (b->grid_copied[k]) (void)hipEventDestroy(b->grid_copied[k]);
     }
     for (auto& e : b->done)
         if (e) (void)hipEventDestroy(e);
@@ -2048,11 +2071,12 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
         }
     } unwind{b};
     int rc = ICP_OK;
+    PackDesc packs[ICP_BATCH_MAX_SEQUENCES];
     for (int i = 0; i < count; ++i) {
         icp_ctx* ctx = ctxs[i];
         if ((rc = continue_launch(ctx, -1))) return batch_fail(b, rc, ctx->error);  // (an older chunked launch of this member goes first)
         if ((rc = register_begin(ctx, xyz[i], n[i], mem, target_mode, (init_poses && !from_last) ? init_poses + 16 * i : nullptr,
-                                 from_last != 0)))
+                                 from_last != 0, &packs[i])))
             return batch_fail(b, rc, ctx->error);
         if (!fused_path(ctx) || ctx->lazy_now)
             return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched registration: the fused iteration path with eagerly estimated "
@@ -2073,7 +2097,8 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
     const int slot = b->slot;
     b->slot = (slot + 1) % icp_batch::SLOTS;
     const size_t it_bytes = iterate_desc_bytes() * (size_t)count, ss_bytes = sum_solve_desc_bytes() * (size_t)count;
-    const size_t need = (size_t)iters * (it_bytes + ss_bytes);
+    const size_t pack_bytes = ((sizeof(PackDesc) * (size_t)count + 255) / 256) * 256;  // the packing launch's table leads the slot
+    const size_t need = pack_bytes + (size_t)iters * (it_bytes + ss_bytes);
     if (b->host_bytes[slot] < need) {
         if (b->copied[slot]) ICP_HIP(first, hipEventSynchronize(b->copied[slot]));
         if (b->host[slot]) (void)hipHostFree(b->host[slot]);
@@ -2094,7 +2119,8 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
     };
     std::vector<Op> ops;
     ops.reserve(2 * (size_t)iters);
-    size_t used = 0;
+    memcpy(b->host[slot], packs, sizeof(PackDesc) * (size_t)count);
+    size_t used = pack_bytes;
     int prev_rows[ICP_BATCH_MAX_SEQUENCES] = {}, prev_quad[ICP_BATCH_MAX_SEQUENCES];
     for (int i = 0; i < count; ++i) prev_quad[i] = 1;
     for (int it = 0; it < iters; ++it) {
@@ -2126,6 +2152,7 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
     // ---- one copy, then the launches
     ICP_HIP(first, hipMemcpyAsync(b->dev[slot].ptr, b->host[slot], used, hipMemcpyHostToDevice, first->stream));
     ICP_HIP(first, hipEventRecord(b->copied[slot], first->stream));
+    if ((rc = launch_pack_targets_batch(first, packs, b->dev[slot].as<PackDesc>(), count))) return batch_fail(b, rc, first->error);
     for (const Op& op : ops) {
         const char* table = b->dev[slot].as<char>() + op.offset;
         rc = op.kind == 0 ? launch_iterate_batch(first, op.it, table) : launch_sum_solve_batch(first, count, table);
@@ -2149,11 +2176,65 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
     return ICP_OK;
 }
 
+int icp_batch_project(icp_batch* b, const float* const* xyz, const int64_t* n, float* const* vmap_out) {
+    if (!b || !xyz || !n || !vmap_out) return ICP_ERR_INVALID_ARGUMENT;
+    DeviceGuard device_guard(b->device);
+    const int count = (int)b->members.size();
+    for (int i = 0; i < count; ++i)
+        if (n[i] < 0 || (n[i] > 0 && !xyz[i]) || !vmap_out[i] || b->members[i]->stream != b->members[0]->stream)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "batched projection: device pointers, one stream (icp_batch_set_stream)");
+    const int rc = project_batch_device(b->members.data(), count, xyz, n, vmap_out);
+    if (rc) return batch_fail(b, rc, b->members[0]->error);
+    return ICP_OK;
+}
+
 int icp_batch_map_update(icp_batch* b) {
     if (!b) return ICP_ERR_INVALID_ARGUMENT;
+    DeviceGuard device_guard(b->device);
+    const int count = (int)b->members.size();
+    icp_ctx* first = b->members[0];
+    bool one_stream = true;
     for (icp_ctx* ctx : b->members) {
-        const int rc = icp_map_update(ctx, nullptr, nullptr, 0, ICP_MEM_DEVICE, ICP_TARGETS_ALL, nullptr);
-        if (rc) return batch_fail(b, rc, ctx->error);
+        { DeviceGuard join_map_stream(ctx); }
+        one_stream = one_stream && ctx->stream == first->stream;
+        if (!ctx->have_device_pose)
+            return batch_fail(b, ICP_ERR_INVALID_ARGUMENT, "rel_pose = NULL needs a previous registration on every member");
+    }
+    if (!one_stream || count == 1) {  // members on streams of their own: one update each, as icp_map_update
+        for (icp_ctx* ctx : b->members) {
+            const int rc = icp_map_update(ctx, nullptr, nullptr, 0, ICP_MEM_DEVICE, ICP_TARGETS_ALL, nullptr);
+            if (rc) return batch_fail(b, rc, ctx->error);
+        }
+        return ICP_OK;
+    }
+    // the host bookkeeping of every member's update (window, jobs of the rebuild, buffers), the launches of the grid builds
+    // left out: their arguments travel to the device in one table, four launches build the B grids
+    const int slot = b->grid_slot;
+    b->grid_slot = (slot + 1) % icp_batch::SLOTS;
+    if (!b->grid_host[slot]) {
+        ICP_HIP(first, hipHostMalloc((void**)&b->grid_host[slot], sizeof(GridBuildDesc) * ICP_BATCH_MAX_SEQUENCES, hipHostMallocDefault));
+        ICP_HIP(first, b->grid_dev[slot].reserve(sizeof(GridBuildDesc) * ICP_BATCH_MAX_SEQUENCES));
+        ICP_HIP(first, hipEventCreateWithFlags(&b->grid_copied[slot], hipEventDisableTiming));
+    } else {
+        ICP_HIP(first, hipEventSynchronize(b->grid_copied[slot]));  // (three updates ago)
+    }
+    GridBuildDesc* table = b->grid_host[slot];
+    int rc = ICP_OK;
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = b->members[i];
+        if ((rc = continue_launch(ctx, -1))) return batch_fail(b, rc, ctx->error);
+        if ((rc = ensure_state(ctx))) return batch_fail(b, rc, ctx->error);
+        if ((rc = map_update_body(ctx, nullptr, nullptr, nullptr, 0, false, nullptr, -1, &table[i])))
+            return batch_fail(b, rc, ctx->error);
+    }
+    ICP_HIP(first, hipMemcpyAsync(b->grid_dev[slot].ptr, table, sizeof(GridBuildDesc) * (size_t)count, hipMemcpyHostToDevice,
+                                  first->stream));
+    ICP_HIP(first, hipEventRecord(b->grid_copied[slot], first->stream));
+    if ((rc = launch_grid_build_batch(first, table, b->grid_dev[slot].as<GridBuildDesc>(), count)))
+        return batch_fail(b, rc, first->error);
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = b->members[i];
+        if ((rc = build_grid_finish(ctx, table[i])) || (rc = map_update_finish(ctx))) return batch_fail(b, rc, ctx->error);
     }
     return ICP_OK;
 }

@@ -829,16 +829,46 @@ __global__ void k_pack_targets(const float* __restrict__ xyz, int n, float4* __r
     out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init, bool keep_pose) {
+// ... for B registrations in one launch (icp_batch_register_launch): blockIdx.y = the member, its arguments in a table in
+// device memory
+__global__ void k_pack_targets_batch(const PackDesc* __restrict__ table) {
+    const PackDesc& d = table[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.st && i < 64) state_init_wave(d.st, d.init.m, d.keep_pose, d.box, d.gen, d.hist, i);
+    if (i >= d.n) return;
+    d.out[i] = make_float4(d.xyz[3 * i], d.xyz[3 * i + 1], d.xyz[3 * i + 2], __int_as_float(i));
+}
+
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init, bool keep_pose, PackDesc* defer) {
     ICP_HIP(ctx, ctx->tgt4.reserve((size_t)(n > 0 ? n : 1) * sizeof(float4)));
     if (n <= 0) return ICP_OK;
-    Pose16 p;
-    memset(p.m, 0, sizeof(p.m));
-    if (init) p = *init;
-    hipLaunchKernelGGL(k_pack_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xyz_dev, (int)n,
-                       ctx->tgt4.as<float4>(), init ? reg_state(ctx) : (RegState*)nullptr, p, keep_pose ? 1 : 0,
-                       pose_box(ctx), init ? next_box_generation(ctx) : 0u, ctx->pose_hist);
+    PackDesc d;
+    memset(&d, 0, sizeof(d));
+    if (init) d.init = *init;
+    d.xyz = xyz_dev;
+    d.n = (int)n;
+    d.out = ctx->tgt4.as<float4>();
+    d.st = init ? reg_state(ctx) : (RegState*)nullptr;
+    d.keep_pose = keep_pose ? 1 : 0;
+    d.box = pose_box(ctx);
+    d.gen = init ? next_box_generation(ctx) : 0u;
+    d.hist = ctx->pose_hist;
+    if (defer) {  // the caller launches (B registrations per launch)
+        *defer = d;
+        return ICP_OK;
+    }
+    hipLaunchKernelGGL(k_pack_targets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d.xyz, d.n, d.out, d.st,
+                       d.init, d.keep_pose, d.box, d.gen, d.hist);
     ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+int launch_pack_targets_batch(icp_ctx* first, const PackDesc* table_host, const PackDesc* table_dev, int count) {
+    int max_n = 0;
+    for (int b = 0; b < count; ++b) max_n = table_host[b].n > max_n ? table_host[b].n : max_n;
+    if (max_n <= 0) return ICP_OK;
+    hipLaunchKernelGGL(k_pack_targets_batch, dim3((unsigned)((max_n + 255) / 256), count), dim3(256), 0, first->stream, table_dev);
+    ICP_HIP(first, hipGetLastError());
     return ICP_OK;
 }
 

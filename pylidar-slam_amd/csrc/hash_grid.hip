@@ -242,20 +242,20 @@ int compact_valid_rows(icp_ctx* ctx, const float* xyz, int64_t n, bool skip_null
 // + (carry_m > 0: a pose-only update, option "carry_normals") the normals the old grid holds, rotated into the new frame
 // like the points (n' = R^-1 n; re-normalised, so that a thousand pose-only updates in a row leave unit vectors) and filed
 // by ORIGINAL index: the scatter of this build puts them at the points' new cell-sorted positions instead of zeros.
-__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
+__device__ __forceinline__ void grid_clear_body(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
-                             int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket,
+                             int* __restrict__ seed, const MapMoveJob& move, int* __restrict__ scan_ticket,
                              unsigned long long* __restrict__ hood_used, const float4* __restrict__ old_normals,
-                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry) {
+                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry, const unsigned bx) {
     __shared__ float T[16];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
         if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
     }
-    const long long first = (long long)blockIdx.x * blockDim.x;
+    const long long first = (long long)bx * blockDim.x;
     const bool moves = first < move.m;  // block-uniform (a carry job comes with a move job over the same points)
     if (moves && threadIdx.x == 0) map_move_prepare(move, T);
-    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int i = bx * blockDim.x + threadIdx.x;
     if (i < size) {
         GridEntry e;
         e.key = GRID_EMPTY;
@@ -289,6 +289,15 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
             if (o >= 0 && o < carry_m) carry[o] = out;
         }
     }
+}
+
+__global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
+                             const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
+                             int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket,
+                             unsigned long long* __restrict__ hood_used, const float4* __restrict__ old_normals,
+                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry) {
+    grid_clear_body(table, size, nn_cache, old_pts, seed_n, old_m, evicted, seed, move, scan_ticket, hood_used, old_normals,
+                    old_nflag, carry_m, carry, blockIdx.x);
 }
 
 // rows[cell][c] = (start, count) of the neighbour cell c of every occupied cell (0,0 if that neighbour is empty)
@@ -374,14 +383,14 @@ __device__ inline void wave_group_by_key(unsigned long long key, bool active, in
 // the lanes of a wave share a handful of keys again — in insertion order a map merged from many grid-sampled clouds has 64
 // different cells per wave (64 trips of the grouping loop, 64 claims, 64 counter updates: 16.9 us at C2, 24 us at 181 695
 // points).  Which thread claims a point does not matter: ranks inside a cell come from atomics either way.
-__global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h, float inv_hc,
+__device__ __forceinline__ void grid_insert2_body(const float* __restrict__ xyz, int m, float inv_h, float inv_hc,
                                GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
                                int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
                                const float4* __restrict__ old_pts, int old_m, int evicted, int kept,
-                               int* __restrict__ visit) {
+                               int* __restrict__ visit, const unsigned bx) {
     // (with `old_pts` the four outputs are indexed by THREAD and visit[thread] names the point, -1: none — the scatter walks
     // the same order, so that its stores by new position are clustered as well)
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = bx * blockDim.x + threadIdx.x;
     int i = t;
     bool active = t < m;
     if (old_pts) {
@@ -429,6 +438,15 @@ __global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h
     rank_of[i] = base + rank;
     cslot_of[i] = cslot;
     crank_of[i] = cbase + crank;
+}
+
+__global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h, float inv_hc,
+                               GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
+                               int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
+                               const float4* __restrict__ old_pts, int old_m, int evicted, int kept,
+                               int* __restrict__ visit) {
+    grid_insert2_body(xyz, m, inv_h, inv_hc, table, tsize, slot_of, rank_of, cslot_of, crank_of, old_pts, old_m, evicted, kept,
+                      visit, blockIdx.x);
 }
 
 __device__ inline unsigned long long grid_scan_item(const GridEntry* __restrict__ table, long long i, long long n,
@@ -504,12 +522,13 @@ __device__ inline bool scan_wait(const unsigned long long* __restrict__ desc_a,
     return false;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restrict__ table, long long n,
+__device__ __forceinline__ void grid_scan_body(GridEntry* __restrict__ table, long long n,
                                                             unsigned int tsize, int m,
                                                             unsigned long long* __restrict__ desc_a,
                                                             unsigned long long* __restrict__ desc_b, unsigned gen,
                                                             int poll_limit, int* __restrict__ slot_of_cell,
-                                                            int* __restrict__ ncells_out, int* __restrict__ ticket) {
+                                                            int* __restrict__ ncells_out, int* __restrict__ ticket,
+                                                            const int tiles) {
     __shared__ unsigned long long lds[16];
     __shared__ unsigned long long prefix_s;
     __shared__ int gave_up;
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
         __syncthreads();
     }
     unsigned long long off = excl + prefix_s;
-    if (threadIdx.x == 0 && tile == (int)gridDim.x - 1) *ncells_out = (int)((prefix_s + tot) >> 32);
+    if (threadIdx.x == 0 && tile == tiles - 1) *ncells_out = (int)((prefix_s + tot) >> 32);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const long long i = base + k;
@@ -593,6 +612,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restric
         }
         off += v[k];
     }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan(GridEntry* __restrict__ table, long long n,
+                                                            unsigned int tsize, int m,
+                                                            unsigned long long* __restrict__ desc_a,
+                                                            unsigned long long* __restrict__ desc_b, unsigned gen,
+                                                            int poll_limit, int* __restrict__ slot_of_cell,
+                                                            int* __restrict__ ncells_out, int* __restrict__ ticket) {
+    grid_scan_body(table, n, tsize, m, desc_a, desc_b, gen, poll_limit, slot_of_cell, ncells_out, ticket, (int)gridDim.x);
 }
 
 // `visit` (k_grid_insert2's order, "insert_by_cell"): thread t handles point visit[t] (-1: none), its claims are filed by t
@@ -638,6 +666,23 @@ __device__ inline void grid_scatter_part(int t, const float* __restrict__ xyz, i
 
 // The neighbour rows and the scatter both need the scanned table and nothing of each other: one launch, the first
 // `row_blocks` workgroups build rows (grid-stride over the occupied cells x 27), the others scatter the points.
+__device__ __forceinline__ void grid_rows_scatter_body(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
+                                    unsigned int mask, const int* __restrict__ slot_of_cell,
+                                    const int* __restrict__ ncells_dev, int2* __restrict__ rows, int row_blocks,
+                                    const int* __restrict__ slot_of, const int* __restrict__ rank_of,
+                                    const int* __restrict__ cslot_of, const int* __restrict__ crank_of,
+                                    float4* __restrict__ sorted, float4* __restrict__ csorted,
+                                    float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
+                                    int* __restrict__ pos_of_orig, const float4* __restrict__ carry, int carry_m,
+                                    const int* __restrict__ visit, int visit_n, const int bx) {
+    if (bx < row_blocks) {  // block-uniform
+        build_rows_part(table, mask, slot_of_cell, ncells_dev, rows, bx, row_blocks);
+        return;
+    }
+    grid_scatter_part((bx - row_blocks) * blockDim.x + threadIdx.x, xyz, m, table, slot_of, rank_of, cslot_of,
+                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m, visit, visit_n);
+}
+
 __global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const GridEntry* __restrict__ table,
                                     unsigned int mask, const int* __restrict__ slot_of_cell,
                                     const int* __restrict__ ncells_dev, int2* __restrict__ rows, int row_blocks,
@@ -647,12 +692,43 @@ __global__ void k_grid_rows_scatter(const float* __restrict__ xyz, int m, const 
                                     float4* __restrict__ normals, int* __restrict__ nflag, int* __restrict__ row_of_pos,
                                     int* __restrict__ pos_of_orig, const float4* __restrict__ carry, int carry_m,
                                     const int* __restrict__ visit, int visit_n) {
-    if ((int)blockIdx.x < row_blocks) {  // block-uniform
-        build_rows_part(table, mask, slot_of_cell, ncells_dev, rows, blockIdx.x, row_blocks);
-        return;
-    }
-    grid_scatter_part((blockIdx.x - row_blocks) * blockDim.x + threadIdx.x, xyz, m, table, slot_of, rank_of, cslot_of,
-                      crank_of, sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m, visit, visit_n);
+    grid_rows_scatter_body(xyz, m, table, mask, slot_of_cell, ncells_dev, rows, row_blocks, slot_of, rank_of, cslot_of, crank_of,
+                           sorted, csorted, normals, nflag, row_of_pos, pos_of_orig, carry, carry_m, visit, visit_n,
+                           (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The four launches of a grid build for B maps at once (icp_batch_map_update, api.hip): blockIdx.y = the map, its arguments
+// — exactly those of the four kernels above — in a GridBuildDesc in device memory; a map with fewer workgroups than the
+// largest of the batch lets the surplus return.  Same bodies, same results.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_grid_clear_batch(const GridBuildDesc* __restrict__ t) {
+    const GridBuildDesc& d = t[blockIdx.y];
+    if (blockIdx.x >= d.clear_blocks) return;
+    grid_clear_body(d.table, d.n2, d.nn_cache, d.old_pts, d.seed_n, d.seed_m, d.seed_evicted, d.seed, d.move, d.scan_ticket,
+                    d.hood_used, d.old_normals, d.old_nflag, d.carry_m, d.carry, blockIdx.x);
+}
+
+__global__ void k_grid_insert2_batch(const GridBuildDesc* __restrict__ t) {
+    const GridBuildDesc& d = t[blockIdx.y];
+    if (blockIdx.x >= d.visit_blocks) return;
+    grid_insert2_body(d.xyz, d.m, d.inv_h, d.inv_hc, d.table, d.tsize, d.slot_of, d.rank_of, d.cslot_of, d.crank_of, d.order_pts,
+                      d.order_old_m, d.order_evicted, d.order_kept, d.visit, blockIdx.x);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan_batch(const GridBuildDesc* __restrict__ t) {
+    const GridBuildDesc& d = t[blockIdx.y];
+    if (blockIdx.x >= d.scan_blocks) return;  // (before the ticket is drawn: the tiles of a map number 0 .. scan_blocks - 1)
+    grid_scan_body(d.table, (long long)d.n2, d.tsize, d.m, d.desc_a, d.desc_b, d.scan_gen, d.poll_limit, d.slot_of_cell,
+                   d.ncells, d.scan_ticket, (int)d.scan_blocks);
+}
+
+__global__ void k_grid_rows_scatter_batch(const GridBuildDesc* __restrict__ t) {
+    const GridBuildDesc& d = t[blockIdx.y];
+    if (blockIdx.x >= d.row_blocks + d.visit_blocks) return;
+    grid_rows_scatter_body(d.xyz, d.m, d.table, d.tsize - 1, d.slot_of_cell, d.ncells, d.rows, (int)d.row_blocks, d.slot_of,
+                           d.rank_of, d.cslot_of, d.crank_of, d.sorted, d.csorted, d.normals, d.nflag, d.row_of_pos,
+                           d.pos_of_orig, d.carry, d.carry_m, d.visit, d.visit_n, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -732,7 +808,7 @@ static unsigned int next_pow2(unsigned int v) {
     return p;
 }
 
-int build_grid(icp_ctx* ctx) {
+int build_grid(icp_ctx* ctx, GridBuildDesc* defer) {
     const int64_t m = ctx->map_m;
     ctx->grid_valid = false;
     if (m <= 0) {
@@ -852,6 +928,7 @@ int build_grid(icp_ctx* ctx) {
     int* scan_ticket = ctx->scan_desc.as<int>();
     unsigned long long* desc = ctx->scan_desc.as<unsigned long long>() + 8;
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
+    GridBuildDesc d{};
     {
         const int seed_n = ctx->seed_job_n;
         ctx->seed_job_n = 0;
@@ -859,47 +936,115 @@ int build_grid(icp_ctx* ctx) {
         const MapMoveJob move = ctx->move_job;  // the kept points re-expressed in the new frame (map update)
         ctx->move_job = MapMoveJob();
         if (move.m > span) span = move.m;
-        hipLaunchKernelGGL(k_grid_clear, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, table,
-                           (unsigned int)n2, ctx->nn_cache.as<int4>(), ctx->sorted_pts.as<float4>(), seed_n,
-                           ctx->seed_job_m, ctx->seed_job_evicted, ctx->seed_orig.as<int>(), move, scan_ticket, hood_used,
-                           ctx->normals.as<float4>(), ctx->nflag.as<int>(), carry_m, ctx->normals_carry.as<float4>());
+        d.table = table;
+        d.n2 = (unsigned)n2;
+        d.tsize = tsize;
+        d.nn_cache = ctx->nn_cache.as<int4>();
+        d.old_pts = ctx->sorted_pts.as<float4>();
+        d.seed_n = seed_n;
+        d.seed_m = ctx->seed_job_m;
+        d.seed_evicted = ctx->seed_job_evicted;
+        d.seed = ctx->seed_orig.as<int>();
+        d.move = move;
+        d.scan_ticket = scan_ticket;
+        d.hood_used = hood_used;
+        d.old_normals = ctx->normals.as<float4>();
+        d.old_nflag = ctx->nflag.as<int>();
+        d.carry_m = carry_m;
+        d.carry = ctx->normals_carry.as<float4>();
+        d.clear_blocks = (unsigned)((span + 255) / 256);
     }
     const long long visit_n = by_cell ? ctx->order_old_m + (m - ctx->order_kept) : 0;
-    const unsigned vb = (unsigned)(((by_cell ? visit_n : m) + 255) / 256);  // workgroups of the claiming / scattering threads
     int* visit = by_cell ? ctx->worklist.as<int>() : (int*)nullptr;  // (the lazy-normal worklist is idle during a build)
-    hipLaunchKernelGGL(k_grid_insert2, dim3(vb), dim3(256), 0, ctx->stream, xyz, (int)m, inv_h, inv_h / COARSE_FACTOR, table,
-                       tsize, ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                       ctx->crank_of.as<int>(), by_cell ? (const float4*)ctx->sorted_pts.as<float4>() : (const float4*)nullptr,
-                       (int)ctx->order_old_m, (int)ctx->order_evicted, (int)ctx->order_kept, visit);
-    hipLaunchKernelGGL(k_grid_scan, dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, table, n2, tsize, (int)m, desc,
-                       desc + nb, scan_gen, ctx->scan_poll_limit, ctx->slot_of_cell.as<int>(), ncells_dev, scan_ticket);
+    d.xyz = xyz;
+    d.m = (int)m;
+    d.inv_h = inv_h;
+    d.inv_hc = inv_h / COARSE_FACTOR;
+    d.slot_of = ctx->slot_of.as<int>();
+    d.rank_of = ctx->rank_of.as<int>();
+    d.cslot_of = ctx->cslot_of.as<int>();
+    d.crank_of = ctx->crank_of.as<int>();
+    d.order_pts = by_cell ? (const float4*)ctx->sorted_pts.as<float4>() : (const float4*)nullptr;
+    d.order_old_m = (int)ctx->order_old_m;
+    d.order_evicted = (int)ctx->order_evicted;
+    d.order_kept = (int)ctx->order_kept;
+    d.visit = visit;
+    d.visit_n = (int)visit_n;
+    d.visit_blocks = (unsigned)(((by_cell ? visit_n : m) + 255) / 256);  // workgroups of the claiming / scattering threads
+    d.desc_a = desc;
+    d.desc_b = desc + nb;
+    d.scan_gen = scan_gen;
+    d.poll_limit = ctx->scan_poll_limit;
+    d.slot_of_cell = ctx->slot_of_cell.as<int>();
+    d.ncells = ncells_dev;
+    d.scan_blocks = (unsigned)nb;
     {
         long long want = ((long long)m * 27 + 255) / 256;
-        const unsigned rb = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
-        hipLaunchKernelGGL(k_grid_rows_scatter, dim3(rb + vb), dim3(256), 0, ctx->stream, xyz, (int)m, table, tsize - 1,
-                           ctx->slot_of_cell.as<int>(), ncells_dev, ctx->rows.as<int2>(), (int)rb,
-                           ctx->slot_of.as<int>(), ctx->rank_of.as<int>(), ctx->cslot_of.as<int>(),
-                           ctx->crank_of.as<int>(), ctx->sorted_pts.as<float4>(), ctx->csorted.as<float4>(),
-                           ctx->normals.as<float4>(), ctx->nflag.as<int>(), ctx->row_of_pos.as<int>(),
-                           ctx->pos_of_orig.as<int>(), ctx->normals_carry.as<float4>(), carry_m, visit, (int)visit_n);
+        d.row_blocks = (unsigned)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
     }
+    d.rows = ctx->rows.as<int2>();
+    d.sorted = ctx->sorted_pts.as<float4>();
+    d.csorted = ctx->csorted.as<float4>();
+    d.normals = ctx->normals.as<float4>();
+    d.nflag = ctx->nflag.as<int>();
+    d.row_of_pos = ctx->row_of_pos.as<int>();
+    d.pos_of_orig = ctx->pos_of_orig.as<int>();
+    d.with_hoods = with_hoods ? 1 : 0;
+    d.hood_cap = (unsigned long long)hood_cap;
     // neighbourhood lists for the kNN normals (option "hoods"; maps beyond 2^22 points keep the row walk: 27 x 16 B per
     // point would be gigabytes).  The start of a run is an int: 27 M < 2^31 holds for every map that gets here
     ctx->hoods_valid = false;
-    if (with_hoods) {
-        const size_t cap = hood_cap;
-        unsigned long long* used = hood_used;
-        const unsigned hb = (unsigned)((m + HOOD_THREADS / 32 - 1) / (HOOD_THREADS / 32));  // (cells <= points)
-        hipLaunchKernelGGL(k_hood_build, dim3(hb), dim3(HOOD_THREADS), 0, ctx->stream, ctx->slot_of_cell.as<int>(),
-                           ncells_dev, ctx->rows.as<int2>(), ctx->sorted_pts.as<float4>(), ctx->hood.as<float4>(),
-                           (long long)cap, used);
-        ctx->hoods_valid = true;
-    }
     ctx->ctable_ptr = table + tsize;
     ctx->ctable_size = tsize;
-    ICP_HIP(ctx, hipGetLastError());
     ctx->grid_valid = true;
     ctx->grid_gen += 1;  // cell-sorted positions handed out before this build are void
+    if (defer) {  // the caller launches (B maps per launch) and finishes
+        *defer = d;
+        return ICP_OK;
+    }
+    hipLaunchKernelGGL(k_grid_clear, dim3(d.clear_blocks), dim3(256), 0, ctx->stream, d.table, d.n2, d.nn_cache, d.old_pts,
+                       d.seed_n, d.seed_m, d.seed_evicted, d.seed, d.move, d.scan_ticket, d.hood_used, d.old_normals,
+                       d.old_nflag, d.carry_m, d.carry);
+    hipLaunchKernelGGL(k_grid_insert2, dim3(d.visit_blocks), dim3(256), 0, ctx->stream, d.xyz, d.m, d.inv_h, d.inv_hc, d.table,
+                       d.tsize, d.slot_of, d.rank_of, d.cslot_of, d.crank_of, d.order_pts, d.order_old_m, d.order_evicted,
+                       d.order_kept, d.visit);
+    hipLaunchKernelGGL(k_grid_scan, dim3(d.scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, d.table, (long long)d.n2, d.tsize,
+                       d.m, d.desc_a, d.desc_b, d.scan_gen, d.poll_limit, d.slot_of_cell, d.ncells, d.scan_ticket);
+    hipLaunchKernelGGL(k_grid_rows_scatter, dim3(d.row_blocks + d.visit_blocks), dim3(256), 0, ctx->stream, d.xyz, d.m, d.table,
+                       d.tsize - 1, d.slot_of_cell, d.ncells, d.rows, (int)d.row_blocks, d.slot_of, d.rank_of, d.cslot_of,
+                       d.crank_of, d.sorted, d.csorted, d.normals, d.nflag, d.row_of_pos, d.pos_of_orig, d.carry, d.carry_m,
+                       d.visit, d.visit_n);
+    ICP_HIP(ctx, hipGetLastError());
+    return build_grid_finish(ctx, d);
+}
+
+int build_grid_finish(icp_ctx* ctx, const GridBuildDesc& d) {
+    if (d.with_hoods) {
+        const unsigned hb = (unsigned)((d.m + HOOD_THREADS / 32 - 1) / (HOOD_THREADS / 32));  // (cells <= points)
+        hipLaunchKernelGGL(k_hood_build, dim3(hb), dim3(HOOD_THREADS), 0, ctx->stream, d.slot_of_cell, d.ncells, d.rows, d.sorted,
+                           ctx->hood.as<float4>(), (long long)d.hood_cap, d.hood_used);
+        ctx->hoods_valid = true;
+        ICP_HIP(ctx, hipGetLastError());
+    }
+    return ICP_OK;
+}
+
+// the four launches for `count` maps (table_host: what the prepared builds returned, for the grid sizes; table_dev: the same
+// table in device memory)
+int launch_grid_build_batch(icp_ctx* first, const GridBuildDesc* th, const GridBuildDesc* td, int count) {
+    unsigned clear = 0, visit = 0, scan = 0, scatter = 0;
+    for (int b = 0; b < count; ++b) {
+        clear = th[b].clear_blocks > clear ? th[b].clear_blocks : clear;
+        visit = th[b].visit_blocks > visit ? th[b].visit_blocks : visit;
+        scan = th[b].scan_blocks > scan ? th[b].scan_blocks : scan;
+        const unsigned sc = th[b].row_blocks + th[b].visit_blocks;
+        scatter = sc > scatter ? sc : scatter;
+    }
+    hipLaunchKernelGGL(k_grid_clear_batch, dim3(clear, count), dim3(256), 0, first->stream, td);
+    hipLaunchKernelGGL(k_grid_insert2_batch, dim3(visit, count), dim3(256), 0, first->stream, td);
+    hipLaunchKernelGGL(k_grid_scan_batch, dim3(scan, count), dim3(SCAN_THREADS), 0, first->stream, td);
+    hipLaunchKernelGGL(k_grid_rows_scatter_batch, dim3(scatter, count), dim3(256), 0, first->stream, td);
+    ICP_HIP(first, hipGetLastError());
     return ICP_OK;
 }
 

@@ -226,6 +226,66 @@ struct MapMoveJob {
     const RegState* st = nullptr;  // device-resident pose instead of `rel`
 };
 
+// Everything the four launches of a grid build take (hash_grid.hip): filled by build_grid, handed to the kernels by value
+// (one map) or through a table in device memory (B maps per launch: icp_batch_map_update)
+struct GridBuildDesc {
+    // k_grid_clear: the table of both levels emptied; + NN cache -> frame seeds, + the re-expression of the kept points, + the
+    // normals carried through a pose-only update
+    GridEntry* table;
+    unsigned n2;              // slots of both levels
+    unsigned tsize;           // slots of one level
+    const int4* nn_cache;
+    const float4* old_pts;    // cell-sorted points of the PREVIOUS grid
+    int seed_n, seed_m, seed_evicted;
+    int* seed;
+    MapMoveJob move;
+    int* scan_ticket;
+    unsigned long long* hood_used;
+    const float4* old_normals;
+    const int* old_nflag;
+    int carry_m;
+    float4* carry;
+    unsigned clear_blocks;
+    // k_grid_insert2
+    const float* xyz;
+    int m;
+    float inv_h, inv_hc;
+    int *slot_of, *rank_of, *cslot_of, *crank_of;
+    const float4* order_pts;  // = old_pts when the claims follow the previous grid's cell order, else nullptr
+    int order_old_m, order_evicted, order_kept;
+    int* visit;
+    int visit_n;
+    unsigned visit_blocks;    // workgroups of the claiming / scattering threads
+    // k_grid_scan
+    unsigned long long *desc_a, *desc_b;
+    unsigned scan_gen;
+    int poll_limit;
+    int* slot_of_cell;
+    int* ncells;
+    unsigned scan_blocks;
+    // k_grid_rows_scatter
+    int2* rows;
+    unsigned row_blocks;
+    float4 *sorted, *csorted, *normals;
+    int *nflag, *row_of_pos, *pos_of_orig;
+    // behind the four launches (host side): neighbourhood lists wanted for this build
+    int with_hoods;
+    unsigned long long hood_cap;
+};
+
+// the arguments of k_pack_targets (grid_sample.hip), as the batched launch reads them from device memory; n = 0: nothing to do
+struct PackDesc {
+    const float* xyz;
+    float4* out;
+    RegState* st;
+    unsigned long long* box;
+    float* hist;
+    Pose16 init;
+    int n, keep_pose;
+    unsigned gen;
+    int pad;
+};
+
 struct AlignParams {
     int scheme;
     float sigma;
@@ -320,6 +380,21 @@ struct icp_ctx {
     int knn_rings = -1;                // "knn_rings": fine rings of the kNN before the coarse level (-1: min(max_rings, 2))
     int knn_lanes = 4;                 // "knn_lanes": lanes per map point in the kNN kernels (4 or 2)
     int use_nn_cache = 2;              // "nn_cache": 0 off, 1 exact NN cache, 2 + a missed entry seeds the search
+    // "late_from": fused launches from that iteration on run the late kernel (search.hip: records settle nearly every query); -1
+    // (the default): never.  MEASURED (round 6): 26.5 vs 31 us per late launch of a batch of eight sequences (four
+    // workgroups per CU instead of two), no difference for one sequence (its late iterations wait for the lead workgroup) — and
+    // a frame whose constant-velocity guess is off (the two turn-around frames of the benchmark's trajectory: every query still
+    // misses in iterations 3 and 4) searches its 512 misses per workgroup two waves at a time: 440 us per launch instead of 20
+    int late_from = -1;
+    int late_waves = 8;                // "late_waves": 8 | 6 — waves per SIMD the late kernel is built for (64 / 80 registers: 4 / 3 workgroups per CU)
+    // "hit_records": the first hit behind a search leaves a record (winner, normal, bound) later hits are decided from
+    // (search.hip).  Bit-identical, 64 instead of 128 bytes requested per hit — and MEASURED slower (round 6): 2684 vs
+    // 2831 scans/s on the headline, 6472 vs 6586 with sixteen sequences per launch: the 2 % of queries whose winner and runner-up
+    // are closer than the pose still moves fail the record's test and fetch the candidate set in a DEPENDENT round trip behind
+    // the pose, and the slowest workgroup of a launch is one that holds such a query (phase A max 7.04 vs 6.32 us; the
+    // speculative gathers of the set were free: they ride behind the lead's solve).  Off by default
+    int hit_records = 0;
+    icp::DeviceBuffer nn_rec;          // float4[2 N]: the hit records
     int fuse_iteration = 1;            // "fuse_iteration": search + rows + partial sums in one kernel when normals are ready
     int narrow_from = 0;               // "narrow_from": ICP iteration from which the fused kernel runs with 128 threads per block (-1: never)
     int wave_misses_dense = 4;         // "wave_misses_dense": the same threshold in the 128-query shape (early iterations)
@@ -505,7 +580,11 @@ namespace icp {
     } while (0)
 
 // ---- hash_grid.hip
-int build_grid(icp_ctx* ctx);
+// defer != nullptr: everything but the launches — *defer receives their arguments (the caller launches them, e.g. for B maps
+// at once: launch_grid_build_batch) and calls build_grid_finish afterwards
+int build_grid(icp_ctx* ctx, GridBuildDesc* defer = nullptr);
+int build_grid_finish(icp_ctx* ctx, const GridBuildDesc& d);  // the neighbourhood lists, where the build wants them
+int launch_grid_build_batch(icp_ctx* first, const GridBuildDesc* table_host, const GridBuildDesc* table_dev, int count);
 // exclusive scan of n ints (in place allowed); total written to *total_dev (device int) if non-null
 int exclusive_scan_i32(icp_ctx* ctx, const int* in, int* out, int64_t n, int* total_dev);
 // ordered compaction: copies rows (row_floats floats each) whose flag != 0; count to *count_dev
@@ -580,6 +659,7 @@ int launch_procrustes_pass(icp_ctx* ctx, const float* tgt, const float* ref, con
 int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_dev, int32_t* index_dev, bool keep_keys = false,
                    float* rows_dev = nullptr);
 int project_pixels_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* rows_dev, float* cols_dev);
+int project_batch_device(icp_ctx* const* ctxs, int count, const float* const* xyz_dev, const int64_t* n, float* const* vmap_dev);
 int kitti_correct_device(icp_ctx* ctx, const float* scan_dev, int64_t n, int stride, double* out_dev);
 
 // ---- projective.hip
@@ -601,7 +681,9 @@ int distort_device(icp_ctx* ctx, const float* xyz_dev, const double* ts_dev, int
 // targets -> float4 rows (x, y, z, bits(row)) in ctx->tgt4
 // targets -> float4 rows; with `init` the registration state is initialised by the same launch (init->m = the initial
 // guess; keep_pose: the pose the state already holds — the previous result — is the guess)
-int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init = nullptr, bool keep_pose = false);
+int prepare_targets(icp_ctx* ctx, const float* xyz_dev, int64_t n, const Pose16* init = nullptr, bool keep_pose = false,
+                    PackDesc* defer = nullptr);  // defer: the launch is left to the caller (launch_pack_targets_batch)
+int launch_pack_targets_batch(icp_ctx* first, const PackDesc* table_host, const PackDesc* table_dev, int count);
 int voxel_statistics_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, double voxel, long long* voxels_dev,
                             long long* hashes_dev, long long* ids_dev, long long* sizes_dev, float* means_dev,
                             float* covs_dev, int* count_dev);

@@ -5,6 +5,8 @@
 // wins each pixel (:404-415) — deterministic only single-threaded.  Here every point does one 64-bit atomicMin on
 // (range bits << 32 | ~index) per pixel, then a resolve pass gathers the winner: nearest point wins, equal ranges go to
 // the highest point index (the outcome of a stable descending sort + last-write-wins).
+#include <string.h>
+
 #include "icp_internal.h"
 #include "projection_device.h"
 
@@ -82,6 +84,52 @@ __global__ void k_project_resolve(const float* __restrict__ xyz, unsigned long l
     }
 }
 
+// B projections per launch (icp_batch_project): blockIdx.y = the member; its arguments ride in the kernel-argument segment
+// (48 bytes per member).  Same arithmetic per point and per pixel as k_project / k_project_resolve.
+struct ProjBatchEntry {
+    const float* xyz;
+    unsigned long long* zbuf;
+    float* vmap;
+    int n, npix;
+    ProjParams pp;
+};
+struct ProjBatchArgs {
+    ProjBatchEntry e[ICP_BATCH_MAX_SEQUENCES];
+};
+
+__global__ void k_project_batch(ProjBatchArgs a) {
+    const ProjBatchEntry& e = a.e[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e.n) return;
+    const float x = e.xyz[3 * i], y = e.xyz[3 * i + 1], z = e.xyz[3 * i + 2];
+    float row, col, r;
+    spherical_pixel(x, y, z, e.pp, row, col, r);
+    const float prow = rintf(row), pcol = rintf(col);
+    if (!(prow >= 0.0f && prow <= (float)(e.pp.height - 1) && pcol >= 0.0f && pcol <= (float)(e.pp.width - 1))) return;
+    if (!(r > 0.0f)) return;
+    const int pix = (int)prow * e.pp.width + (int)pcol;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned long long)(~(unsigned)i);
+    atomicMin(&e.zbuf[pix], key);
+}
+
+__global__ void k_project_resolve_batch(ProjBatchArgs a) {
+    const ProjBatchEntry& e = a.e[blockIdx.y];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= e.npix) return;
+    const unsigned long long k = e.zbuf[p];
+    if (k != ~0ull) e.zbuf[p] = ~0ull;  // clean for the next projection
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (k != ~0ull) {
+        const int idx = (int)(~(unsigned)(k & 0xffffffffull));
+        x = e.xyz[3 * idx];
+        y = e.xyz[3 * idx + 1];
+        z = e.xyz[3 * idx + 2];
+    }
+    e.vmap[p] = x;
+    e.vmap[e.npix + p] = y;
+    e.vmap[2 * e.npix + p] = z;
+}
+
 __global__ void k_project_pixels(const float* __restrict__ xyz, int n, ProjParams pp, float* __restrict__ rows,
                                  float* __restrict__ cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +202,38 @@ int project_device(icp_ctx* ctx, const float* xyz_dev, int64_t n, float* vmap_de
                        vmap_dev, index_dev, keep_keys ? 0 : 1, rows_dev);
     if (keep_keys) ctx->zbuf_clean = nullptr;  // the caller reads the (range, ~index) keys: cleared by the next projection
     ICP_HIP(ctx, hipGetLastError());
+    return ICP_OK;
+}
+
+// vertex maps of `count` scans (device pointers) in two launches; every member keeps its own z-buffer
+int project_batch_device(icp_ctx* const* ctxs, int count, const float* const* xyz_dev, const int64_t* n, float* const* vmap_dev) {
+    ProjBatchArgs a;
+    memset(&a, 0, sizeof(a));
+    int max_n = 0, max_pix = 0;
+    icp_ctx* first = ctxs[0];
+    for (int b = 0; b < count; ++b) {
+        icp_ctx* ctx = ctxs[b];
+        const int npix = ctx->cfg.height * ctx->cfg.width;
+        ICP_HIP(ctx, ctx->zbuf.reserve((size_t)npix * sizeof(unsigned long long)));
+        unsigned long long* zb = ctx->zbuf.as<unsigned long long>();
+        if (ctx->zbuf_clean != zb || ctx->zbuf_clean_pixels != npix) {  // a fresh allocation / another image size
+            hipLaunchKernelGGL(k_zbuf_clear, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, zb, npix);
+            ctx->zbuf_clean = zb;
+            ctx->zbuf_clean_pixels = npix;
+        }
+        a.e[b].xyz = xyz_dev[b];
+        a.e[b].zbuf = zb;
+        a.e[b].vmap = vmap_dev[b];
+        a.e[b].n = (int)n[b];
+        a.e[b].npix = npix;
+        a.e[b].pp = proj_params(ctx);
+        max_n = (int)n[b] > max_n ? (int)n[b] : max_n;
+        max_pix = npix > max_pix ? npix : max_pix;
+    }
+    if (max_n > 0)
+        hipLaunchKernelGGL(k_project_batch, dim3((unsigned)((max_n + 255) / 256), count), dim3(256), 0, first->stream, a);
+    hipLaunchKernelGGL(k_project_resolve_batch, dim3((unsigned)((max_pix + 255) / 256), count), dim3(256), 0, first->stream, a);
+    ICP_HIP(first, hipGetLastError());
     return ICP_OK;
 }
 

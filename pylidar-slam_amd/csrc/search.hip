@@ -1177,6 +1177,18 @@ __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*pa
 //   B. the 4-lane groups of the whole block take the list entries in order: only ceil(misses / 16) waves search, the
 //      others go straight to the reduction.
 // The list order is not deterministic, the result is: every row lands in the slot of its query.
+// HIT RECORD (round 6; VERDICT r5 item 2: "make a cache hit cost what it uses").  A hit used to request 128 bytes — target,
+// cache entry, the three candidate points AND their three normals, six of the eight loads 16-byte gathers — to use 36, and
+// decided in two dependent round trips (entry, then candidates).  Now the first hit behind a search leaves a RECORD next to
+// the entry: the winner's point, its normal, the iteration k' of that hit and a bound B on the distance of EVERY OTHER map
+// point at pose k' — B = min(L - delta(k -> k'), |candidate 2|, |candidate 3|) with the entry's L (everything outside the
+// set, at the search's pose k) and the other members' exact distances at k'.  A later iteration tests the record alone:
+// |winner - T p| < B - delta(k' -> now) certifies the winner as THE nearest neighbour (every other point is still farther),
+// from 48 coalesced bytes per query and no gather; the record is a lower-bound argument like the entry's, exact.  Only when
+// that test fails (or there is no record: the iteration right behind a search) the entry's candidate set is fetched and
+// tested as before — so every query the record certifies is one the set test certifies too (triangle inequality), the
+// searches are the same searches, the neighbours the same neighbours.  A search invalidates the record of its query.
+// (Not in the resident tail, which keeps the set in registers, nor with normals on demand, whose rows wait for flags.)
 // First iteration of a frame: no cache yet, but `frame_seed` (optional) names, per scan slot, the map point that was the
 // neighbour of the same slot at the end of the PREVIOUS frame (original map index, shifted by the points evicted
 // since) — a candidate that starts the search with a tight bound; like any seed it cannot change the minimum.
@@ -1186,6 +1198,8 @@ struct IterInputs {
     const float4* normals;   // by cell-sorted position
     int4* nn_cache;          // per query: (position | iteration of the search << 24, bits(L), positions of up to two more
                              // candidates or -1) — L bounds every map point that is not a member of that candidate set
+    float4* rec;             // HIT RECORDS, two float4 per query, or nullptr (see "hit record" at the kernel): (winner xyz,
+                             // bits(bound)), (winner normal, bits(iteration the bound refers to; -1: no record))
     const float* pose_hist;  // [iteration][12]: the pose every earlier iteration of this registration ran with
     const int* frame_seed;   // original map index per query or nullptr
     double* partials;
@@ -1489,6 +1503,8 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
            cq3 = cq, cn3 = cq;
     int4 c = make_int4(-1, 0, -1, -1);
     int seed_o = -1, seed_sp = -1;
+    constexpr bool REC = !TAIL && LAZY_KN == 0;  // hit records (see above)
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
 #pragma unroll 1
     for (int tj = 0;; ++tj) {  // (one trip unless TAIL)
     const LocalTid threadIdx = TAIL ? reloaded_tid() : LocalTid{::threadIdx.x};  // (icp_internal.h)
@@ -1498,6 +1514,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
     if (lq < Q && need_load) {
         need_load = false;
         c = make_int4(-1, 0, -1, -1);
+        r1.w = __int_as_float(-1);
         valid = qi < in.n;
         if (valid) {
             t4 = in.tgt[qi];
@@ -1507,7 +1524,12 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
         if (valid) {
             if (in.use_cache) {
                 c = in.nn_cache[qi];
-                if (c.x >= 0) {
+                if (REC && in.rec) {  // entry and record together: 48 coalesced bytes
+                    r0 = in.rec[2 * (size_t)qi];
+                    r1 = in.rec[2 * (size_t)qi + 1];
+                }
+                // the candidate set only where there is no record to try first (the iteration behind a search)
+                if (c.x >= 0 && !(REC && in.rec && __float_as_int(r1.w) >= 0)) {
                     cq = g.pts[c.x & CACHE_POS_MASK];
                     cn = in.normals[c.x & CACHE_POS_MASK];  // speculative: needed on a hit only
                     if (c.z >= 0) {  // the other members of the candidate set the search left
@@ -1592,39 +1614,82 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
             float seed_d2 = INFINITY;
             int seed_idx = 0x7fffffff, seed_pos = -1;
             if (in.use_cache) {
-                if (c.x >= 0) {
+                const float margin = (!TAIL || iter_now == in.refresh_at) ? in.refresh_margin : 0.f;
+                if (REC && in.rec && c.x >= 0 && __float_as_int(r1.w) >= 0) {  // the record first
+                    const int k2 = __float_as_int(r1.w), age2 = iter_now - k2;
+                    if (age2 >= 1 && age2 <= CACHE_HIST) {
+                        const float dx = r0.x - px, dy = r0.y - py, dz = r0.z - pz;
+                        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        float ox, oy, oz;  // where the target was when the record's bound was formed
+                        transform_point(hist_s[k2 % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
+                        const float mx = px - ox, my = py - oy, mz = pz - oz;
+                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        hit = sqrtf(d2) * 1.000001f < r0.w - delta - margin;
+                    }
+                    if (hit) {
+                        point_to_plane_row(px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, ap.scheme, ap.sigma, row);
+                    } else {  // not certified by the record alone: the entry's candidate set after all (a dependent round trip)
+                        cq = g.pts[c.x & CACHE_POS_MASK];
+                        cn = in.normals[c.x & CACHE_POS_MASK];
+                        if (c.z >= 0) {
+                            cq2 = g.pts[c.z];
+                            cn2 = in.normals[c.z];
+                        }
+                        if (c.w >= 0) {
+                            cq3 = g.pts[c.w];
+                            cn3 = in.normals[c.w];
+                        }
+                    }
+                }
+                if (!hit && c.x >= 0) {
                     const int k = (int)((unsigned)c.x >> CACHE_ITER_SHIFT), age = iter_now - k;  // searched `age` launches ago
                     float dx = cq.x - px, dy = cq.y - py, dz = cq.z - pz;
                     float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     int hit_pos = c.x & CACHE_POS_MASK;
                     float4 wq = cq, wn = cn;  // the winner (the set itself stays as loaded: the tail keeps it for the next trip)
+                    float others2 = INFINITY;  // squared distance of the nearest member of the set that is NOT the winner
                     // the candidate set: its nearest member is THE neighbour as long as everything else (>= L) stays farther
                     if (c.z >= 0) {
                         dx = cq2.x - px, dy = cq2.y - py, dz = cq2.z - pz;
                         const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                         if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(wq.w))) {
+                            others2 = fminf(others2, d2);
                             d2 = e2;
                             wq = cq2;
                             wn = cn2;
                             hit_pos = c.z;
+                        } else {
+                            others2 = fminf(others2, e2);
                         }
                     }
                     if (c.w >= 0) {
                         dx = cq3.x - px, dy = cq3.y - py, dz = cq3.z - pz;
                         const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                         if (better(e2, __float_as_int(cq3.w), d2, __float_as_int(wq.w))) {
+                            others2 = fminf(others2, d2);
                             d2 = e2;
                             wq = cq3;
                             wn = cn3;
                             hit_pos = c.w;
+                        } else {
+                            others2 = fminf(others2, e2);
                         }
                     }
+                    float outside = 0.f;  // lower bound on every map point outside the set, at THIS pose
                     if (age >= 1 && age <= CACHE_HIST) {
                         float ox, oy, oz;  // where the target was when its neighbour was searched
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
                         const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                        hit = sqrtf(d2) * 1.000001f < __int_as_float(c.y) - delta - ((!TAIL || iter_now == in.refresh_at) ? in.refresh_margin : 0.f);
+                        outside = __int_as_float(c.y) - delta;
+                        hit = sqrtf(d2) * 1.000001f < outside - margin;
+                    }
+                    if (REC && in.rec && hit) {
+                        // the record of this hit: winner, normal, and what bounds every OTHER map point at this pose — the
+                        // set's other members exactly (rounded down), everything outside the set by `outside`
+                        const float bound = fminf(outside, sqrtf(others2) * 0.999999f);
+                        in.rec[2 * (size_t)qi] = make_float4(wq.x, wq.y, wq.z, bound);
+                        in.rec[2 * (size_t)qi + 1] = make_float4(wn.x, wn.y, wn.z, __int_as_float(iter_now));
                     }
                     if (hit && LAZY && wn.w != 1.f) {  // the neighbour's normal has not been estimated yet: phase N forms the row
                         const int k2 = atomicAdd(&nlazy, 1);
@@ -1667,6 +1732,12 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
     // lanes (search_ball_lane); what does not fit its pattern (own cell empty, a ball that leaves the 2x2x2 block, more than
     // 256 candidates, four candidates within a key's resolution) goes back on the list for the generic paths below
     // the row of a query whose neighbour a search has just named — or (LAZY) the query on the waiting list of phase N
+    // what a search leaves for its query: the entry — and no hit record (the first hit on the new entry forms one)
+    const auto store_entry = [&](int slot, const int4 e) {
+        const int q = query_of(slot);
+        in.nn_cache[q] = e;
+        if (REC && in.rec) in.rec[2 * (size_t)q + 1] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    };
     const auto row_or_wait = [&](int slot, const float4 mp, const float4 q, const float4 nn, int pos) {
         if (LAZY && nn.w != 1.f) {
             const int k2 = atomicAdd(&nlazy, 1);
@@ -1711,7 +1782,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
                     const int lq2 = __float_as_int(mp.w);
                     const float4 q = g.pts[p0];
                     const float4 nn = in.normals[p0];
-                    in.nn_cache[query_of(lq2)] = make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2);
+                    store_entry(lq2, make_int4(pack_cache(p0, iter_now), __float_as_int(L * 0.999999f), p1, p2));
                     row_or_wait(lq2, mp, q, nn, p0);
                     if (g.dbg) atomicAdd(&g.dbg[0], 1);
                 } else {
@@ -1754,8 +1825,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
                                            __int_as_float(ms.x), ms.y, ms.z);
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
-                                                      -1, -1);
+                store_entry(lq, make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f), -1, -1));
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -1793,10 +1863,9 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
                 const int lq = __float_as_int(mp.w);
                 // the runner-up and the third ride along: L then bounds everything but the set
                 const bool pair = r2.pos >= 0 && b.pos >= 0, triple = pair && r3.pos >= 0;
-                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now),
-                                                 __float_as_int(sqrtf(triple ? r3.second : (pair ? r2.second : b.second)) *
-                                                                0.999999f),
-                                                 pair ? r2.pos : -1, triple ? r3.pos : -1);
+                store_entry(lq, make_int4(pack_cache(b.pos, iter_now),
+                                          __float_as_int(sqrtf(triple ? r3.second : (pair ? r2.second : b.second)) * 0.999999f),
+                                          pair ? r2.pos : -1, triple ? r3.pos : -1));
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -1830,8 +1899,8 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
             const Best& b = near.b;
             if (sub == 0) {
                 const int lq = __float_as_int(mp.w);
-                in.nn_cache[query_of(lq)] = make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f),
-                                                 near.pos1, near.pos2);
+                store_entry(lq, make_int4(pack_cache(b.pos, iter_now), __float_as_int(sqrtf(b.second) * 0.999999f), near.pos1,
+                                          near.pos2));
                 if (b.pos >= 0) {
                     const float4 q = g.pts[b.pos];
                     const float4 nn = in.normals[b.pos];
@@ -1969,6 +2038,271 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_batch(const IterateDe
     const IterateDesc d = load_descriptor(table, seq);
     if (is_lead ? !(d.lead.box && d.lead.solve) : pb >= d.blocks) return;  // (no solve pending for this sequence / a shorter scan)
     iterate_body<THREADS, Q, false, false, 0>(d.g, d.in, d.st, d.ap, d.lead, is_lead, pb, 0, pb, d.blocks);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The LATE kernel (round 6).  From the third or fourth iteration on nearly every query is settled by its hit record — one
+// lane, 48 coalesced bytes, a dozen registers — yet the launches ran the kernel above: 128 registers and 69 KB of LDS per
+// workgroup for the searches it carries, i.e. two workgroups (16 waves) per CU, four rounds of workgroups per batched launch,
+// every round a latency chain (loads -> pose -> rows -> barrier -> block sums) nothing overlaps with.  This kernel is the same
+// iteration built for those launches: phase A is the generic kernel's (record first, then the entry's candidate set, same
+// tests, same record written on a set hit), what neither settles is listed and searched by a whole wave each (search_rows_wave, then the coarse level by the same wave:
+// exact, every path), two waves at a time.  64 registers and 33 KB of LDS: four workgroups (32 waves) per CU.  Same rows for the
+// same queries in the same slots, same block sums: the same bits as the generic kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int LATE_MISS_CAP = 64;
+static constexpr int LATE_SEARCH_WAVES = 2;
+
+template <int THREADS>
+__device__ __forceinline__ void iterate_late_body(GridView g, IterInputs in, RegState* __restrict__ st, AlignParams ap,
+                                                  LeadArgs lead, const bool is_lead, const int pb, const int off) {
+    constexpr int Q = THREADS;
+    g.dbg = nullptr;
+    g.stamps = nullptr;
+    __shared__ float rowbuf[Q][9];
+    __shared__ double part[Q / 32][NEQ];
+    __shared__ int2 cellstack[7][64 * LATE_SEARCH_WAVES];
+    __shared__ float4 miss_p[LATE_MISS_CAP];
+    __shared__ int4 miss_seed[LATE_MISS_CAP];
+    __shared__ unsigned short over_q[Q];  // the slots of the misses beyond LATE_MISS_CAP (searched without a seed: never seen in a converging loop)
+    __shared__ int nmiss;
+    __shared__ float pose_s[12];
+    __shared__ float hist_s[CACHE_HIST][12];
+    __shared__ int ctl_s[4];
+    static_assert(sizeof(rowbuf) >= (32 * NEQ + NEQ + 1) * sizeof(double), "the lead's scratch lives in the row buffer");
+    static_assert(Q <= 65536, "slots are listed as 16-bit numbers");
+    if (lead.box) {
+        if (is_lead) {  // block-uniform
+            lead_solve<THREADS>(lead, st, ap, reinterpret_cast<double*>(&rowbuf[0][0]), nullptr);
+            return;
+        }
+    } else if (st->done) {
+        return;
+    }
+    const int vb = logical_block(in, pb, off);
+    const int lq = threadIdx.x;
+    const int qi = in.chunk_stride <= 0 ? vb * Q + lq
+                                        : (vb + (lq / IT_QUERIES) * in.chunk_stride) * IT_QUERIES + (lq % IT_QUERIES);
+    if ((int)threadIdx.x < 12 * CACHE_HIST) {
+        const int e = threadIdx.x / 12, j = in.iter - 1 - e;  // iteration j, most recent first
+        if (j >= 0) hist_s[j % CACHE_HIST][threadIdx.x % 12] = in.pose_hist[(size_t)j * 12 + threadIdx.x % 12];
+    }
+    // ---- what does not depend on the pose: target and hit record (48 coalesced bytes), in flight while the lead solves
+    bool valid = qi < in.n;
+    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), r0 = t4, r1 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (valid) {
+        t4 = in.tgt[qi];
+        valid = target_valid(t4.x, t4.y, t4.z, in.mode);
+    }
+    if (valid) {
+        r0 = in.rec[2 * (size_t)qi];
+        r1 = in.rec[2 * (size_t)qi + 1];
+    }
+    // ---- the pose: from the mailbox (lead launch) or from the RegState (classic launch)
+    if (threadIdx.x < 4) ctl_s[threadIdx.x] = threadIdx.x == 0 ? vb : 0;
+    __syncthreads();
+    if (lead.box) {
+        if (threadIdx.x < BOX_USED) {
+            const unsigned long long* p = box_granule(lead.box, lead.gen, vb % BOX_REPLICAS, threadIdx.x);
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == lead.gen) break;
+                if (wall_clock64() - t0 > lead.timeout_ticks) {
+                    atomicAdd(&ctl_s[3], 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned bits = (unsigned)(v & 0xffffffffull);
+            if (threadIdx.x < 12) pose_s[threadIdx.x] = __uint_as_float(bits);
+            else ctl_s[threadIdx.x - 11] = (int)bits;  // 12 -> done, 13 -> iteration
+        }
+    } else if (threadIdx.x < 12) {
+        pose_s[threadIdx.x] = st->pose[threadIdx.x];
+        if (threadIdx.x == 0) ctl_s[2] = st->iter;
+    }
+    if (threadIdx.x == 0) nmiss = 0;
+    __syncthreads();
+    if (ctl_s[3]) {  // the hand-off did not arrive within its wall-clock budget -> a loud error, not a hang
+        if (threadIdx.x == 0) atomicAdd(&st->handoff_timeouts, 1);
+        return;
+    }
+    if (ctl_s[1]) return;  // the loop is finished (block-uniform)
+    const int iter_now = in.iter;
+    // ---- phase A: the record, then the entry's candidate set (the generic kernel's tests, word for word)
+    {
+        float row[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) row[k] = 0.f;
+        if (valid) {
+            float px, py, pz;
+            transform_point(pose_s, t4.x, t4.y, t4.z, px, py, pz);
+            bool hit = false;
+            float seed_d2 = INFINITY;
+            int seed_idx = 0x7fffffff, seed_pos = -1;
+            const float margin = in.refresh_margin;
+            const int k2 = __float_as_int(r1.w), age2 = iter_now - k2;
+            if (k2 >= 0 && age2 >= 1 && age2 <= CACHE_HIST) {
+                const float dx = r0.x - px, dy = r0.y - py, dz = r0.z - pz;
+                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                float ox, oy, oz;
+                transform_point(hist_s[k2 % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
+                const float mx = px - ox, my = py - oy, mz = pz - oz;
+                const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                hit = sqrtf(d2) * 1.000001f < r0.w - delta - margin;
+                if (hit) point_to_plane_row(px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, ap.scheme, ap.sigma, row);
+            }
+            if (!hit) {
+                const int4 c = in.nn_cache[qi];
+                if (c.x >= 0) {
+                    const int k = (int)((unsigned)c.x >> CACHE_ITER_SHIFT), age = iter_now - k;
+                    int hit_pos = c.x & CACHE_POS_MASK;
+                    float4 wq = g.pts[hit_pos];
+                    float4 cq2 = wq, cq3 = wq;
+                    if (c.z >= 0) cq2 = g.pts[c.z];
+                    if (c.w >= 0) cq3 = g.pts[c.w];
+                    float dx = wq.x - px, dy = wq.y - py, dz = wq.z - pz;
+                    float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    float others2 = INFINITY;
+                    if (c.z >= 0) {
+                        dx = cq2.x - px, dy = cq2.y - py, dz = cq2.z - pz;
+                        const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (better(e2, __float_as_int(cq2.w), d2, __float_as_int(wq.w))) {
+                            others2 = fminf(others2, d2);
+                            d2 = e2;
+                            wq = cq2;
+                            hit_pos = c.z;
+                        } else {
+                            others2 = fminf(others2, e2);
+                        }
+                    }
+                    if (c.w >= 0) {
+                        dx = cq3.x - px, dy = cq3.y - py, dz = cq3.z - pz;
+                        const float e2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                        if (better(e2, __float_as_int(cq3.w), d2, __float_as_int(wq.w))) {
+                            others2 = fminf(others2, d2);
+                            d2 = e2;
+                            wq = cq3;
+                            hit_pos = c.w;
+                        } else {
+                            others2 = fminf(others2, e2);
+                        }
+                    }
+                    float outside = 0.f;
+                    if (age >= 1 && age <= CACHE_HIST) {
+                        float ox, oy, oz;  // where the target was when its neighbour was searched
+                        transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
+                        const float mx = px - ox, my = py - oy, mz = pz - oz;
+                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        outside = __int_as_float(c.y) - delta;
+                        hit = sqrtf(d2) * 1.000001f < outside - margin;
+                    }
+                    if (hit) {
+                        const float4 wn = in.normals[hit_pos];
+                        const float bound = fminf(outside, sqrtf(others2) * 0.999999f);
+                        in.rec[2 * (size_t)qi] = make_float4(wq.x, wq.y, wq.z, bound);
+                        in.rec[2 * (size_t)qi + 1] = make_float4(wn.x, wn.y, wn.z, __int_as_float(iter_now));
+                        point_to_plane_row(px, py, pz, wq.x, wq.y, wq.z, wn.x, wn.y, wn.z, ap.scheme, ap.sigma, row);
+                    } else if (in.use_cache > 1) {  // a candidate all the same: it seeds the search
+                        seed_d2 = d2;
+                        seed_idx = __float_as_int(wq.w);
+                        seed_pos = hit_pos;
+                    }
+                }
+            }
+            if (!hit) {
+                const int k = atomicAdd(&nmiss, 1);
+                if (k < LATE_MISS_CAP) {
+                    miss_p[k] = make_float4(px, py, pz, __int_as_float(lq));
+                    miss_seed[k] = make_int4(__float_as_int(seed_d2), seed_idx, seed_pos, 0);
+                } else {
+                    over_q[k - LATE_MISS_CAP] = (unsigned short)lq;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+    }
+    // ---- the searches: a whole wave per listed query, LATE_SEARCH_WAVES at a time (the first LATE_MISS_CAP with the seed
+    // phase A found, the rest — never seen in a converging loop — from their slot alone: target reloaded, no seed)
+    __syncthreads();
+    {
+        const int total = nmiss;  // block-uniform
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (total > 0 && wave < LATE_SEARCH_WAVES) {
+            int* wl = reinterpret_cast<int*>(&cellstack[0][wave * 64]);
+            for (int m = wave; m < total; m += LATE_SEARCH_WAVES) {
+                float4 mp;
+                int4 ms;
+                if (m < LATE_MISS_CAP) {
+                    mp = miss_p[m];
+                    ms = miss_seed[m];
+                } else {
+                    const int slot = (int)over_q[m - LATE_MISS_CAP];
+                    const int q = in.chunk_stride <= 0 ? vb * Q + slot
+                                                       : (vb + (slot / IT_QUERIES) * in.chunk_stride) * IT_QUERIES + (slot % IT_QUERIES);
+                    const float4 t = in.tgt[q];
+                    transform_point(pose_s, t.x, t.y, t.z, mp.x, mp.y, mp.z);
+                    mp.w = __int_as_float(slot);
+                    ms = make_int4(__float_as_int(INFINITY), 0x7fffffff, -1, 0);
+                }
+                Best b, r2, r3;
+                if (!search_rows_wave(g, mp.x, mp.y, mp.z, lane, in.max_rings, wl, __int_as_float(ms.x), ms.y, ms.z, b, &r2, &r3)) {
+                    b = search_coarse_w<64>(g, mp.x, mp.y, mp.z, lane, &cellstack[0][wave * 64], 64 * LATE_SEARCH_WAVES,
+                                            __int_as_float(ms.x), ms.y, ms.z);
+                    r2.pos = r3.pos = -1;
+                }
+                if (lane == 0) {
+                    const int slot = __float_as_int(mp.w);
+                    const int q = in.chunk_stride <= 0 ? vb * Q + slot
+                                                       : (vb + (slot / IT_QUERIES) * in.chunk_stride) * IT_QUERIES + (slot % IT_QUERIES);
+                    const bool pair = r2.pos >= 0 && b.pos >= 0, triple = pair && r3.pos >= 0;
+                    in.nn_cache[q] = make_int4(pack_cache(b.pos, iter_now),
+                                               __float_as_int(sqrtf(triple ? r3.second : (pair ? r2.second : b.second)) * 0.999999f),
+                                               pair ? r2.pos : -1, triple ? r3.pos : -1);
+                    in.rec[2 * (size_t)q + 1] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // (the first hit on the new entry forms a record)
+                    if (b.pos >= 0) {
+                        const float4 qp = g.pts[b.pos];
+                        const float4 nn = in.normals[b.pos];
+                        float row[9];
+                        point_to_plane_row(mp.x, mp.y, mp.z, qp.x, qp.y, qp.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
+}
+
+template <int MINW, int THREADS>
+__global__ __launch_bounds__(THREADS, MINW) void k_iterate_late(GridView g, IterInputs in, RegState* __restrict__ st,
+                                                                AlignParams ap, LeadArgs lead) {
+    const int lead_blocks = lead.box ? lead.solve : 0;
+    iterate_late_body<THREADS>(g, in, st, ap, lead, (int)blockIdx.x < lead_blocks, (int)blockIdx.x, lead_blocks);
+}
+
+template <int MINW, int THREADS>
+__global__ __launch_bounds__(THREADS, MINW) void k_iterate_late_batch(const IterateDesc* __restrict__ table, int nseq, int per_seq) {
+    const int p = (int)blockIdx.x;
+    int seq, pb;
+    bool is_lead = false;
+    if (p < BATCH_LEAD_SLOTS) {  // block-uniform
+        if (p >= nseq) return;
+        seq = p;
+        pb = 0;
+        is_lead = true;
+    } else {
+        seq = (p - BATCH_LEAD_SLOTS) / per_seq;
+        pb = (p - BATCH_LEAD_SLOTS) - seq * per_seq;
+    }
+    const IterateDesc d = load_descriptor(table, seq);
+    if (is_lead ? !(d.lead.box && d.lead.solve) : pb >= d.blocks) return;
+    iterate_late_body<THREADS>(d.g, d.in, d.st, d.ap, d.lead, is_lead, pb, 0);
 }
 
 // nn_cache positions of the finished registration -> original map indices, shifted by the `evicted` oldest points the
@@ -3345,6 +3679,9 @@ static int fused_cache_mode(const icp_ctx* ctx) {
     return (ctx->use_nn_cache && ctx->cache_fresh && ctx->map_m < (1 << 24)) ? ctx->use_nn_cache : 0;
 }
 
+// (may later launches of this registration use the NN cache at all?)
+static bool use_cache_possible(const icp_ctx* ctx) { return ctx->use_nn_cache && ctx->map_m < (1 << 24); }
+
 bool next_fused_launch_is_narrow(const icp_ctx* ctx) {
     // (without the NN cache — the first iteration of a registration — every query searches: one lane each with the ball
     // search, which suits the 512-query shape; the 4-lane groups of the generic path want the 128-query shape)
@@ -3391,7 +3728,7 @@ bool fused_tail_planned(icp_ctx* ctx, int iters) {
 // arguments, the grid and the instantiation.  prepare_iterate_fused updates the context's bookkeeping (iteration count,
 // parity, mailbox generation, cache state) as if the launch had happened: the caller launches — alone, or as one sequence
 // of a batched launch.
-enum FusedShape { SHAPE_LAZY11, SHAPE_LAZY6, SHAPE_TAIL, SHAPE_WIDE, SHAPE_NARROW, SHAPE_DENSE8, SHAPE_DENSE6 };
+enum FusedShape { SHAPE_LAZY11, SHAPE_LAZY6, SHAPE_TAIL, SHAPE_WIDE, SHAPE_NARROW, SHAPE_DENSE8, SHAPE_DENSE6, SHAPE_LATE };
 struct FusedLaunch {
     IterateDesc d;
     int grid = 0;       // workgroups of the single launch (the lead included)
@@ -3421,6 +3758,11 @@ static int prepare_iterate_fused(icp_ctx* ctx, bool lead_mode, int prev_rows, in
     in.tgt = ctx->tgt4.as<float4>();
     in.normals = ctx->normals.as<float4>();
     in.nn_cache = ctx->nn_cache.as<int4>();
+    in.rec = nullptr;
+    if (ctx->hit_records && use_cache_possible(ctx)) {
+        ICP_HIP(ctx, ctx->nn_rec.reserve((size_t)(n > 0 ? n : 1) * 2 * sizeof(float4)));
+        in.rec = ctx->nn_rec.as<float4>();
+    }
     in.pose_hist = ctx->pose_hist;
     // previous frame's neighbours as seeds of the first, cache-less iteration (same scan shape only)
     in.frame_seed = (!ctx->cache_fresh && ctx->frame_seed && ctx->seed_n == n && n > 0)
@@ -3513,13 +3855,17 @@ static int prepare_iterate_fused(icp_ctx* ctx, bool lead_mode, int prev_rows, in
     // dense cell alone); same super-rows, same bits
     const bool wide = narrow && ctx->iter_in_registration < ctx->wide_until && ctx->ball_search && !ctx->lazy_now;
     const int kn_lazy = ctx->lazy_now ? ctx->cfg.num_neighbors_normals + 1 : 0;
+    fl.stats = ctx->search_stats != 0;  // (dev: the instrumented instantiations exist for the tail and the two default shapes only)
+    // the late kernel: the 512-query shape once the NN cache and its hit records carry the launch ("late_from")
+    const bool late = narrow && !wide && !tail && !kn_lazy && !fl.stats && use_cache && in.rec && ctx->late_from >= 0 &&
+                      ctx->iter_in_registration >= ctx->late_from;
     fl.shape = kn_lazy == 11 ? SHAPE_LAZY11  // (normals on demand: the 512-query shape from the first iteration on, built for 256 registers)
                : kn_lazy == 6 ? SHAPE_LAZY6
                : tail         ? SHAPE_TAIL
                : wide         ? SHAPE_WIDE
+               : late         ? SHAPE_LATE
                : narrow       ? SHAPE_NARROW
                : ctx->iterate_dense ? SHAPE_DENSE8 : SHAPE_DENSE6;
-    fl.stats = ctx->search_stats != 0;  // (dev: the instrumented instantiations exist for the tail and the two default shapes only)
     fl.d.g = make_view(ctx);
     fl.d.in = in;
     fl.d.st = reg_state(ctx);
@@ -3579,6 +3925,12 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
                 hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS>), grid, dim3(IT_THREADS), 0, ctx->stream,
                                    d.g, d.in, d.st, d.ap, d.lead);
             break;
+        case SHAPE_LATE:
+            if (ctx->late_waves >= 8)
+                hipLaunchKernelGGL((k_iterate_late<8, IT_THREADS>), grid, dim3(IT_THREADS), 0, ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            else
+                hipLaunchKernelGGL((k_iterate_late<6, IT_THREADS>), grid, dim3(IT_THREADS), 0, ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            break;
         case SHAPE_DENSE8:
             hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), grid, dim3(IT_THREADS), 0, ctx->stream,
                                d.g, d.in, d.st, d.ap, d.lead);
@@ -3607,7 +3959,8 @@ int prepare_iterate_batch(icp_ctx* const* ctxs, int count, bool lead_mode, const
         FusedLaunch fl;
         const int rc = prepare_iterate_fused(ctxs[b], lead_mode, prev_rows[b], prev_quad[b], 0, fl);
         if (rc) return rc;
-        if (fl.stats || (fl.shape != SHAPE_WIDE && fl.shape != SHAPE_NARROW) || (b > 0 && (int)fl.shape != out->shape)) {
+        if (fl.stats || (fl.shape != SHAPE_WIDE && fl.shape != SHAPE_NARROW && fl.shape != SHAPE_LATE) ||
+            (b > 0 && (int)fl.shape != out->shape)) {
             ctxs[b]->error = "batched registration: the members must run the same fused shape (narrow / wide; same options)";
             return ICP_ERR_INVALID_ARGUMENT;
         }
@@ -3625,7 +3978,11 @@ int prepare_iterate_batch(icp_ctx* const* ctxs, int count, bool lead_mode, const
 int launch_iterate_batch(icp_ctx* first, const BatchedIteration& it, const void* table_dev) {
     const IterateDesc* table = reinterpret_cast<const IterateDesc*>(table_dev);
     const dim3 grid((unsigned)(BATCH_LEAD_SLOTS + it.count * it.per_seq));
-    if (it.shape == (int)SHAPE_WIDE)
+    if (it.shape == (int)SHAPE_LATE && first->late_waves >= 8)
+        hipLaunchKernelGGL((k_iterate_late_batch<8, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table, it.count, it.per_seq);
+    else if (it.shape == (int)SHAPE_LATE)
+        hipLaunchKernelGGL((k_iterate_late_batch<6, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table, it.count, it.per_seq);
+    else if (it.shape == (int)SHAPE_WIDE)
         hipLaunchKernelGGL((k_iterate_batch<4, 2 * IT_THREADS, IT_THREADS>), grid, dim3(2 * IT_THREADS), 0, first->stream, table,
                            it.count, it.per_seq);
     else

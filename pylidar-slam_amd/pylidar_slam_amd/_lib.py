@@ -125,6 +125,7 @@ EXPORTED_SYMBOLS = {
     "icp_batch_last_error": (C.c_char_p, [_P]),
     "icp_batch_set_stream": (_INT, [_P, _P]),
     "icp_batch_register_launch": (_INT, [_P, _P, _P, _INT, _INT, _P, _INT]),
+    "icp_batch_project": (_INT, [_P, _P, _P, _P]),
     "icp_batch_map_update": (_INT, [_P]),
     "icp_batch_register_end": (_INT, [_P, _P, _P, _P]),
     "icp_normal_equations_ptr": (_P, [_P]),

@@ -826,6 +826,25 @@ class IcpBatch:
         self._check(self._lib.icp_batch_register_launch(self._h, xyz, n, mem, mode,
                                                         init.ctypes.data if init is not None else None, 0))
 
+    def project(self, scans, outs):
+        """`IcpContext.project(scans[b], out=outs[b])` for every member in two launches (cuda tensors: [n_b, 3] float32 scans,
+        [3, H, W] float32 vertex maps)."""
+        if len(scans) != len(self.contexts) or len(outs) != len(self.contexts):
+            raise AssertionError("one scan and one vertex map per member")
+        self.use_torch_stream()
+        keep = []
+        for a, o in zip(scans, outs):
+            p, mem, k = _ptr_mem(a)
+            if mem != MEM_DEVICE or not (isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.float32
+                                         and o.is_contiguous()):
+                raise AssertionError("batched projection takes cuda tensors (float32, contiguous)")
+            keep.append(k)
+        xyz = (C.c_void_p * len(keep))(*[k.data_ptr() for k in keep])
+        n = (C.c_int64 * len(keep))(*[int(k.shape[0]) for k in keep])
+        vm = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        self._check(self._lib.icp_batch_project(self._h, xyz, n, vm))
+        return outs
+
     def map_update(self):
         """`map_update(None)` on every member: the pose-only update by the device-resident pose of its registration."""
         self._check(self._lib.icp_batch_map_update(self._h))

@@ -98,14 +98,15 @@ def _assert_same(single, batched, tag):
 
 
 @pytest.mark.parametrize("variant", ["default", "no_lead", "narrow_only", "live_threshold", "from_last", "host_arrays",
-                                     "ragged"])
+                                     "ragged", "hit_records", "late_kernel"])
 def test_batched_registration_equals_single_sequences(torch_cuda, variant):
     """Three sequences with different scenes, four chained frames each (registration from the previous pose, pose-only map
     update by the device-resident pose): batched vs every sequence alone on a context of its own — poses, parameters,
     per-iteration losses and steps, iteration counts and the re-expressed maps, all bit-equal.  Variants: lead launches off
     (a summing / solving launch per iteration for all members), the 512-thread shape from the first iteration, a live stop
     threshold (members stop after different numbers of iterations: a finished member idles on the device), the initial
-    guess read on the device, host arrays in, scans of different lengths in one batch."""
+    guess read on the device, host arrays in, scans of different lengths in one batch, hit records and the late kernel (both
+    off by default)."""
     kw = dict(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3)
     options, init_mode, device, lengths = {}, "pose", torch_cuda, None
     if variant == "no_lead":
@@ -121,6 +122,10 @@ def test_batched_registration_equals_single_sequences(torch_cuda, variant):
         device = None
     elif variant == "ragged":
         lengths = [32 * 1024, 20 * 1024 + 77, 9 * 1024 + 5]
+    elif variant == "hit_records":
+        options = {"hit_records": 1}
+    elif variant == "late_kernel":  # (the late kernel from the third launch on, batched: k_iterate_late_batch)
+        options = {"hit_records": 1, "late_from": 2, "wide_until": 0}
     seqs = _sequences(3, 32, 1024, 30_000, 4)
     if lengths is not None:
         seqs = [([s[:lengths[b]] for s in sc], m) for b, (sc, m) in enumerate(seqs)]
@@ -203,3 +208,26 @@ def test_two_contexts_with_chunked_launches_on_one_device(torch_cuda):
     assert a.handoff_fallbacks() == 0 and b.handoff_fallbacks() == 0
     a.close()
     b.close()
+
+
+def test_batched_projection_equals_single(torch_cuda):
+    """`icp_batch_project`: the vertex maps of three scans of different lengths in two launches = the three single
+    projections (Projector.build_projection_map, slam/common/projection.py:331-418), bit for bit — twice in a row (the
+    resolve pass leaves every member's z-buffer clean for the next frame)."""
+    from pylidar_slam_amd.engine import IcpBatch
+    kw = dict(height=32, width=1024)
+    seqs = _sequences(3, 32, 1024, 20_000, 2)
+    ctxs = [_ctx(**kw) for _ in seqs]
+    solo = [_ctx(**kw) for _ in seqs]
+    batch = IcpBatch(ctxs)
+    lengths = [32 * 1024, 17 * 1024 + 3, 1]
+    for f in range(2):
+        scans = [torch_cuda.from_numpy(sc[f][:lengths[b]].copy()).cuda() for b, (sc, _) in enumerate(seqs)]
+        outs = [torch_cuda.empty((3, 32, 1024), dtype=torch_cuda.float32, device="cuda") for _ in seqs]
+        batch.project(scans, outs)
+        for b in range(3):
+            ref = solo[b].project(scans[b])
+            assert torch_cuda.equal(outs[b], ref), (f, b)
+    batch.close()
+    for c in ctxs + solo:
+        c.close()

@@ -401,6 +401,12 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 # normals on demand inside the fused kernel (by default only where the map dwarfs the scan) / never
                 # (compared with `no_carry`: a normal estimated on first touch in a LATER frame is estimated from the re-expressed
                 # points, where the default schedule has carried the first frame's estimate over by rotation: rounding apart)
+                # round 6 (both off by default): hit records / the late kernel from the fourth launch on, from the second, in
+                # its 80-register build, behind the 512-thread shape
+                "hit_records": {"hit_records": 1}, "late_kernel": {"hit_records": 1, "late_from": 3},
+                "late_from_1": {"hit_records": 1, "late_from": 1},
+                "late_80_registers": {"hit_records": 1, "late_from": 3, "late_waves": 6},
+                "late_never_wide": {"hit_records": 1, "late_from": 1, "wide_until": 0},
                 "no_carry": {"carry_normals": 0}, "lazy_fused": {"lazy_fused": 2, "carry_normals": 0},
                 # (the stragglers of the eager normals on the map stream instead of inside the estimating launch)
                 "no_carry_tail_stream": {"carry_normals": 0, "normals_tail_stream": 1},
