@@ -72,6 +72,7 @@ after two warm-up frames (~26 s of CPU work), the kd-tree build timed separately
 `ICPFrameToModel` timed through the shims in the build container is kept as context in profiles/ (tools/time_reference.py).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -94,7 +95,7 @@ MIN_STEPS_FOR_HEADLINE = 50  # >= 50 timed frames
 # "profile_rotate").  Round 3 bracketed all 20 launches of every 9th frame: 3 frames of a 20-step run, each ~0.15 ms slower
 # for it, and a mean that depended on which frames of the 14-frame trajectory they were.
 PROFILE_EVERY = 1
-LOOP_PERIOD = 96
+LOOP_PERIOD = 96  # (= pylidar_slam_amd.synthetic.LOOP_PERIOD)
 SYNC_STEP = os.environ.get("BENCH_SYNC_STEP", "0") == "1"  # A/B switch: host round trip between registration and map update
 
 
@@ -138,10 +139,11 @@ def parse():
                     help="after the headline (single process, --sequences-per-gpu 1 only): S independent sequences on S "
                          "streams of this GPU for the same number of steps, reported as `throughput` in the JSON line "
                          "(0: skip; also skipped with --no-cpu-baseline, the switch of the developer A/B runs)")
-    ap.add_argument("--batched-leg", default="4,8,16", metavar="B[,B..]",
+    ap.add_argument("--batched-leg", default="4,8,16,32x4", metavar="B[xG][,B[xG]..]",
                     help="after the headline (single process, one sequence): `throughput_batched` — B sequences per launch "
-                         "(icp_batch_*) for each listed B, 200 timed steps per sequence in three windows (empty string: skip; "
-                         "also skipped with --no-cpu-baseline)")
+                         "(icp_batch_*) for each listed B, or with `xG` B sequences as G batches of B / G on G streams (one host "
+                         "thread); 200 timed steps per sequence in three windows (empty string: skip; also skipped with "
+                         "--no-cpu-baseline)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (icp_set_option), repeatable — for A/B runs")
     ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
@@ -165,38 +167,18 @@ def parse():
 
 def make_workload(seq: int, trajectory: str, frames_needed: int):
     """(scans: dict frame -> [N,3] f32, ground-truth poses, the fixed 100k-point map in the frame of `start`, the order
-    in which the frames are visited, start).  No tracked scan contributes to the map (except `pingpong_r01`)."""
-    from pylidar_slam_amd.synthetic import (SceneConfig, loop_trajectory, make_fixed_map, make_sequence, ray_directions,
-                                            render_scan, rotate_rows)
-    seed = 1234 + 1000 * seq
+    in which the frames are visited, start).  No tracked scan contributes to the map (except `pingpong_r01`).
+    (pylidar_slam_amd.synthetic.make_c2_workload: numpy only, so that worker processes can generate sequences.)"""
+    from pylidar_slam_amd.synthetic import make_c2_workload
+    return make_c2_workload(seq, trajectory, frames_needed)
 
-    def into_frame(model, poses, src, dst):
-        rel = np.linalg.inv(poses[dst]) @ poses[src]
-        return (rotate_rows(model.astype(np.float64), rel[:3, :3]) + rel[:3, 3]).astype(np.float32)  # (BLAS-free: same bits on every host)
 
-    if trajectory == "pingpong":
-        # half-steps: even poses = the mapping pass (never tracked), odd poses = the tracked sequence
-        cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2, yaw_rate=0.005)
-        scans, poses = make_sequence(cfg, 16)
-        even = list(range(0, 16, 2))
-        model = make_fixed_map(cfg, [scans[f] for f in even], poses[even], ref_frame=0, num_points=100_000)
-        order = list(range(3, 16, 2)) + list(range(13, 0, -2))  # 3,5,..,15,13,..,1 then repeats
-        return {f: scans[f] for f in range(1, 16, 2)}, poses, into_frame(model, poses, 0, 1), order, 1
-    if trajectory == "pingpong_r01":
-        cfg = SceneConfig(height=64, width=2048, seed=seed)
-        scans, poses = make_sequence(cfg, 8)
-        model = make_fixed_map(cfg, scans, poses, ref_frame=0, num_points=100_000)
-        return dict(enumerate(scans)), poses, model, list(range(1, 8)) + list(range(6, -1, -1)), 0
-    # loop: 192 half-steps around the circuit; odd poses tracked (96, 0.4 m apart), 8 even poses mapped
-    cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2)
-    poses = loop_trajectory(cfg, 2 * LOOP_PERIOD)
-    order = list(range(3, 2 * LOOP_PERIOD, 2)) + [1]
-    map_frames = list(range(0, 2 * LOOP_PERIOD, 2 * LOOP_PERIOD // 8))
-    dirs = ray_directions(cfg)
-    tracked = order[:min(frames_needed, LOOP_PERIOD)]
-    scans = {f: render_scan(cfg, poses[f], f, dirs) for f in sorted(set(tracked) | set(map_frames))}
-    model = make_fixed_map(cfg, [scans[f] for f in map_frames], poses[map_frames], ref_frame=0, num_points=100_000)
-    return {f: scans[f] for f in tracked}, poses, into_frame(model, poses, 0, 1), order, 1
+def make_workloads(seqs, trajectory: str, frames_needed: int):
+    """Several sequences' workloads, generated by worker processes (one sequence each, single-threaded numpy: the bits of the
+    sequential generation; BENCH_WORKLOAD_WORKERS=1 generates one after the other on this thread)."""
+    from pylidar_slam_amd.synthetic import make_c2_workloads
+    workers = int(os.environ.get("BENCH_WORKLOAD_WORKERS", str(min(16, os.cpu_count() or 1))))
+    return make_c2_workloads(seqs, trajectory, frames_needed, workers=workers)
 
 
 class Tracker:
@@ -412,7 +394,17 @@ def throughput_leg(args, S, device_index, main_tr, workloads=None):
             "max_pose_error_vs_ground_truth_m": err, "max_pose_error_by_sequence_m": err_by_sequence}
 
 
-def batched_leg(args, device_index, workloads, sizes=(4, 8, 16), steps=200, warm=20, windows=3):
+def parse_batch_sizes(text):
+    """"4,8,16,32x4" -> [(4, 1), (8, 1), (16, 1), (32, 4)]: B sequences in ONE batch, or in `x G` batches of B / G sequences on G
+    streams."""
+    out = []
+    for item in [v.strip() for v in text.split(",") if v.strip()]:
+        b, _, g = item.partition("x")
+        out.append((int(b), int(g) if g else 1))
+    return out
+
+
+def batched_leg(args, device_index, workloads, sizes=((4, 1), (8, 1), (16, 1)), steps=200, warm=20, windows=3):
     """B independent sequences advanced by ONE launch per ICP iteration (`icp_batch_*`: the members' arguments in a
     descriptor table in device memory, a lead workgroup per sequence, one host thread, one stream) — SURVEY §8(d): "HBM-bound
     operation is only approachable by batching many independent registrations per launch".  Every sequence is the headline's
@@ -433,23 +425,33 @@ def batched_leg(args, device_index, workloads, sizes=(4, 8, 16), steps=200, warm
            "frame": "projection + 20-iteration registration (constant-velocity guess) + pose to the host + pose-only map "
                     "update / grid rebuild, per sequence; one launch per ICP iteration for all B sequences", "by_B": {}}
     best = None
-    for B in sizes:
+    for B, groups in sizes:
         if B > len(trackers):
             continue
         trs = trackers[:B]
-        batch = IcpBatch([t.ctx for t in trs])
+        # `groups` batches of B / groups sequences, each on a stream of its own, driven by this one thread: while the leads of one
+        # batch's launch solve, the workgroups of the other's stream
+        groups = max(1, min(groups, B))
+        parts = [trs[g::groups] for g in range(groups)]
+        batches = [IcpBatch([t.ctx for t in part]) for part in parts]
+        streams = [torch.cuda.Stream(device=torch.device("cuda", device_index)) for _ in parts] if groups > 1 else [None]
 
         def run(k):
             for _ in range(k):
-                frames = [t.order[t.cursor % len(t.order)] for t in trs]
-                scans = [t.scans[f] for t, f in zip(trs, frames)]
-                batch.project(scans, [t.vmap for t in trs])
-                batch.register_launch(scans, [t.last for t in trs] if args.init == "cv" else None)
-                batch.map_update()
-                for t, f, r in zip(trs, frames, batch.register_end()):
-                    t._account(r, f, t.prev)
-                    t.prev = f
-                    t.cursor += 1
+                pending = []
+                for part, batch, stream in zip(parts, batches, streams):
+                    frames = [t.order[t.cursor % len(t.order)] for t in part]
+                    scans = [t.scans[f] for t, f in zip(part, frames)]
+                    with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                        batch.project(scans, [t.vmap for t in part])
+                        batch.register_launch(scans, [t.last for t in part] if args.init == "cv" else None)
+                        batch.map_update()
+                    pending.append((part, batch, frames))
+                for part, batch, frames in pending:
+                    for t, f, r in zip(part, frames, batch.register_end()):
+                        t._account(r, f, t.prev)
+                        t.prev = f
+                        t.cursor += 1
 
         run(warm)
         torch.cuda.synchronize()
@@ -459,19 +461,22 @@ def batched_leg(args, device_index, workloads, sizes=(4, 8, 16), steps=200, warm
             run(steps)
             torch.cuda.synchronize()
             rates.append(B * steps / (time.perf_counter() - t0))
-        batch.close()
+        for batch in batches:
+            batch.close()
         med = sorted(rates)[len(rates) // 2]
         rec = {"value": med, "windows_scans_per_s": rates, "ms_per_step": B * 1e3 / med, "ms_per_frame_amortised": 1e3 / med,
                "whole_path_algorithmic_GBps": frame_bytes * med / 1e9, "whole_path_frac_of_hbm_peak": frame_bytes * med / HBM_PEAK,
+               "batches_on_streams_of_their_own": groups,
                "max_pose_error_by_sequence_m": [t.max_err for t in trs],
                "handoff_fallbacks": sum(t.ctx.handoff_fallbacks() for t in trs)}
-        out["by_B"][str(B)] = rec
+        out["by_B"][f"{B}x{groups}" if groups > 1 else str(B)] = rec
         if best is None or med > best[1]:
-            best = (B, med, rec)
+            best = (B, med, rec, groups)
     for t in trackers:
         t.close()
     if best is not None:
-        out.update({"value": best[1], "sequences_per_launch": best[0],
+        out.update({"value": best[1], "sequences": best[0], "batches_on_streams_of_their_own": best[3],
+                    "sequences_per_launch": best[0] // best[3],
                     "whole_path_frac_of_hbm_peak": best[2]["whole_path_frac_of_hbm_peak"]})
     return out
 
@@ -942,8 +947,8 @@ def main():
         print(json.dumps({"odometry_loop": odometry_loop_leg(args, local_rank)}))
         return
     if args.leg == "throughput_batched":
-        sizes = tuple(int(v) for v in args.batched_leg.split(",") if v.strip())
-        shared = [make_workload(101 + j, args.trajectory, 300) for j in range(max(sizes))]
+        sizes = parse_batch_sizes(args.batched_leg)
+        shared = make_workloads([101 + j for j in range(max(b for b, _ in sizes))], args.trajectory, 300)
         print(json.dumps({"throughput_batched": batched_leg(args, local_rank, shared, sizes=sizes,
                                                             steps=max(20, args.steps), warm=max(5, args.warmup))}))
         return
@@ -1058,10 +1063,11 @@ def main():
     # (2470 instead of 3430 scans/s, measured)
     through = batched = None
     if rank == 0 and world == 1 and S == 1 and not sharded and not args.no_cpu_baseline:
-        sizes = tuple(int(v) for v in args.batched_leg.split(",") if v.strip())
-        want = max([args.throughput_leg - 1 if args.throughput_leg > 1 else 0] + list(sizes))
-        # the sequences of both throughput legs: generated here, on the main thread, one after the other (see SequenceThread)
-        shared = [make_workload(101 + j, args.trajectory, 300) for j in range(want)]
+        sizes = parse_batch_sizes(args.batched_leg)
+        want = max([args.throughput_leg - 1 if args.throughput_leg > 1 else 0] + [b for b, _ in sizes])
+        # the sequences of both throughput legs: generated by worker PROCESSES, one sequence each (see SequenceThread: threads
+        # of this process were found not to generate the same bits from run to run)
+        shared = make_workloads([101 + j for j in range(want)], args.trajectory, 300)
         if args.throughput_leg > 1:
             through = throughput_leg(args, args.throughput_leg, local_rank, main_tr, workloads=shared)
             main_tr.ctx.set_option("lead_solve", 1)  # (the leg's schedule knobs: back to the defaults)

@@ -13,7 +13,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 __all__ = ["SceneConfig", "ray_directions", "pose_matrix", "trajectory", "render_scan", "make_sequence",
-           "make_fixed_map", "rotate_rows"]
+           "make_fixed_map", "rotate_rows", "make_c2_workload", "make_c2_workloads", "LOOP_PERIOD"]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -220,3 +220,94 @@ def make_fixed_map(cfg: SceneConfig, scans, poses, ref_frame: int, num_points: i
         raise ValueError(f"only {cloud.shape[0]} candidate map points (< {num_points}); add scans or shrink voxel")
     sel = np.sort(rng.choice(cloud.shape[0], size=num_points, replace=False))
     return cloud[sel].astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The benchmark's C2 workload (bench.py): scans to track, ground truth, a fixed 100 000-point map none of the
+# tracked scans is part of.  Lives here — numpy only — so that several sequences can be generated by worker PROCESSES.
+# ----------------------------------------------------------------------------------------------------------------------
+LOOP_PERIOD = 96
+
+
+def make_c2_workload(seq: int, trajectory_name: str, frames_needed: int):
+    """(scans: dict frame -> [N,3] f32, ground-truth poses, the fixed 100k-point map in the frame of `start`, the order
+    in which the frames are visited, start).  No tracked scan contributes to the map (except `pingpong_r01`)."""
+    seed = 1234 + 1000 * seq
+
+    def into_frame(model, poses, src, dst):
+        rel = np.linalg.inv(poses[dst]) @ poses[src]
+        return (rotate_rows(model.astype(np.float64), rel[:3, :3]) + rel[:3, 3]).astype(np.float32)  # (BLAS-free: same bits on every host)
+
+    if trajectory_name == "pingpong":
+        # half-steps: even poses = the mapping pass (never tracked), odd poses = the tracked sequence
+        cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2, yaw_rate=0.005)
+        scans, poses = make_sequence(cfg, 16)
+        even = list(range(0, 16, 2))
+        model = make_fixed_map(cfg, [scans[f] for f in even], poses[even], ref_frame=0, num_points=100_000)
+        order = list(range(3, 16, 2)) + list(range(13, 0, -2))  # 3,5,..,15,13,..,1 then repeats
+        return {f: scans[f] for f in range(1, 16, 2)}, poses, into_frame(model, poses, 0, 1), order, 1
+    if trajectory_name == "pingpong_r01":
+        cfg = SceneConfig(height=64, width=2048, seed=seed)
+        scans, poses = make_sequence(cfg, 8)
+        model = make_fixed_map(cfg, scans, poses, ref_frame=0, num_points=100_000)
+        return dict(enumerate(scans)), poses, model, list(range(1, 8)) + list(range(6, -1, -1)), 0
+    # loop: 192 half-steps around the circuit; odd poses tracked (96, 0.4 m apart), 8 even poses mapped
+    cfg = SceneConfig(height=64, width=2048, seed=seed, step=0.2)
+    poses = loop_trajectory(cfg, 2 * LOOP_PERIOD)
+    order = list(range(3, 2 * LOOP_PERIOD, 2)) + [1]
+    map_frames = list(range(0, 2 * LOOP_PERIOD, 2 * LOOP_PERIOD // 8))
+    dirs = ray_directions(cfg)
+    tracked = order[:min(frames_needed, LOOP_PERIOD)]
+    scans = {f: render_scan(cfg, poses[f], f, dirs) for f in sorted(set(tracked) | set(map_frames))}
+    model = make_fixed_map(cfg, [scans[f] for f in map_frames], poses[map_frames], ref_frame=0, num_points=100_000)
+    return {f: scans[f] for f in tracked}, poses, into_frame(model, poses, 0, 1), order, 1
+
+
+def make_c2_workloads(seqs, trajectory_name: str, frames_needed: int, workers: int = 0):
+    """`make_c2_workload` for several sequences.  workers > 1: by that many worker PROCESSES at a time (`python -m
+    pylidar_slam_amd.synthetic ...`: fresh interpreters that import numpy and this module only — no fork of a process that
+    holds a GPU context, no re-import of the caller's main module; every worker is single-threaded numpy, so the bits are
+    those of the sequential generation — bench.py found THREADS of one process not to be, on a 256-thread host, while the
+    generator still called BLAS).  A worker that fails has its sequence generated here."""
+    seqs = list(seqs)
+    out = {}
+    if workers > 1 and len(seqs) > 1:
+        import os
+        import pickle
+        import subprocess
+        import sys
+        import tempfile
+        pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=pkg_parent + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
+                   OPENBLAS_NUM_THREADS="1")
+        with tempfile.TemporaryDirectory(prefix="c2_workloads_") as tmp:
+            todo, running = list(seqs), []
+            while todo or running:
+                while todo and len(running) < workers:
+                    sq = todo.pop(0)
+                    path = os.path.join(tmp, f"{sq}.pkl")
+                    try:
+                        proc = subprocess.Popen([sys.executable, "-m", "pylidar_slam_amd.synthetic", str(sq), trajectory_name,
+                                                 str(frames_needed), path], env=env, stdout=subprocess.DEVNULL,
+                                                stderr=subprocess.DEVNULL)
+                        running.append((sq, proc, path))
+                    except Exception:
+                        pass  # (generated below)
+                if not running:
+                    break
+                sq, proc, path = running.pop(0)
+                try:
+                    if proc.wait(timeout=600) == 0:
+                        with open(path, "rb") as f:
+                            out[sq] = pickle.load(f)
+                except Exception:
+                    proc.kill()
+    return [out[sq] if sq in out else make_c2_workload(sq, trajectory_name, frames_needed) for sq in seqs]
+
+
+if __name__ == "__main__":  # worker of make_c2_workloads: SEQ TRAJECTORY FRAMES OUTPATH
+    import pickle
+    import sys
+    _seq, _traj, _frames, _path = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    with open(_path, "wb") as _f:
+        pickle.dump(make_c2_workload(_seq, _traj, _frames), _f, protocol=pickle.HIGHEST_PROTOCOL)
