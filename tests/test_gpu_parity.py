@@ -534,6 +534,56 @@ def test_timed_out_handoff_finishes_on_per_iteration_launches(torch_cuda):
             assert np.array_equal(mp, got["plain"][1])
 
 
+def test_device_side_initial_pose_tensor_into_the_plugin(torch_cuda):
+    """BASELINE configs[4] hand-off (VERDICT r5 Missing #7): the initial pose comes from a network on the device — a cuda
+    tensor, [1,4,4], bfloat16 — through `data_dict["init_rpose"]` (slam/initialization.py:222-283 -> icp_odometry.py:147-154).
+    The plugin must take it (rounded to what bfloat16 holds) exactly as it takes the same matrix as a host float32 array."""
+    from pylidar_slam_amd.odometry import MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector
+    from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
+    scans, gt = make_sequence(SceneConfig(height=32, width=1024), 3)
+    guess = (np.linalg.inv(gt[0]) @ gt[1]).astype(np.float32)
+    as_bf16 = torch_cuda.from_numpy(guess).cuda().to(torch_cuda.bfloat16).reshape(1, 4, 4)
+    rounded = as_bf16.to(torch_cuda.float32).cpu().numpy().reshape(4, 4)
+    poses = []
+    for init in (as_bf16, rounded):
+        cfg = MI355XICPConfig(max_num_alignments=6, threshold_delta_pose=0.0, data_key="numpy_pc")
+        odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(32, 1024), device=torch_cuda.device("cuda:0"))
+        odo.init()
+        odo.process_next_frame({"numpy_pc": scans[0]})
+        d = {"numpy_pc": scans[1], "init_rpose": init}
+        odo.process_next_frame(d)
+        poses.append(d["odometry_pose"].copy())
+        odo.ctx.close()
+    assert np.array_equal(poses[0], poses[1])
+    assert np.linalg.norm(poses[0][:3, 3] - guess[:3, 3]) < 0.02  # (converging: six iterations from a bf16-rounded guess)
+
+
+def test_plugin_warns_about_handoff_fallbacks(torch_cuda):
+    """VERDICT r5 Weak #14: a hand-off that times out is repaired silently by the library (`icp_handoff_fallbacks`); the plugin
+    says so once per sequence (at the next `init()` / `get_relative_poses()`)."""
+    import warnings
+    from pylidar_slam_amd.odometry import MI355XICPConfig, MI355XICPFrameToModel, SphericalProjector
+    from pylidar_slam_amd.synthetic import SceneConfig, make_sequence
+    scans, _ = make_sequence(SceneConfig(height=32, width=1024), 3)
+    cfg = MI355XICPConfig(max_num_alignments=8, threshold_delta_pose=0.0, data_key="numpy_pc")
+    odo = MI355XICPFrameToModel(cfg, projector=SphericalProjector(32, 1024), device=torch_cuda.device("cuda:0"))
+    odo.init()
+    odo.ctx.set_option("lead_timeout_ms", 1.0e-5)  # (one tick of the wall clock: the first lead launch gives up)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for s in scans:
+            odo.process_next_frame({"numpy_pc": s})
+        assert odo.ctx.handoff_fallbacks() >= 1
+        rel = odo.get_relative_poses()
+        assert rel is not None and rel.shape[0] == 3
+        said = [w for w in caught if "timed-out pose hand-off" in str(w.message)]
+        assert len(said) == 1, [str(w.message) for w in caught]
+        odo.get_relative_poses()
+        odo.init()  # nothing new since: said once
+        assert len([w for w in caught if "timed-out pose hand-off" in str(w.message)]) == 1
+    odo.ctx.close()
+
+
 def test_carried_normals_equal_reestimated_ones(torch_cuda):
     """Option "carry_normals" (default 1): a pose-only map update rotates the normals the grid holds with the points instead
     of clearing them; 0 is the reference's schedule (local_map.py:365-369: every build_model zeroes the cache, the next
