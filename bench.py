@@ -416,14 +416,21 @@ def batched_leg(args, device_index, workloads, sizes=((4, 1), (8, 1), (16, 1)), 
     from pylidar_slam_amd.engine import IcpBatch
     trackers = [Tracker(args, 100 + j, args.trajectory, warm + steps, device_index, workload=w)
                 for j, w in enumerate(workloads)]
+    # schedule knobs of this mode (as the 4-thread leg has its own): the 512-thread shape from the first iteration (two workgroups
+    # per CU: with B sequences in a launch the 1024-thread shape's one-per-CU residency only hurts — 6216 vs 5526 scans/s at B = 8)
+    # and the grid builds over cell lists (B whole tables cleared and scanned per step otherwise: 6865 vs 6657 at B = 16)
+    leg_options = {"wide_until": 0.0, "cell_lists": 1.0}
     for opt in [o for o in os.environ.get("BENCH_BATCH_OPTIONS", "").split(",") if o]:  # (developer A/B runs of this leg only)
-        for t in trackers:
-            t.ctx.set_option(opt.split("=")[0], float(opt.split("=")[1]))
+        leg_options[opt.split("=")[0]] = float(opt.split("=")[1])
+    for t in trackers:
+        for name, value in leg_options.items():
+            t.ctx.set_option(name, value)
     carried = not any(o.replace(" ", "") in ("carry_normals=0", "carry_normals=0.0") for o in args.option)
     frame_bytes = args.iters * BYTES_PER_POINT_ITER * 131072 + 28 * 131072 + (48 + 28 + (0 if carried else 132)) * 100_000
     out = {"unit": "scans/s", "steps_per_sequence_per_window": steps, "windows": windows, "warmup_steps": warm,
            "frame": "projection + 20-iteration registration (constant-velocity guess) + pose to the host + pose-only map "
-                    "update / grid rebuild, per sequence; one launch per ICP iteration for all B sequences", "by_B": {}}
+                    "update / grid rebuild, per sequence; one launch per ICP iteration for all B sequences",
+           "options": [f"{k}={v:g}" for k, v in leg_options.items()], "by_B": {}}
     best = None
     for B, groups in sizes:
         if B > len(trackers):

@@ -128,7 +128,10 @@ int icp_synchronize(icp_ctx* ctx);
  *   "frame_seed" 0 | 1 (1)          the neighbours of the last frame seed the first iteration of the next one
  *   "exchange_timeout_ms" (5000)    how long a rank waits for its peers inside the in-library exchange
  *   "knn_rings" n (-1: auto), "knn_lanes" 2 | 4 (4), "target_occupancy" points per cell (16), "search_stats" 0 | 1 | 2 | 3 | 4 (0; dev: 3 / 4 = 1 / 2 + a per-workgroup dump on stderr)
- *   "scan_poll_limit" n (2^20)      grid build: polls of a predecessor tile's descriptor before a tile of the one-launch table
+ *   "cell_lists" 0 | 1 (0)          grid build: the table slots a build claims are listed; the next build empties those slots, not the
+ *                                   whole table, and the cells' starts are scanned over the lists instead of over every slot
+ *                                   (measured: slower for one map per launch, faster for a batch of maps — DESIGN §0)
+ *   "scan_poll_limit" n (2^20)      grid build (without "cell_lists"): polls of a predecessor tile's descriptor before a tile of the one-launch table
  *                                   scan computes its prefix from the table itself (a safeguard; tests set 0 to walk that path)
  *   "prune_guard" m (0.002)         searches scan neighbour cells whose box is within m metres of the best distance instead of
  *                                   pruning them (the gap of a pruned cell bounds the cache's L: a guard keeps L off the best)

@@ -365,7 +365,8 @@ void icp_destroy(icp_ctx* ctx) {
                             &ctx->csorted,    &ctx->crank_of,  &ctx->pos_of_orig, &ctx->dbg_counts, &ctx->nn_cache,  &ctx->pm_v,
                             &ctx->pm_n,       &ctx->pm_mv,      &ctx->pm_mn,      &ctx->pm_z,      &ctx->pm_tmp,
                             &ctx->vox_out,    &ctx->seed_orig,  &ctx->scan_desc,  &ctx->posebox,   &ctx->pose_hist_buf,
-                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows, &ctx->normals_tail, &ctx->nn_rec};
+                            &ctx->hood,       &ctx->normals_carry, &ctx->tail_rows, &ctx->normals_tail, &ctx->nn_rec,
+                            &ctx->cell_list[0][0], &ctx->cell_list[0][1], &ctx->cell_list[1][0], &ctx->cell_list[1][1], &ctx->cell_counts};
     for (DeviceBuffer* b : bufs) b->release();
     for (auto& r : ctx->rslot) {
         if (r.host) (void)hipHostFree(r.host);
@@ -446,6 +447,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "far_min") ctx->far_min = iv < 0 ? 0 : (int)iv;
     else if (k == "far_max") ctx->far_max = iv < 0 ? 0 : (iv > 512 ? 512 : (int)iv);
     else if (k == "insert_by_cell") ctx->insert_by_cell = iv != 0 ? 1 : 0;
+    else if (k == "cell_lists") ctx->cell_lists = iv != 0 ? 1 : 0;
     else if (k == "normals_tail_stream") ctx->normals_tail_stream = iv != 0 ? 1 : 0;
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);

@@ -242,26 +242,40 @@ int compact_valid_rows(icp_ctx* ctx, const float* xyz, int64_t n, bool skip_null
 // + (carry_m > 0: a pose-only update, option "carry_normals") the normals the old grid holds, rotated into the new frame
 // like the points (n' = R^-1 n; re-normalised, so that a thousand pose-only updates in a row leave unit vectors) and filed
 // by ORIGINAL index: the scatter of this build puts them at the points' new cell-sorted positions instead of zeros.
+// CELL LISTS (round 6; VERDICT r3-r5: "k_grid_scan walks a 1.25 M-slot table to find 8 k occupied cells"): every table slot a
+// build claims is appended to a list (k_grid_insert2: fine and coarse level apart, one counter update per WORKGROUP); the next
+// build empties exactly those slots instead of the whole table, and the prefix sums that turn the cells' counts into their
+// starts run over the lists (k_cells_scan) — 9 000 entries instead of 262 144 slots at the headline sizes.  Two list sets in
+// alternation (`lists.prev` was written by the previous build).  The ORDER of the cells in the cell-sorted arrays becomes the
+// order of the claims — as immaterial as the order of the points inside a cell already was: every consumer breaks ties on the
+// original index, every sum over a neighbourhood is order-independent.
 __device__ __forceinline__ void grid_clear_body(GridEntry* __restrict__ table, unsigned int size, const int4* __restrict__ nn_cache,
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
                              int* __restrict__ seed, const MapMoveJob& move, int* __restrict__ scan_ticket,
                              unsigned long long* __restrict__ hood_used, const float4* __restrict__ old_normals,
-                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry, const unsigned bx) {
+                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry, const CellLists& lists,
+                             const unsigned bx) {
     __shared__ float T[16];
     if (bx == 0 && threadIdx.x == 0) {
         *scan_ticket = 0;               // the tile numbers of this build's k_grid_scan
         if (hood_used) *hood_used = 0;  // the list space k_hood_build hands out (a memset launch of its own cost 5 us)
+        if (lists.counts) lists.counts[0] = lists.counts[1] = 0;  // this build's lists start empty (nobody reads them here)
     }
     const long long first = (long long)bx * blockDim.x;
     const bool moves = first < move.m;  // block-uniform (a carry job comes with a move job over the same points)
     if (moves && threadIdx.x == 0) map_move_prepare(move, T);
     unsigned int i = bx * blockDim.x + threadIdx.x;
-    if (i < size) {
+    {
         GridEntry e;
         e.key = GRID_EMPTY;
         e.start = 0;
         e.count = 0;
-        table[i] = e;
+        if (lists.prev_counts) {  // the slots the previous build claimed, nothing else
+            if ((int)i < lists.prev_counts[0]) table[lists.prev_fine[i]] = e;
+            if ((int)i < lists.prev_counts[1]) table[lists.prev_coarse[i]] = e;
+        } else if (i < size) {
+            table[i] = e;
+        }
     }
     if ((int)i < seed_n) {
         const int x = nn_cache[i].x, pos = x & 0xffffff;  // (.x = position | iteration << 24, search.hip)
@@ -295,9 +309,9 @@ __global__ void k_grid_clear(GridEntry* __restrict__ table, unsigned int size, c
                              const float4* __restrict__ old_pts, int seed_n, int old_m, int evicted,
                              int* __restrict__ seed, MapMoveJob move, int* __restrict__ scan_ticket,
                              unsigned long long* __restrict__ hood_used, const float4* __restrict__ old_normals,
-                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry) {
+                             const int* __restrict__ old_nflag, int carry_m, float4* __restrict__ carry, CellLists lists) {
     grid_clear_body(table, size, nn_cache, old_pts, seed_n, old_m, evicted, seed, move, scan_ticket, hood_used, old_normals,
-                    old_nflag, carry_m, carry, blockIdx.x);
+                    old_nflag, carry_m, carry, lists, blockIdx.x);
 }
 
 // rows[cell][c] = (start, count) of the neighbour cell c of every occupied cell (0,0 if that neighbour is empty)
@@ -341,11 +355,15 @@ __device__ inline void build_rows_part(const GridEntry* __restrict__ table, unsi
 // ---------------------------------------------------------------------------------------------------------------------
 // (the occupied cells are counted by the scan, not here: one atomic counter for ten thousand claims was two thirds of the
 // insertion kernel — 31 us)
-__device__ inline unsigned int grid_claim(GridEntry* __restrict__ table, unsigned int mask, unsigned long long key) {
+// *fresh: this call put the key into an empty slot (exactly one caller per key and build sees that)
+__device__ inline unsigned int grid_claim(GridEntry* __restrict__ table, unsigned int mask, unsigned long long key, bool* fresh) {
     unsigned int slot = hash_cell(key) & mask;
     while (true) {
         unsigned long long old = atomicCAS(&table[slot].key, GRID_EMPTY, key);
-        if (old == GRID_EMPTY || old == key) break;
+        if (old == GRID_EMPTY || old == key) {
+            *fresh = old == GRID_EMPTY;
+            break;
+        }
         slot = (slot + 1) & mask;
     }
     return slot;
@@ -387,7 +405,7 @@ __device__ __forceinline__ void grid_insert2_body(const float* __restrict__ xyz,
                                GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
                                int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
                                const float4* __restrict__ old_pts, int old_m, int evicted, int kept,
-                               int* __restrict__ visit, const unsigned bx) {
+                               int* __restrict__ visit, const CellLists& lists, const unsigned bx) {
     // (with `old_pts` the four outputs are indexed by THREAD and visit[thread] names the point, -1: none — the scatter walks
     // the same order, so that its stores by new position are clustered as well)
     const int t = bx * blockDim.x + threadIdx.x;
@@ -415,10 +433,29 @@ __device__ __forceinline__ void grid_insert2_body(const float* __restrict__ xyz,
     wave_group_by_key(ckey, active, cleader, crank, csize);
     const int lane = threadIdx.x & 63;
     int slot = 0, base = 0, cslot = 0, cbase = 0;
-    if (active && leader == lane) slot = (int)grid_claim(table, tsize - 1, key);
-    if (active && cleader == lane) cslot = (int)(tsize + grid_claim(table + tsize, tsize - 1, ckey));
+    bool fresh = false, cfresh = false;
+    if (active && leader == lane) slot = (int)grid_claim(table, tsize - 1, key, &fresh);
+    if (active && cleader == lane) cslot = (int)(tsize + grid_claim(table + tsize, tsize - 1, ckey, &cfresh));
     if (active && leader == lane) base = atomicAdd(&table[slot].count, size);  // the two requests are in flight together
     if (active && cleader == lane) cbase = atomicAdd(&table[cslot].count, csize);
+    if (lists.counts) {
+        // the slots this workgroup has just claimed, appended to the build's cell lists: collected in LDS, ONE counter update
+        // per workgroup and level (a counter update per claim was two thirds of an earlier insertion kernel)
+        __shared__ int nf_s, nc_s, bf_s, bc_s;
+        __shared__ int lf_s[256], lc_s[256];
+        if (threadIdx.x == 0) nf_s = nc_s = 0;
+        __syncthreads();
+        if (fresh) lf_s[atomicAdd(&nf_s, 1)] = slot;
+        if (cfresh) lc_s[atomicAdd(&nc_s, 1)] = cslot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bf_s = nf_s ? atomicAdd(&lists.counts[0], nf_s) : 0;
+            bc_s = nc_s ? atomicAdd(&lists.counts[1], nc_s) : 0;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nf_s) lists.fine[bf_s + threadIdx.x] = lf_s[threadIdx.x];
+        if ((int)threadIdx.x < nc_s) lists.coarse[bc_s + threadIdx.x] = lc_s[threadIdx.x];
+    }
     slot = __shfl(slot, leader, 64);
     base = __shfl(base, leader, 64);
     cslot = __shfl(cslot, cleader, 64);
@@ -444,9 +481,67 @@ __global__ void k_grid_insert2(const float* __restrict__ xyz, int m, float inv_h
                                GridEntry* __restrict__ table, unsigned int tsize, int* __restrict__ slot_of,
                                int* __restrict__ rank_of, int* __restrict__ cslot_of, int* __restrict__ crank_of,
                                const float4* __restrict__ old_pts, int old_m, int evicted, int kept,
-                               int* __restrict__ visit) {
+                               int* __restrict__ visit, CellLists lists) {
     grid_insert2_body(xyz, m, inv_h, inv_hc, table, tsize, slot_of, rank_of, cslot_of, crank_of, old_pts, old_m, evicted, kept,
-                      visit, blockIdx.x);
+                      visit, lists, blockIdx.x);
+}
+
+// The starts of the cells from their counts, over the build's CELL LISTS: workgroup 0 the fine level, workgroup 1 the coarse
+// level, each an exclusive scan of its list in chunks of CS_THREADS x CS_ITEMS entries (8 192: one or two chunks at the headline
+// sizes; a 1M-point map has ~80 000 cells: ten chunks).  Both levels hold all m points, so both scans run from 0.
+static constexpr int CS_THREADS = 1024, CS_ITEMS = 8;
+
+__device__ __forceinline__ void cells_scan_body(GridEntry* __restrict__ table, const CellLists& lists, int* __restrict__ ncells_out,
+                                                const int level) {
+    __shared__ int wsum[CS_THREADS / 64];
+    __shared__ int carry_s;
+    const int* __restrict__ list = level == 0 ? lists.fine : lists.coarse;
+    const int n = lists.counts[level];
+    if (level == 0 && threadIdx.x == 0) *ncells_out = n;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += CS_THREADS * CS_ITEMS) {  // block-uniform
+        int slot[CS_ITEMS], cnt[CS_ITEMS], s = 0;
+#pragma unroll
+        for (int k = 0; k < CS_ITEMS; ++k) {  // (consecutive entries per thread: the scan order is the list order)
+            const int i = base + (int)threadIdx.x * CS_ITEMS + k;
+            slot[k] = i < n ? list[i] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < CS_ITEMS; ++k) {
+            cnt[k] = slot[k] >= 0 ? table[slot[k]].count : 0;
+            s += cnt[k];
+        }
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < CS_THREADS / 64; ++w) {
+            const int v = wsum[w];
+            if (w < wave) woff += v;
+            tot += v;
+        }
+        int off = carry_s + woff + incl - s;
+#pragma unroll
+        for (int k = 0; k < CS_ITEMS; ++k) {
+            if (slot[k] >= 0) table[slot[k]].start = off;
+            off += cnt[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_cells_scan(GridEntry* __restrict__ table, CellLists lists, int* __restrict__ ncells_out) {
+    cells_scan_body(table, lists, ncells_out, (int)blockIdx.x);
 }
 
 __device__ inline unsigned long long grid_scan_item(const GridEntry* __restrict__ table, long long i, long long n,
@@ -706,21 +801,27 @@ __global__ void k_grid_clear_batch(const GridBuildDesc* __restrict__ t) {
     const GridBuildDesc& d = t[blockIdx.y];
     if (blockIdx.x >= d.clear_blocks) return;
     grid_clear_body(d.table, d.n2, d.nn_cache, d.old_pts, d.seed_n, d.seed_m, d.seed_evicted, d.seed, d.move, d.scan_ticket,
-                    d.hood_used, d.old_normals, d.old_nflag, d.carry_m, d.carry, blockIdx.x);
+                    d.hood_used, d.old_normals, d.old_nflag, d.carry_m, d.carry, d.lists, blockIdx.x);
 }
 
 __global__ void k_grid_insert2_batch(const GridBuildDesc* __restrict__ t) {
     const GridBuildDesc& d = t[blockIdx.y];
     if (blockIdx.x >= d.visit_blocks) return;
     grid_insert2_body(d.xyz, d.m, d.inv_h, d.inv_hc, d.table, d.tsize, d.slot_of, d.rank_of, d.cslot_of, d.crank_of, d.order_pts,
-                      d.order_old_m, d.order_evicted, d.order_kept, d.visit, blockIdx.x);
+                      d.order_old_m, d.order_evicted, d.order_kept, d.visit, d.lists, blockIdx.x);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_grid_scan_batch(const GridBuildDesc* __restrict__ t) {
     const GridBuildDesc& d = t[blockIdx.y];
-    if (blockIdx.x >= d.scan_blocks) return;  // (before the ticket is drawn: the tiles of a map number 0 .. scan_blocks - 1)
+    if (blockIdx.x >= d.scan_blocks || d.lists.counts) return;  // (before the ticket is drawn: the tiles of a map number 0 .. scan_blocks - 1; a member on cell lists is scanned by k_cells_scan_batch)
     grid_scan_body(d.table, (long long)d.n2, d.tsize, d.m, d.desc_a, d.desc_b, d.scan_gen, d.poll_limit, d.slot_of_cell,
                    d.ncells, d.scan_ticket, (int)d.scan_blocks);
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_cells_scan_batch(const GridBuildDesc* __restrict__ t) {
+    const GridBuildDesc& d = t[blockIdx.y];
+    if (!d.lists.counts || d.clear_blocks == 0) return;  // (a member on the table scan / an empty map)
+    cells_scan_body(d.table, d.lists, d.ncells, (int)blockIdx.x);
 }
 
 __global__ void k_grid_rows_scatter_batch(const GridBuildDesc* __restrict__ t) {
@@ -929,13 +1030,46 @@ int build_grid(icp_ctx* ctx, GridBuildDesc* defer) {
     unsigned long long* desc = ctx->scan_desc.as<unsigned long long>() + 8;
     int* ncells_dev = &reg_state(ctx)->grid_cells;  // written by the scan, read by k_build_rows and, with the result, by the host
     GridBuildDesc d{};
+    // cell lists ("cell_lists"): this build appends to one set; the other set — if the previous build wrote it for THIS table —
+    // names the slots to empty
+    CellLists lists;
+    long long prev_cells_bound = -1;  // >= 0: the previous build's lists are usable (at most that many entries per level)
+    if (ctx->cell_lists) {
+        const int cur = ctx->cell_set, prev = cur ^ 1;
+        ICP_HIP(ctx, ctx->cell_list[cur][0].reserve((size_t)m * sizeof(int)));
+        ICP_HIP(ctx, ctx->cell_list[cur][1].reserve((size_t)m * sizeof(int)));
+        if (!ctx->cell_counts.ptr) {
+            ICP_HIP(ctx, ctx->cell_counts.reserve(64));
+            ICP_HIP(ctx, hipMemsetAsync(ctx->cell_counts.ptr, 0, ctx->cell_counts.bytes, ctx->stream));
+            ctx->cells_table = nullptr;
+        }
+        lists.fine = ctx->cell_list[cur][0].as<int>();
+        lists.coarse = ctx->cell_list[cur][1].as<int>();
+        lists.counts = ctx->cell_counts.as<int>() + 2 * cur;
+        if (ctx->cells_table == (const void*)table && ctx->cells_tsize == tsize && ctx->cell_list[prev][0].ptr &&
+            ctx->cell_list[prev][1].ptr) {
+            lists.prev_fine = ctx->cell_list[prev][0].as<int>();
+            lists.prev_coarse = ctx->cell_list[prev][1].as<int>();
+            lists.prev_counts = ctx->cell_counts.as<int>() + 2 * prev;
+            prev_cells_bound = ctx->cells_m;
+        }
+        ctx->cells_table = table;
+        ctx->cells_tsize = tsize;
+        ctx->cells_m = m;
+        ctx->cell_set = prev;
+    } else {
+        ctx->cells_table = nullptr;  // (a build without lists: the next one with lists clears the whole table)
+    }
     {
         const int seed_n = ctx->seed_job_n;
         ctx->seed_job_n = 0;
-        long long span = n2 > seed_n ? n2 : (long long)seed_n;
+        // threads of the clearing launch: one per table slot — or, with the previous build's cell lists, one per entry of those
+        long long span = prev_cells_bound >= 0 ? (prev_cells_bound > 1 ? prev_cells_bound : 1) : n2;
+        if (seed_n > span) span = seed_n;
         const MapMoveJob move = ctx->move_job;  // the kept points re-expressed in the new frame (map update)
         ctx->move_job = MapMoveJob();
         if (move.m > span) span = move.m;
+        d.lists = lists;
         d.table = table;
         d.n2 = (unsigned)n2;
         d.tsize = tsize;
@@ -975,7 +1109,7 @@ int build_grid(icp_ctx* ctx, GridBuildDesc* defer) {
     d.desc_b = desc + nb;
     d.scan_gen = scan_gen;
     d.poll_limit = ctx->scan_poll_limit;
-    d.slot_of_cell = ctx->slot_of_cell.as<int>();
+    d.slot_of_cell = lists.counts ? lists.fine : ctx->slot_of_cell.as<int>();  // (the fine list IS the dense list of occupied fine cells)
     d.ncells = ncells_dev;
     d.scan_blocks = (unsigned)nb;
     {
@@ -1004,12 +1138,15 @@ int build_grid(icp_ctx* ctx, GridBuildDesc* defer) {
     }
     hipLaunchKernelGGL(k_grid_clear, dim3(d.clear_blocks), dim3(256), 0, ctx->stream, d.table, d.n2, d.nn_cache, d.old_pts,
                        d.seed_n, d.seed_m, d.seed_evicted, d.seed, d.move, d.scan_ticket, d.hood_used, d.old_normals,
-                       d.old_nflag, d.carry_m, d.carry);
+                       d.old_nflag, d.carry_m, d.carry, d.lists);
     hipLaunchKernelGGL(k_grid_insert2, dim3(d.visit_blocks), dim3(256), 0, ctx->stream, d.xyz, d.m, d.inv_h, d.inv_hc, d.table,
                        d.tsize, d.slot_of, d.rank_of, d.cslot_of, d.crank_of, d.order_pts, d.order_old_m, d.order_evicted,
-                       d.order_kept, d.visit);
-    hipLaunchKernelGGL(k_grid_scan, dim3(d.scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, d.table, (long long)d.n2, d.tsize,
-                       d.m, d.desc_a, d.desc_b, d.scan_gen, d.poll_limit, d.slot_of_cell, d.ncells, d.scan_ticket);
+                       d.order_kept, d.visit, d.lists);
+    if (d.lists.counts)
+        hipLaunchKernelGGL(k_cells_scan, dim3(2), dim3(CS_THREADS), 0, ctx->stream, d.table, d.lists, d.ncells);
+    else
+        hipLaunchKernelGGL(k_grid_scan, dim3(d.scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, d.table, (long long)d.n2, d.tsize,
+                           d.m, d.desc_a, d.desc_b, d.scan_gen, d.poll_limit, d.slot_of_cell, d.ncells, d.scan_ticket);
     hipLaunchKernelGGL(k_grid_rows_scatter, dim3(d.row_blocks + d.visit_blocks), dim3(256), 0, ctx->stream, d.xyz, d.m, d.table,
                        d.tsize - 1, d.slot_of_cell, d.ncells, d.rows, (int)d.row_blocks, d.slot_of, d.rank_of, d.cslot_of,
                        d.crank_of, d.sorted, d.csorted, d.normals, d.nflag, d.row_of_pos, d.pos_of_orig, d.carry, d.carry_m,
@@ -1033,16 +1170,19 @@ int build_grid_finish(icp_ctx* ctx, const GridBuildDesc& d) {
 // table in device memory)
 int launch_grid_build_batch(icp_ctx* first, const GridBuildDesc* th, const GridBuildDesc* td, int count) {
     unsigned clear = 0, visit = 0, scan = 0, scatter = 0;
+    bool any_lists = false;
     for (int b = 0; b < count; ++b) {
         clear = th[b].clear_blocks > clear ? th[b].clear_blocks : clear;
         visit = th[b].visit_blocks > visit ? th[b].visit_blocks : visit;
-        scan = th[b].scan_blocks > scan ? th[b].scan_blocks : scan;
+        if (th[b].lists.counts) any_lists = any_lists || th[b].clear_blocks > 0;
+        else scan = th[b].scan_blocks > scan ? th[b].scan_blocks : scan;
         const unsigned sc = th[b].row_blocks + th[b].visit_blocks;
         scatter = sc > scatter ? sc : scatter;
     }
     hipLaunchKernelGGL(k_grid_clear_batch, dim3(clear, count), dim3(256), 0, first->stream, td);
     hipLaunchKernelGGL(k_grid_insert2_batch, dim3(visit, count), dim3(256), 0, first->stream, td);
-    hipLaunchKernelGGL(k_grid_scan_batch, dim3(scan, count), dim3(SCAN_THREADS), 0, first->stream, td);
+    if (any_lists) hipLaunchKernelGGL(k_cells_scan_batch, dim3(2, count), dim3(CS_THREADS), 0, first->stream, td);
+    if (scan > 0) hipLaunchKernelGGL(k_grid_scan_batch, dim3(scan, count), dim3(SCAN_THREADS), 0, first->stream, td);
     hipLaunchKernelGGL(k_grid_rows_scatter_batch, dim3(scatter, count), dim3(256), 0, first->stream, td);
     ICP_HIP(first, hipGetLastError());
     return ICP_OK;

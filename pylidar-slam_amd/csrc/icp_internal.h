@@ -226,6 +226,18 @@ struct MapMoveJob {
     const RegState* st = nullptr;  // device-resident pose instead of `rel`
 };
 
+// The cell lists of a grid build (hash_grid.hip): the table slots it claims, fine and coarse level apart, with their counts;
+// `prev_*` = what the previous build left (the slots this build has to empty).  counts == nullptr: no lists (the table is
+// cleared and scanned as a whole); prev_counts == nullptr: the whole table is cleared (a first build, another table)
+struct CellLists {
+    int* fine = nullptr;
+    int* coarse = nullptr;
+    int* counts = nullptr;  // [2]: fine, coarse
+    const int* prev_fine = nullptr;
+    const int* prev_coarse = nullptr;
+    const int* prev_counts = nullptr;
+};
+
 // Everything the four launches of a grid build take (hash_grid.hip): filled by build_grid, handed to the kernels by value
 // (one map) or through a table in device memory (B maps per launch: icp_batch_map_update)
 struct GridBuildDesc {
@@ -246,6 +258,7 @@ struct GridBuildDesc {
     int carry_m;
     float4* carry;
     unsigned clear_blocks;
+    CellLists lists;
     // k_grid_insert2
     const float* xyz;
     int m;
@@ -350,6 +363,20 @@ struct icp_ctx {
     icp::GridEntry* ctable_ptr = nullptr;
     unsigned int ctable_size = 0;
     icp::DeviceBuffer scan_tmp;
+    // "cell_lists": the slots a grid build claims are listed, the next build empties those (not the table) and the cells'
+    // starts are scanned over the lists (hash_grid.hip: CellLists).  Two sets in alternation, [set][fine | coarse].
+    // MEASURED (round 6): for ONE sequence the build got slower — 7.0 + 12.4 + 14.2 + 8.0 = 41.6 us against 6.7 + 8.2 +
+    // 9.2 + 8.2 = 32.3 (the list appends cost the insertion 800 same-address counter updates, and one workgroup per level
+    // scanning 6 500 scattered counts is slower than 128 tiles streaming 262 144 slots) — 2722 vs 2835 scans/s; with eight or
+    // sixteen maps per launch it is the faster build (6865 vs 6657 scans/s at B = 16: the bytes of B whole tables count there).
+    // Off by default; the batched bench leg switches it on
+    int cell_lists = 0;
+    icp::DeviceBuffer cell_list[2][2];
+    icp::DeviceBuffer cell_counts;     // int[2 sets][2 levels] (+ padding)
+    int cell_set = 0;                  // the set the NEXT build writes
+    const void* cells_table = nullptr; // the table (and its size, and the point count) the other set describes; nullptr: nothing
+    unsigned cells_tsize = 0;
+    int64_t cells_m = 0;
     icp::DeviceBuffer scan_desc;       // descriptors of the one-launch table scan of the grid build (k_grid_scan)
     uint64_t scan_builds = 0;          // launches of that scan so far (its descriptors are tagged with it)
     int scan_poll_limit = 1 << 20;     // "scan_poll_limit" (dev): polls of a predecessor's descriptor before a tile sums the table itself

@@ -2417,18 +2417,16 @@ __device__ inline void smallest_eigenvector(float a00, float a01, float a02, flo
         }
     }
     // ties -> the last axis, like vh[2] of an already diagonal input (selects, not indexing: V stays in registers)
-    float lam = A[2][2], x = V[0][2], y = V[1][2], z = V[2][2];
-    if (A[1][1] < lam) {
-        lam = A[1][1];
-        x = V[0][1];
-        y = V[1][1];
-        z = V[2][1];
-    }
-    if (A[0][0] < lam) {
-        x = V[0][0];
-        y = V[1][0];
-        z = V[2][0];
-    }
+    // (two rounds of conditional moves on values; written as `if (..) x = V[0][1]` the optimiser turned the choice of the
+    // COLUMN into an index and parked V in 48 bytes of scratch memory — in every normal kernel)
+    const bool c1 = A[1][1] < A[2][2];
+    float lam = c1 ? A[1][1] : A[2][2];
+    float x = c1 ? V[0][1] : V[0][2], y = c1 ? V[1][1] : V[1][2], z = c1 ? V[2][1] : V[2][2];
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(lam));  // (keeps the two rounds apart: values, not a column number)
+    const bool c0 = A[0][0] < lam;
+    x = c0 ? V[0][0] : x;
+    y = c0 ? V[1][0] : y;
+    z = c0 ? V[2][0] : z;
     const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
     nx = x * inv;
     ny = y * inv;
