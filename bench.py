@@ -139,7 +139,7 @@ def parse():
                     help="after the headline (single process, --sequences-per-gpu 1 only): S independent sequences on S "
                          "streams of this GPU for the same number of steps, reported as `throughput` in the JSON line "
                          "(0: skip; also skipped with --no-cpu-baseline, the switch of the developer A/B runs)")
-    ap.add_argument("--batched-leg", default="4,8,16,32x4", metavar="B[xG][,B[xG]..]",
+    ap.add_argument("--batched-leg", default="4,8,16,48x4", metavar="B[xG][,B[xG]..]",
                     help="after the headline (single process, one sequence): `throughput_batched` — B sequences per launch "
                          "(icp_batch_*) for each listed B, or with `xG` B sequences as G batches of B / G on G streams (one host "
                          "thread); 200 timed steps per sequence in three windows (empty string: skip; also skipped with "
@@ -481,6 +481,18 @@ def batched_leg(args, device_index, workloads, sizes=((4, 1), (8, 1), (16, 1)), 
             best = (B, med, rec, groups)
     for t in trackers:
         t.close()
+    # the dominant kernel of this mode by rocprofv3 (committed trace of this leg, with its commit): k_iterate_batch advances B
+    # sequences by one iteration per launch = B x 36 N algorithmic bytes
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "rocprof_iterate_batch.json")))
+        rec["file"] = "profiles/rocprof_iterate_batch.json"
+        for row in rec.get("by_B", {}).values():
+            if row.get("avg_launch_us"):
+                row["algorithmic_GBps"] = row["sequences_per_launch"] * BYTES_PER_POINT_ITER * 131072 / (row["avg_launch_us"] * 1e-6) / 1e9
+                row["frac_of_hbm_peak"] = row["algorithmic_GBps"] * 1e9 / HBM_PEAK
+        out["dominant_kernel_by_rocprof"] = rec
+    except Exception:
+        pass
     if best is not None:
         out.update({"value": best[1], "sequences": best[0], "batches_on_streams_of_their_own": best[3],
                     "sequences_per_launch": best[0] // best[3],

@@ -24,6 +24,13 @@ with open(out+"/kernel_stats.txt","w") as o:
     print(f"# B={B}: {steps} steps in the sampled part; wall {span:.1f} us/step, kernel time {busy:.1f} us/step, gaps {span-busy:.1f} us/step; per frame {span/B:.1f} us", file=o)
     for k,v in tot.most_common(24): print(f"{k:72s} {cnt[k]/steps:6.1f} launches/step {v/steps:9.1f} us/step  avg {v/cnt[k]:8.1f} us", file=o)
 print(open(out+"/kernel_stats.txt").read())
+import json
+it=[r for r in half if "k_iterate" in r["Kernel_Name"]]
+d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in it]
+frames=[d[i:i+20] for i in range(0,len(d)-len(d)%20,20)]
+json.dump({"sequences_per_launch":B,"launches":len(d),"avg_launch_us":sum(d)/max(1,len(d)),
+           "by_iteration_us":[sum(f[i] for f in frames)/len(frames) for i in range(20)] if frames else [],
+           "wall_us_per_step":span,"kernel_us_per_step":busy}, open(out+"/iterate_batch.json","w"), indent=1)
 # timeline of one step in the middle of the sampled part
 idx=[i for i,r in enumerate(half) if "k_sum_solve_batch" in r["Kernel_Name"]]
 if len(idx)>3:
