@@ -448,15 +448,19 @@ int icp_set_normal_equations_buffer(icp_ctx* ctx, void* device_ptr);
  *   icp_batch_set_stream       icp_set_stream on every member (a batch enqueues everything on ONE stream);
  *   icp_batch_register_launch  icp_register_launch (from_last = 0; init_poses = count x 16 floats or NULL: identity) or
  *                              icp_register_launch_from_last (from_last = 1) on every member: xyz[b] / n[b] = member b's
- *                              scan.  Every iteration is enqueued (no chunking: a member whose loop has ended costs
- *                              nothing on the device).  Point-to-plane registrations on the fused path only (eager
- *                              normals, no exchange, no profiling): ICP_ERR_INVALID_ARGUMENT otherwise;
+ *                              scan.  With a forced iteration count every iteration is enqueued; with a live stop
+ *                              threshold a first chunk (as many as the slowest member ran last time, plus one), further
+ *                              chunks from icp_batch_register_end while a member is still running — a member whose loop has
+ *                              ended idles on the device.  While the batch holds iterations back its members refuse the
+ *                              single-context entry points (ICP_ERR_INVALID_ARGUMENT).  Point-to-plane registrations on the
+ *                              fused path only (eager normals, no exchange, no profiling): ICP_ERR_INVALID_ARGUMENT otherwise;
  *   icp_batch_project          icp_project for every member in two launches: xyz[b] [n[b],3] -> vmap_out[b] [3,H,W] of member b
  *                              (Projector.build_projection_map, slam/common/projection.py:331-418, as ICPFrameToModel._read_input
  *                              calls it per frame, icp_odometry.py:333); DEVICE pointers only;
  *   icp_batch_map_update       icp_map_update(member, NULL, NULL, ...) for every member: the pose-only update by the
  *                              device-resident pose of the registration just launched (icp_odometry.py:379) — the B grid
- *                              rebuilds in four launches;
+ *                              rebuilds in four launches (held-back iterations are enqueued first: the update reads the END of
+ *                              the registration);
  *   icp_batch_register_end     icp_register_end for every member (results[b]; loss_per_iter_out / dx_per_iter_out:
  *                              count x max_num_alignments (x 6) entries or NULL): ONE wait for all of them.  Returns the
  *                              first member's non-zero status, every member's own in results[b].status. */

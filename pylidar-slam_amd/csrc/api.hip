@@ -1596,6 +1596,9 @@ static int enqueue_result_copy(icp_ctx* ctx, bool refresh = false, hipEvent_t sh
 
 // enqueues the iterations a chunked launch has held back (all of them, or the next `count`) and copies the result again
 static int continue_launch(icp_ctx* ctx, int count) {
+    if (ctx->batch_hold)  // (a batched registration of this context is enqueued in chunks: its batch owns what is held back)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "a batched registration of this context still holds iterations back: "
+                                                   "icp_batch_register_end (or icp_batch_map_update) first");
     if (ctx->launch_remaining <= 0) return ICP_OK;
     if (count < 0 || count > ctx->launch_remaining) count = ctx->launch_remaining;
     ctx->in_registration = true;
@@ -1652,6 +1655,9 @@ static int recover_handoff(icp_ctx* ctx, RegState& st, std::vector<char>& block)
 int icp_register_end(icp_ctx* ctx, icp_register_result* result, double* loss_per_iter_out, float* dx_per_iter_out) {
     DeviceGuard device_guard(ctx, false);  // (the pose arrives while the map update runs)
     if (!ctx || !result || (!ctx->in_registration && !ctx->result_pending())) return ICP_ERR_INVALID_ARGUMENT;
+    if (ctx->batch_hold)
+        return fail(ctx, ICP_ERR_INVALID_ARGUMENT, "a batched registration of this context still holds iterations back: "
+                                                   "collect it with icp_batch_register_end");
     RegisteringGuard leave_on_exit(ctx);
     RegState st;
     const bool async = ctx->result_pending();
@@ -1981,6 +1987,10 @@ struct icp_batch {
     hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr};  // the slot's copy has left the pinned buffer
     hipEvent_t done[2] = {nullptr, nullptr};                  // ONE event behind the results of a batched registration
     int slot = 0, done_next = 0;
+    // the registration in progress: iterations [run_next, run_iters) are still held back (a live stop threshold: chunks)
+    bool run_active = false, run_lead = false;
+    int run_next = 0, run_iters = 0, run_done = 0;
+    int run_prev_rows[ICP_BATCH_MAX_SEQUENCES] = {}, run_prev_quad[ICP_BATCH_MAX_SEQUENCES] = {};
     // ... and of the batched grid build behind a map update: [count] GridBuildDesc per slot
     GridBuildDesc* grid_host[SLOTS] = {nullptr, nullptr, nullptr};
     DeviceBuffer grid_dev[SLOTS];
@@ -2012,9 +2022,11 @@ void icp_batch_destroy(icp_batch* b) {
     if (!b) return;
     DeviceGuard device_guard(b->device);
     (void)hipDeviceSynchronize();  // (launches that read the tables; members whose result slots wait for the batch's events)
-    for (icp_ctx* ctx : b->members)
+    for (icp_ctx* ctx : b->members) {
+        ctx->batch_hold = false;  // (iterations the batch still held back are dropped: the members' results stand as they are)
         for (auto& r : ctx->rslot)
             if (r.wait == b->done[0] || r.wait == b->done[1]) r.wait = r.event;
+    }
     for (int k = 0; k < icp_batch::SLOTS; ++k) {
         if (b->host[k]) (void)hipHostFree(b->host[k]);
         b->dev[k].release();
@@ -2037,6 +2049,118 @@ int icp_batch_set_stream(icp_batch* b, void* hip_stream) {
         if (rc) return batch_fail(b, rc, ctx->error);
     }
     return ICP_OK;
+}
+
+// Enqueues the next `chunk` iterations of the batch's registration in progress (all that are left when chunk < 0): their
+// descriptor tables into a fresh pinned slot, one copy, the launches; behind the chunk's last iteration a summing / solving
+// launch that also delivers every member's result block; ONE event behind it all.  `packs` (first chunk only): the target
+// packing / state initialisation of the members, run in front.
+static int batch_enqueue(icp_batch* b, int chunk, const PackDesc* packs, bool first_chunk) {
+    const int count = (int)b->members.size();
+    icp_ctx* const* ctxs = b->members.data();
+    icp_ctx* first = ctxs[0];
+    const int left = b->run_iters - b->run_next;
+    if (chunk < 0 || chunk > left) chunk = left;
+    if (chunk <= 0) return ICP_OK;
+    const int it_begin = b->run_next, it_end = it_begin + chunk;
+    const bool lead = b->run_lead;
+    int rc = ICP_OK;
+    const int slot = b->slot;
+    b->slot = (slot + 1) % icp_batch::SLOTS;
+    const size_t it_bytes = iterate_desc_bytes() * (size_t)count, ss_bytes = sum_solve_desc_bytes() * (size_t)count;
+    const size_t pack_bytes = ((sizeof(PackDesc) * (size_t)count + 255) / 256) * 256;  // the packing launch's table leads the slot
+    const size_t need = pack_bytes + (size_t)chunk * (it_bytes + ss_bytes);
+    if (b->host_bytes[slot] < need) {
+        if (b->copied[slot]) ICP_HIP(first, hipEventSynchronize(b->copied[slot]));
+        if (b->host[slot]) (void)hipHostFree(b->host[slot]);
+        b->host[slot] = nullptr;
+        b->host_bytes[slot] = 0;
+        ICP_HIP(first, hipHostMalloc((void**)&b->host[slot], need, hipHostMallocDefault));
+        b->host_bytes[slot] = need;
+    }
+    ICP_HIP(first, b->dev[slot].reserve(need));
+    if (!b->copied[slot]) ICP_HIP(first, hipEventCreateWithFlags(&b->copied[slot], hipEventDisableTiming));
+    else ICP_HIP(first, hipEventSynchronize(b->copied[slot]));  // (three chunks ago: long past)
+    for (int i = 0; i < count; ++i) {
+        ctxs[i]->in_registration = true;
+        if ((rc = result_fold_begin(ctxs[i], !first_chunk))) return batch_fail(b, rc, ctxs[i]->error);
+    }
+    struct Op {
+        int kind;  // 0: fused iteration, 1: sum + solve
+        size_t offset;
+        BatchedIteration it;
+    };
+    std::vector<Op> ops;
+    ops.reserve(2 * (size_t)chunk);
+    if (packs) memcpy(b->host[slot], packs, sizeof(PackDesc) * (size_t)count);
+    size_t used = pack_bytes;
+    for (int it = it_begin; it < it_end; ++it) {
+        Op op{0, used, BatchedIteration()};
+        if ((rc = prepare_iterate_batch(ctxs, count, lead, b->run_prev_rows, b->run_prev_quad, b->host[slot] + used, &op.it))) {
+            for (int i = 0; i < count; ++i)
+                if (!ctxs[i]->error.empty()) b->error = ctxs[i]->error;
+            return rc;
+        }
+        used += it_bytes;
+        ops.push_back(op);
+        bool solve = true;
+        if (lead) {  // (as enqueue_iterations: the narrow launches solve the iteration before them themselves)
+            for (int i = 0; i < count; ++i) {
+                b->run_prev_rows[i] = op.it.rows[i];
+                b->run_prev_quad[i] = op.it.quad[i];
+            }
+            solve = it + 1 == it_end || !next_fused_launch_is_narrow(first) || (op.it.quad[0] && !first->lead_after_dense);
+        }
+        if (solve) {
+            Op so{1, used, BatchedIteration()};
+            if ((rc = prepare_sum_solve_batch(ctxs, count, op.it.rows, op.it.quad, lead, it + 1 == it_end, b->host[slot] + used)))
+                return batch_fail(b, rc, "batched registration: sum + solve");
+            used += ss_bytes;
+            ops.push_back(so);
+            for (int i = 0; i < count; ++i) b->run_prev_rows[i] = 0;
+        }
+    }
+    b->run_next = it_end;
+    // ---- one copy, then the launches
+    ICP_HIP(first, hipMemcpyAsync(b->dev[slot].ptr, b->host[slot], used, hipMemcpyHostToDevice, first->stream));
+    ICP_HIP(first, hipEventRecord(b->copied[slot], first->stream));
+    if (packs && (rc = launch_pack_targets_batch(first, packs, b->dev[slot].as<PackDesc>(), count))) return batch_fail(b, rc, first->error);
+    for (const Op& op : ops) {
+        const char* table = b->dev[slot].as<char>() + op.offset;
+        rc = op.kind == 0 ? launch_iterate_batch(first, op.it, table) : launch_sum_solve_batch(first, count, table);
+        if (rc) return batch_fail(b, rc, first->error);
+    }
+    // ---- the results: every member's block lands in its own pinned slot (written by the chunk's last solving launch), ONE
+    // event; further chunks of the same registration record the same event again
+    if (first_chunk) {
+        b->run_done = b->done_next;
+        b->done_next ^= 1;
+    }
+    hipEvent_t& done = b->done[b->run_done];
+    if (!done) ICP_HIP(first, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    for (int i = 0; i < count; ++i) {
+        icp_ctx* ctx = ctxs[i];
+        ctx->launch_enqueued = it_end;
+        ctx->launch_remaining = 0;  // (what the batch still holds back is the batch's: run_next .. run_iters)
+        ctx->batch_hold = it_end < b->run_iters;
+        if ((rc = enqueue_result_copy(ctx, !first_chunk, done))) return batch_fail(b, rc, ctx->error);
+        ctx->result_fold_to = nullptr;
+        ctx->result_folded = false;
+        ctx->in_registration = false;  // the result waits in its slot
+    }
+    ICP_HIP(first, hipEventRecord(done, first->stream));
+    if (it_end >= b->run_iters) b->run_active = false;
+    return ICP_OK;
+}
+
+// everything the batch still holds back goes onto the stream (a map update by the device-resident poses, another launch, the
+// destruction of the batch follow the WHOLE registration)
+static int batch_flush(icp_batch* b) {
+    if (!b->run_active) return ICP_OK;
+    const int rc = batch_enqueue(b, -1, nullptr, false);
+    b->run_active = false;
+    for (icp_ctx* ctx : b->members) ctx->batch_hold = false;
+    return rc;
 }
 
 int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64_t* n, int mem, int target_mode,
@@ -2073,6 +2197,7 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
         }
     } unwind{b};
     int rc = ICP_OK;
+    if ((rc = batch_flush(b))) return rc;  // (iterations of the previous batched registration still held back go first)
     PackDesc packs[ICP_BATCH_MAX_SEQUENCES];
     for (int i = 0; i < count; ++i) {
         icp_ctx* ctx = ctxs[i];
@@ -2095,85 +2220,25 @@ int icp_batch_register_launch(icp_batch* b, const float* const* xyz, const int64
     }
     lead = lead && g_registering[d].load() <= counted;
     for (int i = 0; i < count; ++i) ctxs[i]->lead_latched = lead;
-    // ---- the frame's launches, prepared: descriptors into the pinned slot
-    const int slot = b->slot;
-    b->slot = (slot + 1) % icp_batch::SLOTS;
-    const size_t it_bytes = iterate_desc_bytes() * (size_t)count, ss_bytes = sum_solve_desc_bytes() * (size_t)count;
-    const size_t pack_bytes = ((sizeof(PackDesc) * (size_t)count + 255) / 256) * 256;  // the packing launch's table leads the slot
-    const size_t need = pack_bytes + (size_t)iters * (it_bytes + ss_bytes);
-    if (b->host_bytes[slot] < need) {
-        if (b->copied[slot]) ICP_HIP(first, hipEventSynchronize(b->copied[slot]));
-        if (b->host[slot]) (void)hipHostFree(b->host[slot]);
-        b->host[slot] = nullptr;
-        b->host_bytes[slot] = 0;
-        ICP_HIP(first, hipHostMalloc((void**)&b->host[slot], need, hipHostMallocDefault));
-        b->host_bytes[slot] = need;
+    // ---- the iterations: all of them (forced count), or a first chunk — as many as the slowest member ran last time plus one —
+    // with a live stop threshold (icp_batch_register_end enqueues more while a member is still running; launches behind
+    // every member's stop would be no-ops that still cost their slot on the stream: a hundred of them with the default
+    // max_num_alignments)
+    int first_chunk = iters;
+    if (first->cfg.threshold_delta_pose > 0.f && first->chunked_launch) {
+        int most = 0;
+        for (int i = 0; i < count; ++i) most = std::max(most, ctxs[i]->last_iterations > 0 ? ctxs[i]->last_iterations : 3);
+        first_chunk = std::min(iters, most + 1);
     }
-    ICP_HIP(first, b->dev[slot].reserve(need));
-    if (!b->copied[slot]) ICP_HIP(first, hipEventCreateWithFlags(&b->copied[slot], hipEventDisableTiming));
-    else ICP_HIP(first, hipEventSynchronize(b->copied[slot]));  // (three frames ago: long past)
-    for (int i = 0; i < count; ++i)
-        if ((rc = result_fold_begin(ctxs[i], false))) return batch_fail(b, rc, ctxs[i]->error);
-    struct Op {
-        int kind;  // 0: fused iteration, 1: sum + solve
-        size_t offset;
-        BatchedIteration it;
-    };
-    std::vector<Op> ops;
-    ops.reserve(2 * (size_t)iters);
-    memcpy(b->host[slot], packs, sizeof(PackDesc) * (size_t)count);
-    size_t used = pack_bytes;
-    int prev_rows[ICP_BATCH_MAX_SEQUENCES] = {}, prev_quad[ICP_BATCH_MAX_SEQUENCES];
-    for (int i = 0; i < count; ++i) prev_quad[i] = 1;
-    for (int it = 0; it < iters; ++it) {
-        Op op{0, used, BatchedIteration()};
-        if ((rc = prepare_iterate_batch(ctxs, count, lead, prev_rows, prev_quad, b->host[slot] + used, &op.it))) {
-            for (int i = 0; i < count; ++i)
-                if (!ctxs[i]->error.empty()) b->error = ctxs[i]->error;
-            return rc;
-        }
-        used += it_bytes;
-        ops.push_back(op);
-        bool solve = true;
-        if (lead) {  // (as enqueue_iterations: the narrow launches solve the iteration before them themselves)
-            for (int i = 0; i < count; ++i) {
-                prev_rows[i] = op.it.rows[i];
-                prev_quad[i] = op.it.quad[i];
-            }
-            solve = it + 1 == iters || !next_fused_launch_is_narrow(first) || (op.it.quad[0] && !first->lead_after_dense);
-        }
-        if (solve) {
-            Op so{1, used, BatchedIteration()};
-            if ((rc = prepare_sum_solve_batch(ctxs, count, op.it.rows, op.it.quad, lead, it + 1 == iters, b->host[slot] + used)))
-                return batch_fail(b, rc, "batched registration: sum + solve");
-            used += ss_bytes;
-            ops.push_back(so);
-            for (int i = 0; i < count; ++i) prev_rows[i] = 0;
-        }
-    }
-    // ---- one copy, then the launches
-    ICP_HIP(first, hipMemcpyAsync(b->dev[slot].ptr, b->host[slot], used, hipMemcpyHostToDevice, first->stream));
-    ICP_HIP(first, hipEventRecord(b->copied[slot], first->stream));
-    if ((rc = launch_pack_targets_batch(first, packs, b->dev[slot].as<PackDesc>(), count))) return batch_fail(b, rc, first->error);
-    for (const Op& op : ops) {
-        const char* table = b->dev[slot].as<char>() + op.offset;
-        rc = op.kind == 0 ? launch_iterate_batch(first, op.it, table) : launch_sum_solve_batch(first, count, table);
-        if (rc) return batch_fail(b, rc, first->error);
-    }
-    // ---- the results: every member's block lands in its own pinned slot (written by the last solving launch), ONE event
-    hipEvent_t& done = b->done[b->done_next];
-    b->done_next ^= 1;
-    if (!done) ICP_HIP(first, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    b->run_active = true;
+    b->run_lead = lead;
+    b->run_next = 0;
+    b->run_iters = iters;
     for (int i = 0; i < count; ++i) {
-        icp_ctx* ctx = ctxs[i];
-        ctx->launch_enqueued = iters;
-        ctx->launch_remaining = 0;
-        if ((rc = enqueue_result_copy(ctx, false, done))) return batch_fail(b, rc, ctx->error);
-        ctx->result_fold_to = nullptr;
-        ctx->result_folded = false;
-        ctx->in_registration = false;  // the result waits in its slot
+        b->run_prev_rows[i] = 0;
+        b->run_prev_quad[i] = 1;
     }
-    ICP_HIP(first, hipEventRecord(done, first->stream));
+    if ((rc = batch_enqueue(b, first_chunk, packs, true))) return rc;
     unwind.armed = false;
     return ICP_OK;
 }
@@ -2195,6 +2260,10 @@ int icp_batch_map_update(icp_batch* b) {
     DeviceGuard device_guard(b->device);
     const int count = (int)b->members.size();
     icp_ctx* first = b->members[0];
+    {   // the pose-only update reads the END of the registration: iterations the batch still holds back go first
+        const int rc_flush = batch_flush(b);
+        if (rc_flush) return rc_flush;
+    }
     bool one_stream = true;
     for (icp_ctx* ctx : b->members) {
         { DeviceGuard join_map_stream(ctx); }
@@ -2243,6 +2312,28 @@ int icp_batch_map_update(icp_batch* b) {
 
 int icp_batch_register_end(icp_batch* b, icp_register_result* results, double* loss_per_iter_out, float* dx_per_iter_out) {
     if (!b || !results) return ICP_ERR_INVALID_ARGUMENT;
+    DeviceGuard device_guard(b->device);
+    // a registration enqueued in chunks: wait for what is on the stream; while a member is still running and iterations are
+    // held back, the next chunk (four iterations), and look again
+    while (b->run_active) {
+        icp_ctx* first = b->members[0];
+        ICP_HIP(first, hipEventSynchronize(b->done[b->run_done]));
+        bool running = false;
+        for (icp_ctx* ctx : b->members) {
+            if (ctx->r_count <= 0) continue;
+            RegState st;
+            memcpy(&st, ctx->rslot[(ctx->r_head + ctx->r_count - 1) & 1].host, sizeof(st));  // (the newest pending result: this registration's)
+            running = running || (!st.done && st.status == ICP_OK && st.handoff_timeouts == 0);
+        }
+        if (!running) {
+            b->run_active = false;  // (every member has stopped: the rest is never enqueued)
+            for (icp_ctx* ctx : b->members) ctx->batch_hold = false;
+            break;
+        }
+        const int rc_chunk = batch_enqueue(b, 4, nullptr, false);
+        if (rc_chunk) return rc_chunk;
+    }
+    for (icp_ctx* ctx : b->members) ctx->batch_hold = false;
     int first_rc = ICP_OK;
     const size_t cap = (size_t)b->members[0]->cfg.max_num_alignments;
     for (size_t i = 0; i < b->members.size(); ++i) {

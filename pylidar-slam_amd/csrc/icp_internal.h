@@ -511,6 +511,7 @@ struct icp_ctx {
     bool lead_latched = false;         // lead launches for the registration in progress: decided once, in register_begin
     int tail_capacity = -1;            // workgroups of the tail's shape the device holds at once (-1: not asked yet)
     int handoff_fallbacks = 0;         // registrations finished on per-iteration launches behind a timed-out hand-off
+    bool batch_hold = false;           // a batched registration of this context holds iterations back (api.hip: icp_batch): individual entry points refuse
     bool counted_registering = false;  // this context is counted among the registering contexts of its device (api.hip)
     bool update_behind_registration = false;  // a pose-only map update by the device pose is enqueued behind an uncollected registration
     icp::DeviceBuffer tail_rows;       // tagged super-rows of the tail: [rows][NEQ][2] granules of 8 bytes

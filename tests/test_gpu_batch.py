@@ -35,7 +35,7 @@ def _sequences(count, height, width, map_points, frames, seed0=1234, map_scans=4
     return out
 
 
-def _run_single(kw, options, seq, frames, init_mode, device=None):
+def _run_single(kw, options, seq, frames, init_mode, device=None, sync_order=False):
     scans, model = seq
     ctx = _ctx(**kw)
     for k, v in options.items():
@@ -45,8 +45,12 @@ def _run_single(kw, options, seq, frames, init_mode, device=None):
     for f in range(frames):
         scan = device.from_numpy(scans[f]).cuda() if device is not None else scans[f]
         ctx.register_launch(scan, "last" if (init_mode == "last" and f > 0) else init)
-        ctx.map_update(None, None)
-        r = ctx.register_end()
+        if sync_order:  # (the plugin's order: the pose first — it decides about a key frame —, then the map)
+            r = ctx.register_end()
+            ctx.map_update(r.pose, None)
+        else:
+            ctx.map_update(None, None)
+            r = ctx.register_end()
         out.append(r)
         init = r.pose
     mp = ctx.map_points()
@@ -55,7 +59,7 @@ def _run_single(kw, options, seq, frames, init_mode, device=None):
     return out, mp, fb
 
 
-def _run_batch(kw, options, seqs, frames, init_mode, device=None, lengths=None):
+def _run_batch(kw, options, seqs, frames, init_mode, device=None, lengths=None, sync_order=False):
     from pylidar_slam_amd.engine import IcpBatch
     ctxs = []
     for scans, model in seqs:
@@ -73,8 +77,13 @@ def _run_batch(kw, options, seqs, frames, init_mode, device=None, lengths=None):
             a = sc[f] if lengths is None else sc[f][:lengths[b]]
             scans.append(device.from_numpy(a).cuda() if device is not None else a)
         batch.register_launch(scans, "last" if (init_mode == "last" and f > 0) else inits)
-        batch.map_update()
-        res = batch.register_end()
+        if sync_order:
+            res = batch.register_end()  # (a live threshold: further chunks are enqueued here while a member still runs)
+            for c, r in zip(ctxs, res):
+                c.map_update(r.pose, None)
+        else:
+            batch.map_update()
+            res = batch.register_end()
         for b, r in enumerate(res):
             out[b].append(r)
         inits = [r.pose for r in res]
@@ -98,7 +107,8 @@ def _assert_same(single, batched, tag):
 
 
 @pytest.mark.parametrize("variant", ["default", "no_lead", "narrow_only", "live_threshold", "from_last", "host_arrays",
-                                     "ragged", "hit_records", "late_kernel"])
+                                     "ragged", "hit_records", "late_kernel", "live_threshold_pose_first",
+                                     "many_iterations_pose_first"])
 def test_batched_registration_equals_single_sequences(torch_cuda, variant):
     """Three sequences with different scenes, four chained frames each (registration from the previous pose, pose-only map
     update by the device-resident pose): batched vs every sequence alone on a context of its own — poses, parameters,
@@ -106,9 +116,10 @@ def test_batched_registration_equals_single_sequences(torch_cuda, variant):
     (a summing / solving launch per iteration for all members), the 512-thread shape from the first iteration, a live stop
     threshold (members stop after different numbers of iterations: a finished member idles on the device), the initial
     guess read on the device, host arrays in, scans of different lengths in one batch, hit records and the late kernel (both
-    off by default)."""
+    off by default), and the plugin's order — poses first, then the maps — with a live threshold: the batch enqueues a first
+    chunk of iterations and further chunks from `register_end` while a member is still running."""
     kw = dict(height=32, width=1024, max_num_alignments=12, threshold_delta_pose=0.0, scheme="geman_mcclure", sigma=0.3)
-    options, init_mode, device, lengths = {}, "pose", torch_cuda, None
+    options, init_mode, device, lengths, sync_order = {}, "pose", torch_cuda, None, False
     if variant == "no_lead":
         options = {"lead_solve": 0}
     elif variant == "narrow_only":
@@ -122,6 +133,14 @@ def test_batched_registration_equals_single_sequences(torch_cuda, variant):
         device = None
     elif variant == "ragged":
         lengths = [32 * 1024, 20 * 1024 + 77, 9 * 1024 + 5]
+    elif variant == "live_threshold_pose_first":
+        kw["threshold_delta_pose"] = 1.0e-4
+        kw["max_num_alignments"] = 15
+        sync_order = True
+    elif variant == "many_iterations_pose_first":  # (the reference's dataclass default: 100 — most of them never enqueued)
+        kw["threshold_delta_pose"] = 1.0e-5
+        kw["max_num_alignments"] = 100
+        sync_order = True
     elif variant == "hit_records":
         options = {"hit_records": 1}
     elif variant == "late_kernel":  # (the late kernel from the third launch on, batched: k_iterate_late_batch)
@@ -129,13 +148,13 @@ def test_batched_registration_equals_single_sequences(torch_cuda, variant):
     seqs = _sequences(3, 32, 1024, 30_000, 4)
     if lengths is not None:
         seqs = [([s[:lengths[b]] for s in sc], m) for b, (sc, m) in enumerate(seqs)]
-    batched = _run_batch(kw, options, seqs, 4, init_mode, device)
+    batched = _run_batch(kw, options, seqs, 4, init_mode, device, sync_order=sync_order)
     for b, seq in enumerate(seqs):
-        single = _run_single(kw, options, seq, 4, init_mode, device)
+        single = _run_single(kw, options, seq, 4, init_mode, device, sync_order=sync_order)
         _assert_same(single, ([r for r in batched[0][b]], batched[1][b], batched[2][b]), (variant, b))
-    if variant == "live_threshold":
+    if variant in ("live_threshold", "live_threshold_pose_first", "many_iterations_pose_first"):
         its = [[r.iterations for r in batched[0][b]] for b in range(3)]
-        assert any(i < 15 for row in its for i in row), its  # (the threshold did fire: members went idle inside the batch)
+        assert any(i < kw["max_num_alignments"] for row in its for i in row), its  # (the threshold did fire: members went idle inside the batch)
 
 
 def test_batched_registration_at_benchmark_size(torch_cuda):
