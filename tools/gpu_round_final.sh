@@ -14,7 +14,7 @@ CMD="python bench.py --steps 30 --warmup 5 $LEGS_OFF"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o t -- python $R/bench.py --steps 30 --warmup 5 $LEGS_OFF > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err )
 python tools/rocprof_iterate_summary.py $OUT/prof $OUT/rocprof_iterate_kernel.json $HEAD_SHA "rocprofv3 --kernel-trace --stats -- $CMD" > /dev/null
 cp $(ls $OUT/prof/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null
-python tools/dev/r5_timeline.py $(ls $OUT/prof/*kernel_trace.csv | head -1) k_pack_targets > $OUT/headline_timeline.txt 2>&1
+python tools/frame_timeline.py $(ls $OUT/prof/*kernel_trace.csv | head -1) k_pack_targets > $OUT/headline_timeline.txt 2>&1
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_ref -o t -- python $R/bench.py --steps 30 --warmup 5 $LEGS_OFF --no-profile --option carry_normals=0 > $R/$OUT/prof_ref_bench.json 2> $R/$OUT/prof_ref_bench.err )
 cp $(ls $OUT/prof_ref/*kernel_stats.csv | head -1) $OUT/reference_schedule_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/prof $OUT/prof_ref
@@ -56,6 +56,6 @@ PY
 timeout 600 python bench.py --workload c4 --steps 6 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "c4 rc=$?"; tail -c 400 $OUT/bench_c4.json; echo
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/odo -o t -- python $R/bench.py --leg odometry_loop --no-cpu-baseline > $R/$OUT/odo.json 2> $R/$OUT/odo.err )
 cp $(ls $OUT/odo/*kernel_stats.csv | head -1) $OUT/odometry_loop_kernel_stats.csv 2>/dev/null
-python tools/dev/r5_timeline.py $(ls $OUT/odo/*kernel_trace.csv | head -1) k_dedupe_clear > $OUT/odometry_loop_timeline.txt 2>&1
+python tools/frame_timeline.py $(ls $OUT/odo/*kernel_trace.csv | head -1) k_dedupe_clear > $OUT/odometry_loop_timeline.txt 2>&1
 rm -rf $OUT/odo
 timeout 100 python bench.py --steps 14 --warmup 6 $LEGS_OFF --no-profile --option search_stats=2 > $OUT/stamps.json 2> $OUT/stamps.err; grep "icp phases\|icp lead" $OUT/stamps.err | tail -60 > $OUT/phase_stamps.txt; wc -l $OUT/phase_stamps.txt
