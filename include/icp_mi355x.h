@@ -168,6 +168,10 @@ int icp_synchronize(icp_ctx* ctx);
  *                                   at most 128, by 8 where it has at most 64 (the groups of four points of a cell alternate between the lanes, one butterfly
  *                                   merge of their sorted keys at the end); 1: one lane always, and workgroups with up to
  *                                   "wave_misses" misses go straight to the whole-wave search
+ *   "ball_empty" 0 | 1 (1)          a miss whose own cell is EMPTY (no neighbour row to read) stays with the ball search when it
+ *                                   brings a seed: the other seven cells of its 2x2x2 block by hashed probes, then the same
+ *                                   pruning and scan (frames whose initial guess is half a metre off put a sixth of the scan
+ *                                   into empty cells; 0: those queries go to the cooperative searches, round 5's schedule)
  *   "far_lanes" 0 | 16 (16)         what the ball search hands back (own cell empty, a ball that leaves its block, more than
  *                                   "ball_max" candidates) where a workgroup has more than "far_min" of them and at most
  *                                   "far_max": every such query searched by 16 lanes, THREADS / 16 queries at a time — seven

@@ -450,6 +450,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "cell_lists") ctx->cell_lists = iv != 0 ? 1 : 0;
     else if (k == "normals_tail_stream") ctx->normals_tail_stream = iv != 0 ? 1 : 0;
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
+    else if (k == "ball_empty") ctx->ball_empty = iv != 0 ? 1 : 0;
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);
     else if (k == "lead_timeout_ms") ctx->lead_timeout_ms = value > 1.0e-5 ? value : 1.0e-5;  // (>= one tick of the 100 MHz clock: tests go there)
     else if (k == "chunked_launch") ctx->chunked_launch = value != 0.0 ? 1 : 0;

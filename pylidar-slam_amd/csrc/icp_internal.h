@@ -480,6 +480,7 @@ struct icp_ctx {
     int far_min = 16;                  // "far_min": ... more than that many (fewer: a wave each)
     int far_max = 128;                 // "far_max": ... up to that many of them (THREADS / 16 at a time)
     int ball_lanes = 8;                // "ball_lanes": a miss of a workgroup with few of them gets 2 or 8 lanes of the ball search (IterInputs)
+    int ball_empty = 1;                // "ball_empty": a seeded miss in an EMPTY cell is searched by the ball search too (its 2x2x2 block by seven hashed probes) instead of the cooperative searches
     int ball_max = 256;                // "ball_max": ... if they have at most that many candidates (a lane walks them alone: the longest walk of a launch sets its duration)
     double lead_timeout_ms = 50.0;     // "lead_timeout_ms": how long a workgroup of a lead launch polls the pose mailbox before it gives up (-> ICP_ERR_HIP)
     // "lazy_fused": normals on demand INSIDE the fused iteration kernel (its LAZY instantiation, search.hip) instead of all of

@@ -943,7 +943,7 @@ __device__ inline void ball_merge(Top4& t) {
 template <int W, int LPQ>
 __device__ inline bool search_ball_lane(const GridView& g, float px, float py, float pz, float seed_d2, int max_cand,
                                         int2* __restrict__ stack, int stride, int sub, int& pos0, int& pos1, int& pos2,
-                                        float& L, int& seed_pos) {
+                                        float& L, int& seed_pos, bool through_empty = true) {
     seed_pos = -1;
     const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
     const float h = g.h;
@@ -975,7 +975,20 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
 #pragma unroll
         for (int m = 1; m < 8; ++m) rc[m - 1] = r[((m & 1) ? o1 : 0) + ((m & 2) ? o2 : 0) + ((m & 4) ? o4 : 0)];
     }
-    if (e.key != key) return false;  // own cell empty
+    // own cell EMPTY (round 6): no neighbour row to read — rows belong to occupied cells — but a query that brings a seed still
+    // has its ball: the other seven cells of the 2x2x2 block by hashed probes, all in flight together, then the same pruning
+    // and the same scan.  (A frame whose constant-velocity guess is off by half a metre puts a sixth of the scan into empty
+    // cells in front of the walls it faces; those queries went to the cooperative searches — 110 us first launches.)
+    const bool own_empty = e.key != key;
+    if (own_empty) {
+        if (!through_empty || !(seed_d2 < INFINITY)) return false;  // (option "ball_empty" 0 / nothing bounds the ball)
+        grid_lookup7(g, 0x7f, [&](int k) {
+            const int m = k + 1;
+            return pack_cell(cx + ((m & 1) ? (lx ? -1 : 1) : 0), cy + ((m & 2) ? (ly ? -1 : 1) : 0), cz + ((m & 4) ? (lz ? -1 : 1) : 0));
+        }, rc);
+        e.start = 0;
+        e.count = 0;
+    }
     const int cum0 = (e.count + 3) & ~3;
     if (cum0 > max_cand) return false;
     const float4* __restrict__ pad = g.pts + g.m;  // SORTED_PAD points at +inf
@@ -998,15 +1011,70 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
     if constexpr (LPQ >= 2) kbest = min(kbest, ball_xchg<1>(kbest));
     if constexpr (LPQ >= 4) kbest = min(kbest, ball_xchg<2>(kbest));
     if constexpr (LPQ >= 8) kbest = min(kbest, ball_xchg<4>(kbest));
-    if (kbest >= 0x7f800000u) return false;  // nothing finite in the own cell
+    if (kbest >= 0x7f800000u && !own_empty) return false;  // nothing finite in the own cell
     // the pruning radius: the nearest so far is no farther than its key with the low bits set; the seed is a map point
     // like any other and is met in its cell
-    const float r2 = fminf(seed_d2, __uint_as_float(kbest | BALL_JMASK));
+    const float r2 = own_empty ? seed_d2 : fminf(seed_d2, __uint_as_float(kbest | BALL_JMASK));
     const float R = sqrtf(r2) * 1.000001f + g.prune_guard;
     const bool inside = R < outer;
     const float R2 = R * R;
-    float Lb2 = outer * outer;
+    // a ball that leaves the 2x2x2 block but stays inside the 3x3x3 one (round 6: a query half a metre from its surface in
+    // 0.5 m cells — a sixth of the scan when the initial guess is that far off): every cell of the 26 whose box the ball
+    // reaches, from the own cell's row or, where the own cell is empty, by hashed probes seven at a time
+    const float outer3 = h + fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    bool block3 = !inside && through_empty && R < outer3;
+    float Lb2 = block3 ? outer3 * outer3 : outer * outer;
     int ns = 0, total = cum0;
+    if (block3) {
+        unsigned surv = 0;  // bit idx = (oz + 1) * 9 + (oy + 1) * 3 + (ox + 1) of the cells the ball reaches
+#pragma unroll
+        for (int idx = 0; idx < 27; ++idx) {
+            if (idx == 13) continue;
+            const float gx = axis_gap(idx % 3 - 1, fx, h), gy = axis_gap((idx / 3) % 3 - 1, fy, h), gz = axis_gap(idx / 9 - 1, fz, h);
+            const float gap2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+            if (gap2 > R2) Lb2 = fminf(Lb2, gap2);  // (every point such a cell may hold is at least that far)
+            else surv |= 1u << idx;
+        }
+        while (surv && block3) {  // (group-uniform: the lanes of a query hold the same mask)
+            unsigned long long pick = 0;  // up to seven cell numbers, five bits each (+ 1: 0 = none)
+            int want = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (surv) {
+                    const int idx = __ffs((int)surv) - 1;
+                    surv &= surv - 1u;
+                    pick |= (unsigned long long)(idx + 1) << (5 * k);
+                    want |= 1 << k;
+                }
+            }
+            int2 found[7];
+            if (own_empty) {
+                grid_lookup7(g, want, [&](int k) {
+                    const int idx = (int)((pick >> (5 * k)) & 31ull) - 1;
+                    return pack_cell(cx + idx % 3 - 1, cy + (idx / 3) % 3 - 1, cz + idx / 9 - 1);
+                }, found);
+            } else {
+                const int2* __restrict__ r = g.rows + (size_t)slot * ROW_STRIDE;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const int idx = (int)((pick >> (5 * k)) & 31ull) - 1;
+                    found[k] = (want >> k & 1) ? r[idx] : make_int2(0, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if ((want >> k & 1) && found[k].y > 0) {
+                    if (ns == 7) {  // (the lane's cell stack holds seven: the generic paths take such a query)
+                        block3 = false;
+                    } else {
+                        stack[ns * stride] = make_int2(found[k].x - total, total);
+                        total += (found[k].y + 3) & ~3;
+                        ++ns;
+                    }
+                }
+            }
+        }
+    }
     if (inside) {
 #pragma unroll
         for (int m = 1; m < 8; ++m) {
@@ -1023,9 +1091,9 @@ __device__ inline bool search_ball_lane(const GridView& g, float px, float py, f
             }
         }
     }
-    if (!inside || total > max_cand) {
+    if ((!inside && !block3) || total > max_cand) {
         // the generic paths take over, from the best point of the own cell if that beats the caller's seed
-        if (__uint_as_float(kbest & ~BALL_JMASK) < seed_d2) seed_pos = e.start + (int)(kbest & BALL_JMASK);
+        if (!own_empty && __uint_as_float(kbest & ~BALL_JMASK) < seed_d2) seed_pos = e.start + (int)(kbest & BALL_JMASK);
         return false;
     }
     {
@@ -1214,6 +1282,7 @@ struct IterInputs {
     int far_max;             // option "far_max": the most handed-back queries of a workgroup phase BF takes
     int far_min;             // option "far_min": ... and it takes more than that many (fewer: a wave each, phase B1)
     int ball_lanes;          // option "ball_lanes": the most lanes a miss gets in phase B0 (1, 2 or 8)
+    int ball_empty;          // option "ball_empty": a seeded miss whose own cell is empty stays with the ball search (seven hashed probes)
     int chunk_stride;        // 512-query shape: S = base rows between the four 128-query chunks of a workgroup (= its super-rows)
     float4* normals_rw;      // LAZY instantiation: the normal cache and its flags, writable; fine rings of its kNN
     int* nflag;
@@ -1778,7 +1847,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
             int p0, p1, p2, sp;
             float L;
             const bool ok = search_ball_lane<W, LPQ>(g, mp.x, mp.y, mp.z, __int_as_float(ms.x), in.ball_max,
-                                                     &cellstack[0][threadIdx.x], THREADS, sub, p0, p1, p2, L, sp);
+                                                     &cellstack[0][threadIdx.x], THREADS, sub, p0, p1, p2, L, sp, in.ball_empty != 0);
             if (sub == 0) {
                 if (ok) {
                     const int lq2 = __float_as_int(mp.w);
@@ -3818,6 +3887,7 @@ static int prepare_iterate_fused(icp_ctx* ctx, bool lead_mode, int prev_rows, in
     }
     in.ball = ctx->ball_search;
     in.ball_lanes = ctx->ball_lanes;
+    in.ball_empty = ctx->ball_empty;
     in.far_lanes = ctx->far_lanes;
     in.far_max = min(ctx->far_max, IT_THREADS);
     in.far_min = ctx->far_min;

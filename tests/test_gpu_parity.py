@@ -404,7 +404,7 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 # points, where the default schedule has carried the first frame's estimate over by rotation: rounding apart)
                 # round 6 (both off by default): hit records / the late kernel from the fourth launch on, from the second, in
                 # its 80-register build, behind the 512-thread shape
-                "cell_lists": {"cell_lists": 1},
+                "cell_lists": {"cell_lists": 1}, "no_ball_empty": {"ball_empty": 0},
                 "hit_records": {"hit_records": 1}, "late_kernel": {"hit_records": 1, "late_from": 3},
                 "late_from_1": {"hit_records": 1, "late_from": 1},
                 "late_80_registers": {"hit_records": 1, "late_from": 3, "late_waves": 6},
