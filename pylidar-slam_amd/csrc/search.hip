@@ -1188,6 +1188,10 @@ static constexpr int IT_QUERIES = IT_THREADS / 4;
 // block of 128 queries (Q = 128) writes its base row, a block of 512 queries — four 128-query chunks S base rows apart —
 // its super-row: a quarter of the rows for the summing kernel, same bits.
 // RET: the sum is returned (threads < NEQ; 0.0 elsewhere) instead of being stored
+// (Round 6, measured and dropped: every row converted to float64 ONCE into LDS the searches no longer need, the summing
+// threads reading doubles — 9 conversions per lane instead of 64.  The summing is bound by LDS bandwidth, not by VALU issue:
+// 512 threads x 64 operands x 4 B = 131 KB per workgroup = 0.43 us of the CU's 128 B per clock, twice that with doubles;
+// late launches 10.5 -> 11.1 us, headline and batched throughput -4 %: profiles/r06_ab_sessions.txt.)
 template <int Q, bool RET = false>
 __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
                                            int block) {
@@ -1200,9 +1204,9 @@ __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*pa
             int a, b2;
             neq_operands(e, a, b2);
             const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
-#pragma unroll 8
             // (fma: the product of two floats is exact in float64 — 48 mantissa bits — so the fused form rounds once where the
             // separate multiply and add round once too: the same bits, one instruction less per row)
+#pragma unroll 8
             for (int j = 0; j < IT_QUERIES / 4; ++j) acc = fma((double)rowbuf[j0 + j][a], (double)rowbuf[j0 + j][b2], acc);
         }
         part[sb * 4 + qtr][e] = acc;
@@ -1331,6 +1335,14 @@ static_assert(BATCH_LEAD_SLOTS % 8 == 0 && BATCH_LEAD_SLOTS == ICP_BATCH_MAX_SEQ
 // cache entry .x = cell-sorted position of the neighbour | iteration of the search << 24 (-1: no neighbour); a position
 // needs 24 bits (maps of up to 16.7 M points use the cache), iterations wrap into 7 bits — harmlessly: an entry older
 // than CACHE_HIST launches is a miss
+// The square root of the cache tests: the hardware's v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf() (which the
+// compiler expands to 14 instructions: scaling for denormals, two correction steps, a class test).  The tests are BOUNDS, not
+// results — a hit is certified when an upper bound of the winner's distance is below a lower bound of everybody else's — and
+// their factors (1.000001 up, 0.999999 down: 8 ulp) cover the 1.5 ulp of the squared distance's three roundings plus this one;
+// a denormal argument may come back as 0 — 1e-19 below the truth, against the 1e-7 every test adds to the displacement.
+// Whether a query is certified or searched never changes its neighbour (both are exact): same bits.
+__device__ __forceinline__ float sqrt_1ulp(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 static constexpr int CACHE_ITER_SHIFT = 24;
 static constexpr int CACHE_POS_MASK = (1 << CACHE_ITER_SHIFT) - 1;
 static constexpr int CACHE_HIST = 24;  // poses kept in LDS (1152 B: what the 128-query shape has left of its 40 KB)
@@ -1694,8 +1706,8 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
                         float ox, oy, oz;  // where the target was when the record's bound was formed
                         transform_point(hist_s[k2 % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
-                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                        hit = sqrtf(d2) * 1.000001f < r0.w - delta - margin;
+                        const float delta = sqrt_1ulp(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        hit = sqrt_1ulp(d2) * 1.000001f < r0.w - delta - margin;
                     }
                     if (hit) {
                         point_to_plane_row(px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, ap.scheme, ap.sigma, row);
@@ -1751,14 +1763,14 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
                         float ox, oy, oz;  // where the target was when its neighbour was searched
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
-                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        const float delta = sqrt_1ulp(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
                         outside = __int_as_float(c.y) - delta;
-                        hit = sqrtf(d2) * 1.000001f < outside - margin;
+                        hit = sqrt_1ulp(d2) * 1.000001f < outside - margin;
                     }
                     if (REC && in.rec && hit) {
                         // the record of this hit: winner, normal, and what bounds every OTHER map point at this pose — the
                         // set's other members exactly (rounded down), everything outside the set by `outside`
-                        const float bound = fminf(outside, sqrtf(others2) * 0.999999f);
+                        const float bound = fminf(outside, sqrt_1ulp(others2) * 0.999999f);
                         in.rec[2 * (size_t)qi] = make_float4(wq.x, wq.y, wq.z, bound);
                         in.rec[2 * (size_t)qi + 1] = make_float4(wn.x, wn.y, wn.z, __int_as_float(iter_now));
                     }
@@ -1821,6 +1833,10 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
 #pragma unroll
         for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
     };
+    // (round 6) a workgroup WITHOUT a miss — nearly every one of a late launch — goes straight to the summing: the rows of its
+    // hits are behind the barrier above; the phases below would cost it four dependent reads of the list's counter and a barrier
+    const bool any_miss = nmiss > 0;  // block-uniform
+    if (any_miss) {
     const int ball_lpq = !in.ball ? 0
                          : (in.ball_lanes >= 8 && nmiss * 8 <= THREADS)   ? 8
                          : (in.ball_lanes >= 4 && nmiss * 4 <= THREADS)   ? 4
@@ -1982,6 +1998,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
         }
     }
     __syncthreads();
+    }  // (any_miss)
     if (LAZY && nlazy > 0) {  // ---- phase N (block-uniform): the normals the queries of this workgroup wait for
         const int listed = nlazy, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = threadIdx.x & 3;
         // (another query of this workgroup may wait for the same map point — estimated twice, the same bits; so may another
@@ -2221,8 +2238,8 @@ __device__ __forceinline__ void iterate_late_body(GridView g, IterInputs in, Reg
                 float ox, oy, oz;
                 transform_point(hist_s[k2 % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                 const float mx = px - ox, my = py - oy, mz = pz - oz;
-                const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
-                hit = sqrtf(d2) * 1.000001f < r0.w - delta - margin;
+                const float delta = sqrt_1ulp(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                hit = sqrt_1ulp(d2) * 1.000001f < r0.w - delta - margin;
                 if (hit) point_to_plane_row(px, py, pz, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, ap.scheme, ap.sigma, row);
             }
             if (!hit) {
@@ -2266,13 +2283,13 @@ __device__ __forceinline__ void iterate_late_body(GridView g, IterInputs in, Reg
                         float ox, oy, oz;  // where the target was when its neighbour was searched
                         transform_point(hist_s[k % CACHE_HIST], t4.x, t4.y, t4.z, ox, oy, oz);
                         const float mx = px - ox, my = py - oy, mz = pz - oz;
-                        const float delta = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
+                        const float delta = sqrt_1ulp(fmaf(mz, mz, fmaf(my, my, mx * mx))) * 1.000001f + 1e-7f;
                         outside = __int_as_float(c.y) - delta;
-                        hit = sqrtf(d2) * 1.000001f < outside - margin;
+                        hit = sqrt_1ulp(d2) * 1.000001f < outside - margin;
                     }
                     if (hit) {
                         const float4 wn = in.normals[hit_pos];
-                        const float bound = fminf(outside, sqrtf(others2) * 0.999999f);
+                        const float bound = fminf(outside, sqrt_1ulp(others2) * 0.999999f);
                         in.rec[2 * (size_t)qi] = make_float4(wq.x, wq.y, wq.z, bound);
                         in.rec[2 * (size_t)qi + 1] = make_float4(wn.x, wn.y, wn.z, __int_as_float(iter_now));
                         point_to_plane_row(px, py, pz, wq.x, wq.y, wq.z, wn.x, wn.y, wn.z, ap.scheme, ap.sigma, row);
