@@ -223,6 +223,13 @@ int icp_synchronize(icp_ctx* ctx);
  *   "insert_by_cell" 0 | 1 (1)      behind a map update the points claim their cells of the new grid in the cell order of the
  *                                   previous grid (a rigid step leaves the points of an old cell in one or two new ones: the lanes
  *                                   of a wave share their claims) instead of in insertion order
+ *   "normals_list" 0 | 1 (0)        the stragglers of the eager kNN normals — the ~0.3 % of the map points whose k-th neighbour
+ *                                   the pair pass does not certify — go to a list and a launch of their own right behind the
+ *                                   estimating one: sixteen lanes per point, exact keys, DPP merges, ring 2 by hashed probes
+ *                                   (0: each is finished by a whole wave of the workgroup that met it).  Same normals, bit for
+ *                                   bit.  Off by default: measured, the pair pass alone takes 37 us and the stragglers' launch
+ *                                   55 behind it, against 62 us with the stragglers inside (their chains overlap the other
+ *                                   workgroups' pair passes there)
  *   "normals_tail_stream" 0 | 1 (0) the eager kNN normals behind a map update finish their stragglers (the ~0.2 % of the map
  *                                   points whose k-th neighbour ring 1 does not certify: a ~30 us chain of dependent probes
  *                                   each) on that stream of the context's own instead of inside the estimating launch: they run

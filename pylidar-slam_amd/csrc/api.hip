@@ -449,6 +449,7 @@ int icp_set_option(icp_ctx* ctx, const char* name, double value) {
     else if (k == "insert_by_cell") ctx->insert_by_cell = iv != 0 ? 1 : 0;
     else if (k == "cell_lists") ctx->cell_lists = iv != 0 ? 1 : 0;
     else if (k == "normals_tail_stream") ctx->normals_tail_stream = iv != 0 ? 1 : 0;
+    else if (k == "normals_list") ctx->normals_list = iv != 0 ? 1 : 0;
     else if (k == "ball_lanes") ctx->ball_lanes = iv >= 8 ? 8 : (iv >= 4 ? 4 : (iv >= 2 ? 2 : 1));
     else if (k == "ball_empty") ctx->ball_empty = iv != 0 ? 1 : 0;
     else if (k == "ball_max") ctx->ball_max = iv < 4 ? 4 : (iv > 256 ? 256 : (int)iv);

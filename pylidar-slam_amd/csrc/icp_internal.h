@@ -572,7 +572,9 @@ struct icp_ctx {
     // loop 0.44-0.48 vs 0.44-0.46 ms per frame
     int overlap_map_update = 0;
     int normals_tail_stream = 0;        // "normals_tail_stream": the stragglers of the eager kNN normals behind a map update run on the map stream (measured: no gain, off)
-    icp::DeviceBuffer normals_tail;     // [1 + M] int: count, positions of the stragglers
+    int normals_list = 0;               // "normals_list": the stragglers of the two-lane kNN-normal kernel go to a list and a launch of their own, sixteen lanes each (k_normals_tail16: built in round 6, bit-identical, measured slower — 37 + 55 us against 62); 0: a wave of their workgroup each
+    bool normals_tail_on_map_stream = false;  // (argument of the launch in flight)
+    icp::DeviceBuffer normals_tail;     // [2 + M] int: count, workgroups of the tail launch that are through, positions of the stragglers
     int* normals_tail_list = nullptr;   // (argument of the launch in flight)
     hipStream_t map_stream = nullptr;
     hipEvent_t map_done_event = nullptr, map_start_event = nullptr;

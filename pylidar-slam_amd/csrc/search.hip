@@ -3009,7 +3009,16 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
 #pragma unroll
     for (int round = 0; round < KN; ++round) {
         unsigned long long best = t.key[0];
-        if (NL > 4) {  // a whole wave: the LDS crossbar
+        if (NL == 16) {  // a row of 16 lanes: DPP (search_device.h::row16_step)
+            unsigned long long other = row16_step<0>(best);
+            best = other < best ? other : best;
+            other = row16_step<1>(best);
+            best = other < best ? other : best;
+            other = row16_step<2>(best);
+            best = other < best ? other : best;
+            other = row16_step<3>(best);
+            best = other < best ? other : best;
+        } else if (NL > 4) {  // a whole wave: the LDS crossbar
 #pragma unroll
             for (int o = 1; o < NL; o <<= 1) {
                 const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
@@ -3214,6 +3223,7 @@ __device__ inline int bucket_owner(float x, float y, float z, int world) {
 // head counter serialises a thousand waves on one address, 7 ms.)
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr unsigned HOOD_JMASK = 2047u;
+static constexpr int TAIL_HEADER = 2;  // words in front of the stragglers' list: their count, the workgroups of the tail launch that are through
 static constexpr int NRM2_THREADS = 128;  // 64 map points x 2 lanes
 
 template <int N>
@@ -3330,7 +3340,7 @@ __device__ inline void normal_of_straggler(const GridView& g, int ps, int lane, 
 // the next frame's preprocessing on the caller's stream (api.hip: DeviceGuard's join orders every reader of the normals behind
 // it).  A launch of its own behind this one on the SAME stream was tried in round 4 (+31 us: the 30 us chain per straggler sets
 // the duration of whatever launch runs it); on a stream of its own that chain has ~50 us of independent work to hide behind.
-template <int KN, bool OWNED>
+template <int KN, bool OWNED, bool LIST = false>
 __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int max_rings, int rank, int world,
                                                                 float4* __restrict__ out, int* __restrict__ nflag,
                                                                 int* __restrict__ tail) {
@@ -3369,31 +3379,213 @@ __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int 
             nflag[s2] = 1;
         }
     }
-    if (tail) {  // (kernel argument: uniform) the stragglers go to the chip-wide list
+    if constexpr (LIST) {  // the stragglers go to the chip-wide list (k_normals_tail16 / k_normals_tail behind this launch)
         if (npend > 0) {
             __shared__ int tail_base;
             if (threadIdx.x == 0) tail_base = atomicAdd(&tail[0], npend);
             __syncthreads();
-            if ((int)threadIdx.x < npend) tail[1 + tail_base + threadIdx.x] = pend_s[threadIdx.x];
+            if ((int)threadIdx.x < npend) tail[TAIL_HEADER + tail_base + threadIdx.x] = pend_s[threadIdx.x];
         }
-        return;
+    } else {
+        // ---- the stragglers of this workgroup, a wave per point
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < npend; k += NRM2_THREADS / 64)  // wave-uniform
+            normal_of_straggler<KN, OWNED>(g, pend_s[k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
     }
-    // ---- the stragglers of this workgroup, a wave per point
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = wave; k < npend; k += NRM2_THREADS / 64)  // wave-uniform
-        normal_of_straggler<KN, OWNED>(g, pend_s[k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
 }
 
 // the stragglers of k_normals_hood2 (`tail` list), a wave per point, on a stream of their own
+// The stragglers of k_normals_hood2<.., LIST> — map points whose KN-th neighbour the pair pass does not certify, 0.3 % of a
+// LiDAR map: 70 % of them in sparse cells (ring 2 needed), the rest points of dense cells whose KN-th and KN + 1-th neighbours
+// the truncated 32-bit keys cannot tell apart — in a launch of their own, SIXTEEN lanes per point (round 6; option
+// "normals_list", OFF by default).  Inside k_normals_hood2 each is finished by a whole wave of the workgroup that met it (ring 1
+// again with exact keys, a 64-lane merge through the LDS crossbar, the cells of ring 2 the KN-th distance reaches, another
+// merge, ten dependent loads and the Jacobi solve on one lane): the launch lasts 62 us at the benchmark sizes where the pair
+// pass alone takes 37 (88 against 42 us on the published configuration's 181 695-point map).  Here lane l of a row of 16 takes
+// entries l, l + 16, .. of the cell's neighbourhood list with exact 64-bit keys, the sixteen sorted lists are merged by DPP
+// row exchanges (no LDS); what ring 1 does not certify probes the shell cells of ring 2 its KN-th distance reaches (seven
+// hashed probes per lane, grid_lookup7), scans them and merges again; the members' covariance terms are formed by lanes
+// 1 .. KN - 1, one member each, and summed over the row (order-independent sums: CovSums); lane 0 solves.  What ring 2 does
+// not certify either (a point or two per frame) and lists beyond 2 048 entries take the whole-wave path, wave-uniformly,
+// inside this launch.  Same neighbours, same sums: the same bits (tests: `normals_list` variants).
+// MEASURED (profiles/r06_normals_stragglers.txt): the pair pass without its stragglers 37 us (96 registers: occupancy 5) —
+// and this launch 55 us behind it (35 at best): 92 against 62.  A straggler is a chain — list, merge, probes, cells, merge,
+// members, Jacobi: 13 us for ring 1, 27 more for ring 2 and the members, 5.5 for the solve — whoever runs it; inside the pair
+// kernel that chain starts when a workgroup's pair pass ends and overlaps the other workgroups' passes, in a launch of its own
+// it starts when ALL of them have ended.  Sixteen lanes walk a cell list four times as long as 64 do.  Kept behind its option
+// as the record of the experiment; the published configuration hides its normals behind the host's upload of the next frame
+// either way (frame time 0.417 -> 0.410 ms with NO stragglers at all).
+// tail[0] = count, tail[1] = workgroups of this launch that are through (the last one zeroes both: the list is ready for the
+// next build without a memset launch), positions from tail[TAIL_HEADER].
+static constexpr int TAIL16_THREADS = 256;
+
+// shell cell number s (0 .. 97) of ring 2 -> its offsets: the two 5 x 5 faces z = -2 / +2, then for z = -1, 0, 1 the 16 cells
+// around the 3 x 3 interior
+__device__ inline void ring2_shell_cell(int s, int& ox, int& oy, int& oz) {
+    if (s < 50) {
+        oz = s < 25 ? -2 : 2;
+        const int xy = s < 25 ? s : s - 25;
+        ox = xy % 5 - 2;
+        oy = xy / 5 - 2;
+    } else {
+        const int t = s - 50, r = t & 15;
+        oz = (t >> 4) - 1;
+        if (r < 5) {
+            ox = r - 2;
+            oy = -2;
+        } else if (r < 10) {
+            ox = r - 7;
+            oy = 2;
+        } else {
+            ox = ((r - 10) & 1) ? 2 : -2;
+            oy = ((r - 10) >> 1) - 1;
+        }
+    }
+}
+
+// true: lane 0 of the row holds the covariance in cov6[0..5]
 template <int KN>
-__global__ __launch_bounds__(NRM2_THREADS) void k_normals_tail(GridView g, int max_rings, const int* __restrict__ tail,
+__device__ inline bool cov_ring2_row16(const GridView& g, int ps, int sub, float (&cov6)[6]) {
+    const float4 P = g.pts[ps];
+    const float px = P.x, py = P.y, pz = P.z;
+    const float h = g.h;
+    const int cx = cell_coord(px, g.inv_h), cy = cell_coord(py, g.inv_h), cz = cell_coord(pz, g.inv_h);
+    const float fx = fminf(fmaxf(px - (float)cx * h, 0.f), h);
+    const float fy = fminf(fmaxf(py - (float)cy * h, 0.f), h);
+    const float fz = fminf(fmaxf(pz - (float)cz * h, 0.f), h);
+    const float edge = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
+    if (hh.y > 2048) return false;  // (row-uniform) the wave path
+    if (g.dbg && sub == 0) atomicAdd(&g.dbg[7], 1);  // ("knn: beyond ring 1")
+    TopK<KN> t, m;
+    t.init();
+    {  // ring 1: the cell's neighbourhood list with exact 64-bit keys, four entries of the lane in flight
+        const float4* __restrict__ H = g.hood + hh.x;
+        const int n = hh.y;
+        for (int j = sub; j < n; j += 64) {
+            const bool v1 = j + 16 < n, v2 = j + 32 < n, v3 = j + 48 < n;
+            const float4 q0 = H[j], q1 = H[v1 ? j + 16 : j], q2 = H[v2 ? j + 32 : j], q3 = H[v3 ? j + 48 : j];
+            t.insert(point_key(q0, px, py, pz));
+            if (v1) t.insert(point_key(q1, px, py, pz));
+            if (v2) t.insert(point_key(q2, px, py, pz));
+            if (v3) t.insert(point_key(q3, px, py, pz));
+        }
+    }
+    merge_group<KN, 16>(t, m);
+    // most stragglers are points of DENSE cells whose KN-th and KN + 1-th neighbours the pair pass's truncated 32-bit keys
+    // could not tell apart: the exact keys settle them inside ring 1
+    const float bound1 = h + edge;
+    if (!(m.kth() <= bound1 * bound1 * 0.999999f)) {  // (row-uniform: m is the same in the sixteen lanes)
+        // the shell of ring 2: the cells whose box the KN-th distance so far reaches, seven hashed probes per lane in flight
+        const float kth = m.kth();
+        int2 found[7];
+        int want = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (sub + 16 * k < 98) {
+                int ox, oy, oz;
+                ring2_shell_cell(sub + 16 * k, ox, oy, oz);
+                const float gx = axis_gap(ox, fx, h), gy = axis_gap(oy, fy, h), gz = axis_gap(oz, fz, h);
+                if (!(fmaf(gx, gx, fmaf(gy, gy, gz * gz)) > kth)) want |= 1 << k;
+            }
+        }
+        grid_lookup7(g, want, [&](int k) {
+            int ox, oy, oz;
+            ring2_shell_cell(sub + 16 * k, ox, oy, oz);
+            return pack_cell(cx + ox, cy + oy, cz + oz);
+        }, found);
+        if (sub == 0) {
+            t = m;  // (what ring 1 found rides in lane 0's list)
+        } else {
+            t.init();
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (found[k].y > 0) scan_cell_knn<KN>(g, found[k].x, found[k].y, px, py, pz, t);
+        merge_group<KN, 16>(t, m);
+        // ring 2 certifies the KN-th neighbour (finite: the map holds KN points within its reach)
+        const float bound = 2.0f * h + edge;
+        if (!(m.kth() <= bound * bound * 0.999999f)) return false;
+    }
+    // the covariance (neighbourhood_cov's terms: members 1 .. KN - 1, the nearest — the point itself or a twin — dropped): one
+    // member per lane, summed over the row
+    CovSums cs;
+    cs.zero();
+    unsigned long long mine = KEY_EMPTY;
+#pragma unroll
+    for (int i = 1; i < KN; ++i)
+        if (i % 16 == sub) mine = m.key[i];  // (KN - 1 <= 15 members: lanes 1 .. KN - 1)
+    static_assert(KN <= 16, "one member per lane of the row");
+    if (sub >= 1 && sub < KN) {
+        const float4 q = g.pts[g.pos_of_orig[key_idx(mine)]];
+        cs.add(q.x - px, q.y - py, q.z - pz);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cs.c[k] = row16_sum(cs.c[k]);
+    cs.store(KN - 1, cov6);
+    return true;
+}
+
+template <int KN>
+__global__ __launch_bounds__(TAIL16_THREADS) void k_normals_tail16(GridView g, int max_rings, int* __restrict__ tail,
+                                                                   float4* __restrict__ out, int* __restrict__ nflag) {
+    __shared__ int wl[TAIL16_THREADS / 64][128];
+    __shared__ float wcov[TAIL16_THREADS / 64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, sub = lane & 15;
+    const int count = tail[0];
+    const int waves = gridDim.x * (TAIL16_THREADS / 64);
+    for (int k0 = 4 * (blockIdx.x * (TAIL16_THREADS / 64) + wave); k0 < count; k0 += 4 * waves) {  // wave-uniform
+        const int k = k0 + row;
+        const bool mine = k < count;  // row-uniform
+        const int ps = mine ? tail[TAIL_HEADER + k] : 0;
+        bool ok = !mine;
+        if (mine) {
+            float cov6[6];
+            ok = cov_ring2_row16<KN>(g, ps, sub, cov6);
+            if (ok && sub == 0) {
+                float nx, ny, nz;
+                smallest_eigenvector(cov6[0], cov6[1], cov6[2], cov6[3], cov6[4], cov6[5], nx, ny, nz);
+                out[ps] = make_float4(nx, ny, nz, 1.f);
+                nflag[ps] = 1;
+            }
+        }
+        // what the rows could not settle: the whole wave, one point after the other (wave-uniform)
+        const unsigned long long failed = __ballot(!ok);
+        for (int r = 0; r < 4; ++r) {
+            if (!((failed >> (16 * r)) & 1ull)) continue;
+            const int ps2 = __builtin_amdgcn_readlane(ps, 16 * r);
+            normal_of_straggler<KN, false>(g, ps2, lane, max_rings, wcov[wave], wl[wave], out, nflag);
+        }
+    }
+    // the last workgroup through empties the list for the next build
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&tail[1], 1) == (int)gridDim.x - 1) {
+            tail[0] = 0;
+            tail[1] = 0;
+        }
+    }
+}
+
+// the stragglers of k_normals_hood2 (`tail` list), a wave per point, on a stream of their own ("normals_tail_stream")
+template <int KN>
+__global__ __launch_bounds__(NRM2_THREADS) void k_normals_tail(GridView g, int max_rings, int* __restrict__ tail,
                                                                float4* __restrict__ out, int* __restrict__ nflag) {
     __shared__ int wl[NRM2_THREADS / 64][128];
     __shared__ float wcov[NRM2_THREADS / 64][8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = tail[0], waves = gridDim.x * (NRM2_THREADS / 64);
     for (int k = blockIdx.x * (NRM2_THREADS / 64) + wave; k < count; k += waves)  // wave-uniform
-        normal_of_straggler<KN, false>(g, tail[1 + k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
+        normal_of_straggler<KN, false>(g, tail[TAIL_HEADER + k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&tail[1], 1) == (int)gridDim.x - 1) {
+            tail[0] = 0;
+            tail[1] = 0;
+        }
+    }
 }
 
 template <int KN, int NL>
@@ -3627,14 +3819,23 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
     int* nf = ctx->nflag.as<int>();
     if (NL == 4 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {  // two lanes per point, one pass over the list
         const int b2 = (int)((ctx->map_m + NRM2_THREADS / 2 - 1) / (NRM2_THREADS / 2));
-        int* tail = ctx->normals_tail_list;  // (set by launch_normals_all when the stragglers go to the map stream)
+        int* tail = ctx->normals_tail_list;  // (set by launch_normals_all: the stragglers go to a list and a launch of their own)
+        if (!tail) {  // "normals_list" 0: every workgroup finishes its own stragglers, a wave each (rounds 4-5)
+            if (kn == 11)
+                hipLaunchKernelGGL((k_normals_hood2<11, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+                                   nf, tail);
+            else
+                hipLaunchKernelGGL((k_normals_hood2<6, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+                                   nf, tail);
+            return;
+        }
         if (kn == 11)
-            hipLaunchKernelGGL((k_normals_hood2<11, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+            hipLaunchKernelGGL((k_normals_hood2<11, false, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
                                nf, tail);
         else
-            hipLaunchKernelGGL((k_normals_hood2<6, false>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
+            hipLaunchKernelGGL((k_normals_hood2<6, false, true>), dim3(b2), dim3(NRM2_THREADS), 0, ctx->stream, g, rings, 0, 1, nrm,
                                nf, tail);
-        if (tail) {  // the stragglers: on `tail_stream`, behind the launch above
+        if (ctx->normals_tail_on_map_stream) {  // "normals_tail_stream": a wave per straggler on the map stream, behind the launch above
             (void)hipEventRecord(ctx->map_start_event, ctx->stream);
             (void)hipStreamWaitEvent(ctx->map_stream, ctx->map_start_event, 0);
             int tb = b2 / 2;  // (a sparse map is all stragglers: as many waves as the pair pass had workgroups; at least 64)
@@ -3646,6 +3847,14 @@ static void launch_normals_all_t(icp_ctx* ctx, int kn, const GridView& g) {
                 hipLaunchKernelGGL((k_normals_tail<6>), dim3(tb), dim3(NRM2_THREADS), 0, ctx->map_stream, g, rings, tail, nrm, nf);
             (void)hipEventRecord(ctx->map_done_event, ctx->map_stream);
             ctx->map_stream_busy = true;
+        } else {  // sixteen lanes per straggler, right behind (a LiDAR map leaves 0.3 % of its points: a few hundred rows of 16)
+            int tb = b2 / 16;  // (a sparse map is all stragglers: 16 rows per workgroup, a few trips each)
+            if (tb < 64) tb = 64;
+            if (tb > 1024) tb = 1024;
+            if (kn == 11)
+                hipLaunchKernelGGL((k_normals_tail16<11>), dim3(tb), dim3(TAIL16_THREADS), 0, ctx->stream, g, rings, tail, nrm, nf);
+            else
+                hipLaunchKernelGGL((k_normals_tail16<6>), dim3(tb), dim3(TAIL16_THREADS), 0, ctx->stream, g, rings, tail, nrm, nf);
         }
         return;
     }
@@ -3671,19 +3880,29 @@ int launch_normals_all(icp_ctx* ctx, bool tail_may_overlap) {
     if (ctx->normals_ready || ctx->map_m <= 0) return ICP_OK;
     if (kn != 11 && kn != 6 && kn != 21) return ICP_OK;  // generic k stays lazy
     GridView g = make_view(ctx);
-    // "normals_tail_stream": behind a map update (nothing reads a normal before the next entry point that joins the map
-    // stream) the stragglers of the two-lane kernel run on that stream, beside the next frame's preprocessing
+    // "normals_list" (round 6, default): the stragglers of the two-lane kernel — points ring 1 does not certify — go to a list
+    // and a launch of their own right behind it (k_normals_tail16).  "normals_tail_stream": behind a map update (nothing reads
+    // a normal before the next entry point that joins the map stream) that launch is round 5's wave-per-straggler kernel on
+    // the map stream, beside the next frame's preprocessing (measured neutral then; kept for comparison)
     ctx->normals_tail_list = nullptr;
-    if (tail_may_overlap && ctx->normals_tail_stream && ctx->knn_lanes != 2 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6) &&
-        !ctx->exchange_on && !ctx->prof.enabled && !ctx->search_stats && ctx->stream != ctx->map_stream) {
-        if (!ctx->map_stream) {
+    ctx->normals_tail_on_map_stream = false;
+    if (ctx->knn_lanes != 2 && g.hood && ctx->hoods >= 2 && (kn == 11 || kn == 6)) {
+        const bool other_stream = tail_may_overlap && ctx->normals_tail_stream && !ctx->exchange_on && !ctx->prof.enabled &&
+                                  !ctx->search_stats && ctx->stream != ctx->map_stream;
+        if (other_stream && !ctx->map_stream) {
             ICP_HIP(ctx, hipStreamCreateWithFlags(&ctx->map_stream, hipStreamNonBlocking));
             ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_done_event, hipEventDisableTiming));
             ICP_HIP(ctx, hipEventCreateWithFlags(&ctx->map_start_event, hipEventDisableTiming));
         }
-        ICP_HIP(ctx, ctx->normals_tail.reserve(((size_t)ctx->map_m + 1) * sizeof(int)));
-        ICP_HIP(ctx, hipMemsetAsync(ctx->normals_tail.ptr, 0, sizeof(int), ctx->stream));
-        ctx->normals_tail_list = ctx->normals_tail.as<int>();
+        if (other_stream || ctx->normals_list) {
+            const size_t need = ((size_t)ctx->map_m + TAIL_HEADER) * sizeof(int);
+            if (ctx->normals_tail.bytes < need) {  // (a fresh list: its header zeroed once — every tail launch leaves it zeroed)
+                ICP_HIP(ctx, ctx->normals_tail.reserve(need + need / 4));  // (hipFree of the old block synchronises the device)
+                ICP_HIP(ctx, hipMemsetAsync(ctx->normals_tail.ptr, 0, TAIL_HEADER * sizeof(int), ctx->stream));
+            }
+            ctx->normals_tail_list = ctx->normals_tail.as<int>();
+            ctx->normals_tail_on_map_stream = other_stream;
+        }
     }
     const int tok = prof_begin(ctx, 2);
     if (ctx->knn_lanes == 2)

@@ -32,6 +32,34 @@ __device__ inline float quad_min(float v) {
     return fminf(v, quad_xor<2>(v));
 }
 
+// Exchanges inside a ROW of 16 lanes (the lanes of one straggler of the kNN normals, search.hip::k_normals_tail16) by DPP:
+// STEP 0 / 1 = the lane ^ 1 / ^ 2 (quad permutes), STEP 2 = the mirror of each half row (lane i <-> 7 - i: the other quad of
+// the half), STEP 3 = the mirror of the row (i <-> 15 - i: the other half).  After the four steps of a minimum — or of an
+// order-independent sum — every lane of the row holds the row's result; one VALU instruction per 32-bit word and step, where
+// __shfl_xor pays an address computation, a ds_bpermute and the wait for the LDS crossbar.  All sixteen lanes must be active.
+template <int STEP>
+__device__ inline int row16_step(int v) {
+    static_assert(STEP >= 0 && STEP <= 3, "four steps cover a row of 16");
+    constexpr int ctrl = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x141 : 0x140));  // quad_perm x2, row_half_mirror, row_mirror
+    return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);
+}
+template <int STEP>
+__device__ inline unsigned long long row16_step(unsigned long long v) {
+    const unsigned lo = (unsigned)row16_step<STEP>((int)(unsigned)(v & 0xffffffffull));
+    const unsigned hi = (unsigned)row16_step<STEP>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int STEP>
+__device__ inline double row16_step(double v) {
+    return __longlong_as_double((long long)row16_step<STEP>((unsigned long long)__double_as_longlong(v)));
+}
+__device__ inline double row16_sum(double v) {  // (sums of multiples of 2^-40 below 2^13: exact in any order — CovSums)
+    v += row16_step<0>(v);
+    v += row16_step<1>(v);
+    v += row16_step<2>(v);
+    return v + row16_step<3>(v);
+}
+
 struct Best {
     float d2;
     int idx;       // original index (tie-break)

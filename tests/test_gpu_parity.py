@@ -414,6 +414,9 @@ def test_schedule_options_are_bit_identical(torch_cuda):
                 "no_carry_tail_stream": {"carry_normals": 0, "normals_tail_stream": 1},
                 "no_carry_small_cells": {"carry_normals": 0, "target_occupancy": 2},  # (tiny cells: many stragglers)
                 "no_carry_small_cells_tail_stream": {"carry_normals": 0, "target_occupancy": 2, "normals_tail_stream": 1},
+                # round 6 (off by default): the stragglers in a launch of their own, sixteen lanes each, against a wave of their workgroup each
+                "no_carry_listed_stragglers": {"carry_normals": 0, "normals_list": 1},
+                "no_carry_small_cells_listed_stragglers": {"carry_normals": 0, "target_occupancy": 2, "normals_list": 1},
                 "lazy_fused_no_lead": {"lazy_fused": 2, "lead_solve": 0, "carry_normals": 0},
                 "lazy_fused_nocache": {"lazy_fused": 2, "nn_cache": 0, "carry_normals": 0}, "never_lazy_fused": {"lazy_fused": 0},
                 "lazy_fused_carried": {"lazy_fused": 2},  # (held to 1e-6 below, not to the bit)
@@ -746,10 +749,13 @@ def test_knn_normals_on_stress_clouds(torch_cuda, O, neighbors):
         np.testing.assert_array_equal(eager, whole[ix, :3], err_msg=f"{name} eager")
         ctx.close()
         # the eager kernels of the earlier rounds behind their options: four lanes per point over the neighbourhood lists
-        # (hoods 1), the row walk (hoods 0) — the default (hoods 2) is one lane per point + a queue of the stragglers
-        for hoods in (1, 0):
+        # (hoods 1), the row walk (hoods 0) — the default (hoods 2) is two lanes per point + a wave of the workgroup per
+        # straggler; round 6's stragglers in a launch of their own, sixteen lanes each ("normals_list" 1): hoods = -2 below
+        for hoods in (1, 0, -2):
             ctx = _ctx(num_neighbors_normals=neighbors, max_num_alignments=1, threshold_delta_pose=0.0)
-            ctx.set_option("hoods", hoods)
+            if hoods < 0:
+                ctx.set_option("normals_list", 1)
+            ctx.set_option("hoods", abs(hoods))
             ctx.map_set(cloud)
             owned = ctx.map_normals_owned(0, 1).cpu().numpy()
             np.testing.assert_array_equal(owned, whole, err_msg=f"{name} owned, hoods {hoods}")
@@ -945,6 +951,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
                 "no_carry": {"carry_normals": 0},
                 # the stragglers of the eager normals on the map stream instead of inside the estimating launch: equal to `no_carry`
                 "no_carry_tail_stream": {"carry_normals": 0, "normals_tail_stream": 1},
+                "no_carry_listed_stragglers": {"carry_normals": 0, "normals_list": 1},  # (round 6: a launch of their own, 16 lanes each)
                 "lazy_fused": {"lazy_fused": 2, "carry_normals": 0}}  # normals on demand inside the fused kernel: equal to `no_carry`
     results = {}
     for name, opts in variants.items():
@@ -969,7 +976,7 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
         ctx.close()
     problems = []
     for name, (frames, ix, pose12, nrm, mp) in results.items():
-        ref = results["no_carry" if name in ("lazy_fused", "no_carry_tail_stream") else "default"]
+        ref = results["no_carry" if name in ("lazy_fused", "no_carry_tail_stream", "no_carry_listed_stragglers") else "default"]
         if name == "no_carry":  # (the reference's schedule against the carried one: rounding apart)
             for r, rr in zip(frames, results["default"][0]):
                 np.testing.assert_allclose(r.pose, rr.pose, atol=1e-6)
