@@ -3018,7 +3018,32 @@ __device__ inline void merge_group(TopK<KN>& t, TopK<KN>& m) {
             best = other < best ? other : best;
             other = row16_step<3>(best);
             best = other < best ? other : best;
-        } else if (NL > 4) {  // a whole wave: the LDS crossbar
+        } else if (NL == 64) {
+            // a whole wave (round 6): the minimum of every row of 16 by DPP, then the four rows' minima read into scalar
+            // registers (v_readlane) — 4 x 5 + 8 + 9 VALU instructions where six __shfl_xor steps of a 64-bit key were twelve
+            // ds_bpermute round trips through the LDS crossbar (~800 cycles per round, eleven rounds per merge, two or three
+            // merges per straggler of the kNN normals).  Every lane of the wave must be active.
+            unsigned long long other = row16_step<0>(best);
+            best = other < best ? other : best;
+            other = row16_step<1>(best);
+            best = other < best ? other : best;
+            other = row16_step<2>(best);
+            best = other < best ? other : best;
+            other = row16_step<3>(best);
+            best = other < best ? other : best;
+            const unsigned blo = (unsigned)(best & 0xffffffffull), bhi = (unsigned)(best >> 32);
+            unsigned long long r0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)bhi, 0) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)blo, 0);
+            const unsigned long long r1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)bhi, 16) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)blo, 16);
+            const unsigned long long r2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)bhi, 32) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)blo, 32);
+            const unsigned long long r3 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)bhi, 48) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)blo, 48);
+            r0 = r1 < r0 ? r1 : r0;
+            const unsigned long long r23 = r3 < r2 ? r3 : r2;
+            best = r23 < r0 ? r23 : r0;
+        } else if (NL > 4) {  // (other group sizes: the LDS crossbar)
 #pragma unroll
             for (int o = 1; o < NL; o <<= 1) {
                 const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
@@ -3308,20 +3333,37 @@ __device__ inline bool cov_hood_pair(const GridView& g, int s, int sub, float* _
 
 // one straggler of the pair pass by a whole wave: the merged list of ring 1 from the cell's neighbourhood list, then
 // finish_cov_wave (fine ring 2, coarse level, exhaustive) and the eigen-solve; `wcov` / `wl` = the wave's LDS scratch
+// `cov_out` (round 6): the covariance is left there (LDS, six floats) and nothing is solved — the caller's dense pass of
+// eigen-solves takes the point with the others (the Jacobi solve is a 5 us chain on one lane: per straggler here, once per
+// workgroup there)
 template <int KN, bool OWNED>
 __device__ inline void normal_of_straggler(const GridView& g, int ps, int lane, int max_rings, float* __restrict__ wcov,
-                                           int* __restrict__ wl, float4* __restrict__ out, int* __restrict__ nflag) {
+                                           int* __restrict__ wl, float4* __restrict__ out, int* __restrict__ nflag,
+                                           float* __restrict__ cov_out = nullptr) {
     const float4 P = g.pts[ps];
     const int2 hh = g.rows[(size_t)g.row_of_pos[ps] * ROW_STRIDE + 27];
     TopK<KN> t, m;
     t.init();
     for (int j = lane; j < hh.y; j += 64) t.insert(point_key(g.hood[hh.x + j], P.x, P.y, P.z));
     merge_group<KN, 64>(t, m);  // = the merged list estimate_cov leaves behind ring 1
-    finish_cov_wave<KN>(g, ps, lane, max_rings, m, wcov, wl);
+    // (round 6) three stragglers in ten are points of DENSE cells whose KN-th and KN + 1-th neighbours the pair pass's
+    // truncated keys could not tell apart: the exact keys settle them inside ring 1, no ring 2
+    const float h = g.h;
+    const float fx = fminf(fmaxf(P.x - (float)cell_coord(P.x, g.inv_h) * h, 0.f), h);
+    const float fy = fminf(fmaxf(P.y - (float)cell_coord(P.y, g.inv_h) * h, 0.f), h);
+    const float fz = fminf(fmaxf(P.z - (float)cell_coord(P.z, g.inv_h) * h, 0.f), h);
+    const float bound1 = h + fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz));
+    if (m.kth() <= bound1 * bound1 * 0.999999f) {  // (wave-uniform: m is the same in every lane)
+        if (lane == 0) neighbourhood_cov<KN>(g, P.x, P.y, P.z, m, wcov);
+    } else {
+        finish_cov_wave<KN>(g, ps, lane, max_rings, m, wcov, wl);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
+    if (cov_out) {
+        if (lane < 6) cov_out[lane] = wcov[lane];
+    } else if (lane == 0) {
         float nx, ny, nz;
         smallest_eigenvector(wcov[0], wcov[1], wcov[2], wcov[3], wcov[4], wcov[5], nx, ny, nz);
         if (OWNED) {
@@ -3367,6 +3409,24 @@ __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int 
         if (mine && !ok) pend_s[atomicAdd(&npend, 1)] = s;
     }
     __syncthreads();
+    if constexpr (LIST) {  // the stragglers go to the chip-wide list (k_normals_tail16 / k_normals_tail behind this launch)
+        if (npend > 0) {
+            __shared__ int tail_base;
+            if (threadIdx.x == 0) tail_base = atomicAdd(&tail[0], npend);
+            __syncthreads();
+            if ((int)threadIdx.x < npend) tail[TAIL_HEADER + tail_base + threadIdx.x] = pend_s[threadIdx.x];
+        }
+    } else if (npend > 0) {  // (block-uniform)
+        // ---- the stragglers of this workgroup, a wave per point: their covariances join the others' (round 6: in front of
+        // the dense pass below, which solves them with the rest — the solve was a 5 us chain on one lane per straggler)
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < npend; k += NRM2_THREADS / 64) {  // wave-uniform
+            const int ps = pend_s[k], slot = ps - blockIdx.x * PTS;
+            normal_of_straggler<KN, OWNED>(g, ps, lane, max_rings, wcov[wave], wl[wave], out, nflag, covs[slot]);
+            if (lane == 0) settled[slot] = 1;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < PTS && settled[threadIdx.x]) {  // the eigen-solves on a dense wave
         const int s2 = blockIdx.x * PTS + threadIdx.x;
         float nx, ny, nz;
@@ -3379,22 +3439,8 @@ __global__ __launch_bounds__(NRM2_THREADS) void k_normals_hood2(GridView g, int 
             nflag[s2] = 1;
         }
     }
-    if constexpr (LIST) {  // the stragglers go to the chip-wide list (k_normals_tail16 / k_normals_tail behind this launch)
-        if (npend > 0) {
-            __shared__ int tail_base;
-            if (threadIdx.x == 0) tail_base = atomicAdd(&tail[0], npend);
-            __syncthreads();
-            if ((int)threadIdx.x < npend) tail[TAIL_HEADER + tail_base + threadIdx.x] = pend_s[threadIdx.x];
-        }
-    } else {
-        // ---- the stragglers of this workgroup, a wave per point
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int k = wave; k < npend; k += NRM2_THREADS / 64)  // wave-uniform
-            normal_of_straggler<KN, OWNED>(g, pend_s[k], lane, max_rings, wcov[wave], wl[wave], out, nflag);
-    }
 }
 
-// the stragglers of k_normals_hood2 (`tail` list), a wave per point, on a stream of their own
 // The stragglers of k_normals_hood2<.., LIST> — map points whose KN-th neighbour the pair pass does not certify, 0.3 % of a
 // LiDAR map: 70 % of them in sparse cells (ring 2 needed), the rest points of dense cells whose KN-th and KN + 1-th neighbours
 // the truncated 32-bit keys cannot tell apart — in a launch of their own, SIXTEEN lanes per point (round 6; option

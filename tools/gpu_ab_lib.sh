@@ -1,17 +1,18 @@
 #!/bin/bash
 # A/B of two BUILDS of the library inside one gpurun call (boxes differ by up to 7 % from call to call):
-#   tools/gpu_ab_lib.sh TAG [--tests "pytest -k expression"] [--batched "8,16,48x4"] [--rounds N]
+#   tools/gpu_ab_lib.sh TAG [--tests "pytest -k expression"] [--batched "8,16,48x4"] [--rounds N] [--steps K] [--extra "bench args"]
 # expects tools/ab/base_libicp_mi355x.so (the build to compare with: `git worktree add /tmp/base <commit>; make` and copy it
 # there; *.so is git-ignored and still travels to the box) next to the in-tree build.  Alternates base / new, N rounds.
 set -u
 TAG=$1; shift
-TESTS=""; BATCHED=""; ROUNDS=2; STEPS=70
+TESTS=""; BATCHED=""; ROUNDS=2; STEPS=70; EXTRA=""
 while [ $# -gt 0 ]; do
   case $1 in
     --tests) TESTS=$2; shift 2;;
     --batched) BATCHED=$2; shift 2;;
     --rounds) ROUNDS=$2; shift 2;;
     --steps) STEPS=$2; shift 2;;
+    --extra) EXTRA=$2; shift 2;;   # further bench.py arguments of the headline run, e.g. "--option carry_normals=0"
     *) echo "unknown $1"; exit 2;;
   esac
 done
@@ -25,7 +26,7 @@ fi
 for r in $(seq 1 $ROUNDS); do
   for which in base new; do
     if [ $which = base ]; then cp $BASE $LIB; else cp /tmp/new_lib.so $LIB; fi
-    timeout 300 python bench.py --steps $STEPS --no-cpu-baseline --loop-steps 0 > $OUT/head_$which.json 2> $OUT/head_$which.err
+    timeout 300 python bench.py --steps $STEPS --no-cpu-baseline --loop-steps 0 $EXTRA > $OUT/head_$which.json 2> $OUT/head_$which.err
     python - $OUT/head_$which.json "$which" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get("roofline",{})
