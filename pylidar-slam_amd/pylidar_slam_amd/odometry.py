@@ -655,7 +655,8 @@ class PointToPlaneAlignment:
                      "The argument 'ref_normals' is required for a point to plane alignemnt")
         assert_debug(initial_estimate is None and mask is None,
                      "`initial_estimate` / `mask` are not supported by the MI355X point-to-plane alignment (the "
-                     "frame-to-model loop passes neither, icp_odometry.py:284-287)")
+                     "frame-to-model loop passes neither, icp_odometry.py:284-287; the reference's own align raises on "
+                     "a mask: optimization.py:393-394)")
         r = ref_points.reshape(-1, 3)
         t = tgt_points.reshape(-1, 3)
         n = ref_normals.reshape(-1, 3)

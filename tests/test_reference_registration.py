@@ -97,3 +97,33 @@ def test_dataset_and_filter_registries(reference_on_path, monkeypatch):
     assert d["sample_points"].shape == (3, 3) and d["sample_indices"].shape == (3,)
     # the reference's own members still load
     assert isinstance(flt.load(OmegaConf.create({"filter_name": "grid_sample"})), ref_pre.GridSample)
+
+
+def test_reference_point_to_plane_align_raises_on_a_mask(reference_on_path):
+    """`GaussNewtonPointToPlaneAlignment.align(.., mask=)` (slam/odometry/alignment.py:91-99) does not work in the reference
+    itself: `get_residual_jac_fun` multiplies the [B, N, 6] Jacobian in place by `mask.unsqueeze(1)` = [B, 1, N, 1]
+    (slam/common/optimization.py:393-394), which broadcasts to four dimensions and raises.  The MI355X alignment refuses the
+    argument (AssertionError) instead of inventing a semantics the reference never executed; this pins the reference's side."""
+    import logging
+    logging.disable(logging.WARNING)
+    import numpy as np
+    import torch
+    from slam.common.pose import Pose
+    from slam.odometry.alignment import GaussNewtonPointToPlaneAlignment, GaussNewtonPointToPlaneConfig
+    from pylidar_slam_amd.odometry import PointToPlaneAlignment
+    cfg = GaussNewtonPointToPlaneConfig(gauss_newton_config=dict(max_iters=1, scheme="least_square", sigma=0.5))
+    al = GaussNewtonPointToPlaneAlignment(cfg, pose=Pose("euler"))
+    rng = np.random.default_rng(0)
+    n = 64
+    ref = torch.from_numpy(rng.normal(size=(1, n, 3)).astype(np.float32))
+    tgt = ref + 0.01 * torch.from_numpy(rng.normal(size=(1, n, 3)).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(1, n, 3)).astype(np.float32)), dim=-1)
+    mask = torch.ones(1, n, 1)
+    mask[0, ::3] = 0
+    al.align(ref.clone(), tgt.clone(), nrm.clone())  # (without a mask it runs)
+    with pytest.raises(RuntimeError, match="broadcast shape"):
+        al.align(ref.clone(), tgt.clone(), nrm.clone(), mask=mask)
+    # ... and ours says so before touching a device (no context needed to refuse)
+    ours = PointToPlaneAlignment.__new__(PointToPlaneAlignment)
+    with pytest.raises(AssertionError, match="mask"):
+        ours.align(ref, tgt, nrm, mask=mask)
