@@ -626,21 +626,41 @@ __device__ __forceinline__ Best search_coarse_w(const GridView& g, float px, flo
     return b;
 }
 
-__device__ inline void wave_min64(Best& b) {
-#pragma unroll
-    for (int o = 1; o <= 32; o <<= 1) {
-        const float d2 = __shfl_xor(b.d2, o, 64);
-        const int idx = __shfl_xor(b.idx, o, 64);
-        const int pos = __shfl_xor(b.pos, o, 64);
-        float sec = fminf(b.second, __shfl_xor(b.second, o, 64));
-        if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
-        if (better(d2, idx, b.d2, b.idx)) {
-            b.d2 = d2;
-            b.idx = idx;
-            b.pos = pos;
-        }
-        b.second = sec;
+// (round 6: the four steps inside a row of 16 lanes by DPP — lane ^ 1, ^ 2, the mirror of the half row, the mirror of the row:
+// every step pairs two disjoint groups of lanes, which is all the merge needs — and only the two steps across the rows through
+// the LDS crossbar: 8 ds_bpermute round trips instead of 24 per call, three calls per whole-wave search.  All 64 lanes active.)
+template <int STEP>
+__device__ __forceinline__ void wave_min64_step(Best& b) {
+    float d2, second;
+    int idx, pos;
+    if constexpr (STEP < 4) {
+        d2 = __int_as_float(row16_step<STEP>(__float_as_int(b.d2)));
+        idx = row16_step<STEP>(b.idx);
+        pos = row16_step<STEP>(b.pos);
+        second = __int_as_float(row16_step<STEP>(__float_as_int(b.second)));
+    } else {
+        constexpr int o = STEP == 4 ? 16 : 32;
+        d2 = __shfl_xor(b.d2, o, 64);
+        idx = __shfl_xor(b.idx, o, 64);
+        pos = __shfl_xor(b.pos, o, 64);
+        second = __shfl_xor(b.second, o, 64);
     }
+    float sec = fminf(b.second, second);
+    if (idx != b.idx) sec = fminf(sec, fmaxf(d2, b.d2));  // the loser of two distinct bests is an "other" point
+    if (better(d2, idx, b.d2, b.idx)) {
+        b.d2 = d2;
+        b.idx = idx;
+        b.pos = pos;
+    }
+    b.second = sec;
+}
+__device__ inline void wave_min64(Best& b) {
+    wave_min64_step<0>(b);
+    wave_min64_step<1>(b);
+    wave_min64_step<2>(b);
+    wave_min64_step<3>(b);
+    wave_min64_step<4>(b);
+    wave_min64_step<5>(b);
 }
 
 // One query searched by a WHOLE WAVE (the fused iteration kernel uses it for workgroups with few cache misses: in the
