@@ -1212,11 +1212,42 @@ static constexpr int IT_QUERIES = IT_THREADS / 4;
 // threads reading doubles — 9 conversions per lane instead of 64.  The summing is bound by LDS bandwidth, not by VALU issue:
 // 512 threads x 64 operands x 4 B = 131 KB per workgroup = 0.43 us of the CU's 128 B per clock, twice that with doubles;
 // late launches 10.5 -> 11.1 us, headline and batched throughput -4 %: profiles/r06_ab_sessions.txt.)
-template <int Q, bool RET = false>
+// PADDED (round 6): the caller's row buffer has one spare row behind every 32 (row of slot s at s + (s >> 5)), and a block of
+// 512 queries sums differently: thread = (element e = tid / 16, lane L = 4 * base row + quarter), so that the SIXTEEN partial
+// sums of an element sit in one DPP row of 16 lanes and the canonical tree — (p0 + p1) + (p2 + p3) per base row, then
+// (r0 + r1) + (r2 + r3) — is four DPP exchanges (lane ^ 1, ^ 2, the mirror of the half row, the mirror of the row: each adds
+// exactly the pair the tree adds; a sum does not care which of its two operands comes first) instead of a round through LDS:
+// no `part` array, no barrier, no second stage of 16 reads and 15 dependent adds.  The spare rows spread the sixteen lanes'
+// rows (32 rows = 288 floats apart: one LDS bank) over sixteen banks (33 rows = 297 floats: 9 L mod 32).  Same products,
+// same order, same association: the same bits.
+__device__ __forceinline__ int padded_row(int slot) { return slot + (slot >> 5); }
+
+template <int Q, bool RET = false, bool PADDED = false>
 __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*part)[NEQ], double* __restrict__ partials,
                                            int block) {
     const LocalTid threadIdx = RET ? reloaded_tid() : LocalTid{::threadIdx.x};  // (RET: inside the resident tail's loop)
     constexpr int SUB = Q / IT_QUERIES;  // base rows per block
+    if constexpr (PADDED && SUB == 4 && !RET) {
+        static_assert(NEQ == 32, "one DPP row of 16 lanes per element, 32 elements = 512 threads");
+        if ((int)threadIdx.x < 16 * NEQ) {  // (whole waves: every lane of the rows below is active)
+            const int e = (int)threadIdx.x >> 4, L = (int)threadIdx.x & 15, qtr = L & 3, sb = L >> 2;
+            double acc = 0.0;
+            if (e < NEQ_USED) {
+                int a, b2;
+                neq_operands(e, a, b2);
+                const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
+                const float(*r)[9] = rowbuf + padded_row(j0);  // (32 consecutive rows: j0 is a multiple of 32)
+#pragma unroll 8
+                for (int j = 0; j < IT_QUERIES / 4; ++j) acc = fma((double)r[j][a], (double)r[j][b2], acc);
+            }
+            acc += row16_step<0>(acc);  // p0 + p1 | p2 + p3
+            acc += row16_step<1>(acc);  // (p0 + p1) + (p2 + p3) = the base row's sum, in its four lanes
+            acc += row16_step<2>(acc);  // r0 + r1 | r2 + r3
+            acc += row16_step<3>(acc);  // (r0 + r1) + (r2 + r3)
+            if (L == 0) partials[(size_t)block * NEQ + e] = acc;
+        }
+        return 0.0;
+    }
     if ((int)threadIdx.x < SUB * 4 * NEQ) {
         const int e = threadIdx.x & (NEQ - 1), qtr = (threadIdx.x / NEQ) & 3, sb = threadIdx.x / (4 * NEQ);
         double acc = 0.0;
@@ -1224,10 +1255,11 @@ __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*pa
             int a, b2;
             neq_operands(e, a, b2);
             const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
+            const float(*r)[9] = rowbuf + (PADDED ? padded_row(j0) : j0);
             // (fma: the product of two floats is exact in float64 — 48 mantissa bits — so the fused form rounds once where the
             // separate multiply and add round once too: the same bits, one instruction less per row)
 #pragma unroll 8
-            for (int j = 0; j < IT_QUERIES / 4; ++j) acc = fma((double)rowbuf[j0 + j][a], (double)rowbuf[j0 + j][b2], acc);
+            for (int j = 0; j < IT_QUERIES / 4; ++j) acc = fma((double)r[j][a], (double)r[j][b2], acc);
         }
         part[sb * 4 + qtr][e] = acc;
     }
@@ -1545,7 +1577,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
         g.dbg = nullptr;
         g.stamps = nullptr;
     }
-    __shared__ float rowbuf[Q][9];
+    __shared__ float rowbuf[Q + Q / 32][9];  // (row of slot s at padded_row(s): block_reduce_rows)
     __shared__ double part[Q / 32][NEQ];
     __shared__ int2 cellstack[7][THREADS];
     __shared__ float4 miss_p[Q];   // transformed target + bits(query slot)
@@ -1821,7 +1853,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
             }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rowbuf[lq][k] = row[k];
+        for (int k = 0; k < 9; ++k) rowbuf[padded_row(lq)][k] = row[k];
     }
     __syncthreads();
     if (stamps && threadIdx.x == 0) {
@@ -1851,7 +1883,7 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
         float row[9];
         point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
+        for (int k = 0; k < 9; ++k) rowbuf[padded_row(slot)][k] = row[k];
     };
     // (round 6) a workgroup WITHOUT a miss — nearly every one of a late launch — goes straight to the summing: the rows of its
     // hits are behind the barrier above; the phases below would cost it four dependent reads of the list's counter and a barrier
@@ -2047,17 +2079,17 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
             point_to_plane_row(mp.x, mp.y, mp.z, q.x, q.y, q.z, nn.x, nn.y, nn.z, ap.scheme, ap.sigma, row);
             const int slot = __float_as_int(mp.w);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) rowbuf[slot][k] = row[k];
+            for (int k = 0; k < 9; ++k) rowbuf[padded_row(slot)][k] = row[k];
         }
         if (threadIdx.x == 0) atomicAdd((unsigned long long*)&st->normals_computed, (unsigned long long)listed);
         __syncthreads();
     }
     if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     if (TAIL) {  // the super-row goes to the lead of THIS launch: tagged granules, no fence (solve_device.h)
-        const double v = block_reduce_rows<Q, true>(rowbuf, part, nullptr, vb);
+        const double v = block_reduce_rows<Q, true, true>(rowbuf, part, nullptr, vb);
         if (threadIdx.x < NEQ) tagged_row_store(in.tail_rows, vb, threadIdx.x, gen_now, v);
     } else {
-        block_reduce_rows<Q>(rowbuf, part, in.partials, vb);
+        block_reduce_rows<Q, false, true>(rowbuf, part, in.partials, vb);
     }
     if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
     if (stamps && !dbg_global && threadIdx.x == 0) {  // (top bits of stamps 3 / 0: queries left to B1 / B2, ticks of B0)
