@@ -660,6 +660,7 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead =
 // members' arguments in descriptor tables (pinned host memory -> device memory, copied once per frame by the caller)
 struct BatchedIteration {
     int count = 0, per_seq = 0, shape = 0;
+    int records = 0;  // the members run with hit records: the builds with the record test compiled in
     int rows[ICP_BATCH_MAX_SEQUENCES] = {};
     int quad[ICP_BATCH_MAX_SEQUENCES] = {};
 };

@@ -1569,7 +1569,7 @@ __device__ inline void normal_from_cov(const float* __restrict__ cov, int s, flo
 // workgroup is the lead of its sequence (block-uniform); `pb` / `off`: its physical number among the workgroups of the
 // sequence and the number of lead workgroups in front of them (logical_block); `bx` / `gx`: blockIdx.x / gridDim.x of a
 // launch that holds ONE sequence (the resident tail, the dev stamps).
-template <int THREADS, int Q, bool STATS, bool TAIL, int LAZY_KN>
+template <int THREADS, int Q, bool STATS, bool TAIL, int LAZY_KN, bool REC_BUILD>
 __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState* __restrict__ st, AlignParams ap,
                                              LeadArgs lead, const bool is_lead, const int pb, const int off, const int bx,
                                              const int gx) {
@@ -1638,7 +1638,9 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
            cq3 = cq, cn3 = cq;
     int4 c = make_int4(-1, 0, -1, -1);
     int seed_o = -1, seed_sp = -1;
-    constexpr bool REC = !TAIL && LAZY_KN == 0;  // hit records (see above)
+    // hit records (see above): compiled into the REC_BUILD instantiations only (round 6: the option is off by default — its
+    // tests and the late kernel select those builds; the default kernels carry neither the record test nor its branches)
+    constexpr bool REC = REC_BUILD && !TAIL && LAZY_KN == 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
 #pragma unroll 1
     for (int tj = 0;; ++tj) {  // (one trip unless TAIL)
@@ -2122,15 +2124,15 @@ __device__ __forceinline__ void iterate_body(GridView g, IterInputs in, RegState
     }
 }
 
-template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false, int LAZY_KN = 0>
+template <int MINW, int THREADS, int Q, bool STATS = false, bool TAIL = false, int LAZY_KN = 0, bool REC_BUILD = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_compact(GridView g, IterInputs in,
                                                                    RegState* __restrict__ st, AlignParams ap,
                                                                    LeadArgs lead) {
     // In a lead launch (LeadArgs) workgroup 0 is the lead (the resident tail's lead is its workgroup 0 too, but takes its
     // share of the queries as well: tail_lead_step inside the body)
     const int lead_blocks = (lead.box && !TAIL) ? lead.solve : 0;
-    iterate_body<THREADS, Q, STATS, TAIL, LAZY_KN>(g, in, st, ap, lead, (int)blockIdx.x < lead_blocks, (int)blockIdx.x,
-                                                   lead_blocks, (int)blockIdx.x, (int)gridDim.x);
+    iterate_body<THREADS, Q, STATS, TAIL, LAZY_KN, REC_BUILD>(g, in, st, ap, lead, (int)blockIdx.x < lead_blocks, (int)blockIdx.x,
+                                                              lead_blocks, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2161,7 +2163,7 @@ __device__ __forceinline__ T load_descriptor(const T* table, int index) {
     return out;
 }
 
-template <int MINW, int THREADS, int Q>
+template <int MINW, int THREADS, int Q, bool REC_BUILD = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_iterate_batch(const IterateDesc* __restrict__ table, int nseq, int per_seq) {
     const int p = (int)blockIdx.x;
     int seq, pb;
@@ -2177,7 +2179,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_iterate_batch(const IterateDe
     }
     const IterateDesc d = load_descriptor(table, seq);
     if (is_lead ? !(d.lead.box && d.lead.solve) : pb >= d.blocks) return;  // (no solve pending for this sequence / a shorter scan)
-    iterate_body<THREADS, Q, false, false, 0>(d.g, d.in, d.st, d.ap, d.lead, is_lead, pb, 0, pb, d.blocks);
+    iterate_body<THREADS, Q, false, false, 0, REC_BUILD>(d.g, d.in, d.st, d.ap, d.lead, is_lead, pb, 0, pb, d.blocks);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -4313,8 +4315,13 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
                 hipLaunchKernelGGL((k_iterate_compact<2, IT_THREADS, IT_THREADS, false, true>), grid, dim3(IT_THREADS), 0,
                                    ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
             break;
+        // (`d.in.rec` set — option "hit_records" — selects the builds with the record test compiled in; with the dev stamps
+        // they are not built: the stamped launch of a context with records runs without stamps)
         case SHAPE_WIDE:
-            if (fl.stats)
+            if (d.in.rec)
+                hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, false, false, 0, true>), grid, dim3(2 * IT_THREADS), 0,
+                                   ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
+            else if (fl.stats)
                 hipLaunchKernelGGL((k_iterate_compact<4, 2 * IT_THREADS, IT_THREADS, true>), grid, dim3(2 * IT_THREADS), 0,
                                    ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
             else
@@ -4322,7 +4329,10 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
                                    ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
             break;
         case SHAPE_NARROW:
-            if (fl.stats)
+            if (d.in.rec)
+                hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS, false, false, 0, true>), grid, dim3(IT_THREADS), 0, ctx->stream,
+                                   d.g, d.in, d.st, d.ap, d.lead);
+            else if (fl.stats)
                 hipLaunchKernelGGL((k_iterate_compact<4, IT_THREADS, IT_THREADS, true>), grid, dim3(IT_THREADS), 0, ctx->stream,
                                    d.g, d.in, d.st, d.ap, d.lead);
             else
@@ -4335,12 +4345,14 @@ int launch_iterate_fused(icp_ctx* ctx, int* rows_out, int* quad_out, bool lead_m
             else
                 hipLaunchKernelGGL((k_iterate_late<6, IT_THREADS>), grid, dim3(IT_THREADS), 0, ctx->stream, d.g, d.in, d.st, d.ap, d.lead);
             break;
+        // (the 128-query shapes of rounds 2-3, behind their options: built WITH the record test as before — a launch that
+        // searches must clear the records of the queries it searches, whichever shape follows it)
         case SHAPE_DENSE8:
-            hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES>), grid, dim3(IT_THREADS), 0, ctx->stream,
+            hipLaunchKernelGGL((k_iterate_compact<8, IT_THREADS, IT_QUERIES, false, false, 0, true>), grid, dim3(IT_THREADS), 0, ctx->stream,
                                d.g, d.in, d.st, d.ap, d.lead);
             break;
         case SHAPE_DENSE6:
-            hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES>), grid, dim3(IT_THREADS), 0, ctx->stream,
+            hipLaunchKernelGGL((k_iterate_compact<6, IT_THREADS, IT_QUERIES, false, false, 0, true>), grid, dim3(IT_THREADS), 0, ctx->stream,
                                d.g, d.in, d.st, d.ap, d.lead);
             break;
     }
@@ -4369,6 +4381,7 @@ int prepare_iterate_batch(icp_ctx* const* ctxs, int count, bool lead_mode, const
             return ICP_ERR_INVALID_ARGUMENT;
         }
         out->shape = (int)fl.shape;
+        out->records = fl.d.in.rec != nullptr ? 1 : 0;  // (same options in every member: checked by the caller)
         out->rows[b] = fl.rows;
         out->quad[b] = fl.quad;
         table[b] = fl.d;
@@ -4386,8 +4399,14 @@ int launch_iterate_batch(icp_ctx* first, const BatchedIteration& it, const void*
         hipLaunchKernelGGL((k_iterate_late_batch<8, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table, it.count, it.per_seq);
     else if (it.shape == (int)SHAPE_LATE)
         hipLaunchKernelGGL((k_iterate_late_batch<6, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table, it.count, it.per_seq);
+    else if (it.shape == (int)SHAPE_WIDE && it.records)
+        hipLaunchKernelGGL((k_iterate_batch<4, 2 * IT_THREADS, IT_THREADS, true>), grid, dim3(2 * IT_THREADS), 0, first->stream, table,
+                           it.count, it.per_seq);
     else if (it.shape == (int)SHAPE_WIDE)
         hipLaunchKernelGGL((k_iterate_batch<4, 2 * IT_THREADS, IT_THREADS>), grid, dim3(2 * IT_THREADS), 0, first->stream, table,
+                           it.count, it.per_seq);
+    else if (it.records)
+        hipLaunchKernelGGL((k_iterate_batch<4, IT_THREADS, IT_THREADS, true>), grid, dim3(IT_THREADS), 0, first->stream, table,
                            it.count, it.per_seq);
     else
         hipLaunchKernelGGL((k_iterate_batch<4, IT_THREADS, IT_THREADS>), grid, dim3(IT_THREADS), 0, first->stream, table,
