@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the batched iteration launches, launch by launch: tools/batch_pmc.sh TAG B  -> gpurun_out/TAG/pmc.txt
+# the VALU instructions of the batched iteration launches BY CLASS (and thread cycles, LDS loads / stores, branches), launch by launch: tools/batch_pmc_classes.sh TAG B -> gpurun_out/TAG/pmc.txt
 set -u
 TAG=$1; B=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT

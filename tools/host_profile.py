@@ -1,6 +1,6 @@
 """dev: where the HOST spends a frame of the published-configuration loop (bench.py::odometry_loop_leg with timers around every call)"""
 import os, sys, time, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "pylidar-slam_amd")]
 import numpy as np, torch
 from pylidar_slam_amd.odometry import (ConstantVelocityInitialization, Distortion, DistortionConfig, GridSample, GridSampleConfig,
