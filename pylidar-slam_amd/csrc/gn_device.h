@@ -96,4 +96,15 @@ __device__ inline void neq_operands(int e, int& a, int& b) {
     }
 }
 
+// the same pair from two packed tables (four bits per element): the loop above costs the summing threads of the fused kernel
+// ~20 integer instructions each — a thirtieth of what a late launch issues (profiles/r06_valu_attribution.txt); e in 0 .. 31
+// (30, 31: unused elements, operands 0 x 0 of a thread that adds nothing)
+__device__ inline void neq_operands_lut(int e, int& a, int& b) {
+    const unsigned long long ta = e < 16 ? 0x3222211111000000ull : 0x0087654321054433ull;
+    const unsigned long long tb = e < 16 ? 0x3543254321543210ull : 0x0087666666655454ull;
+    const int sh = (e & 15) * 4;
+    a = (int)((ta >> sh) & 15ull);
+    b = (int)((tb >> sh) & 15ull);
+}
+
 }  // namespace icp

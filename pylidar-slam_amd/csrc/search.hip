@@ -1234,7 +1234,7 @@ __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*pa
             double acc = 0.0;
             if (e < NEQ_USED) {
                 int a, b2;
-                neq_operands(e, a, b2);
+                neq_operands_lut(e, a, b2);
                 const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
                 const float(*r)[9] = rowbuf + padded_row(j0);  // (32 consecutive rows: j0 is a multiple of 32)
 #pragma unroll 8
@@ -1253,7 +1253,7 @@ __device__ inline double block_reduce_rows(const float (*rowbuf)[9], double (*pa
         double acc = 0.0;
         if (e < NEQ_USED) {
             int a, b2;
-            neq_operands(e, a, b2);
+            neq_operands_lut(e, a, b2);
             const int j0 = sb * IT_QUERIES + qtr * (IT_QUERIES / 4);
             const float(*r)[9] = rowbuf + (PADDED ? padded_row(j0) : j0);
             // (fma: the product of two floats is exact in float64 — 48 mantissa bits — so the fused form rounds once where the
