@@ -946,6 +946,9 @@ def test_schedule_options_at_benchmark_size(torch_cuda):
                 "far_lanes_small_balls": {"far_max": 512, "ball_max": 32},
                 "no_flat_rows": {"flat_rows": 0}, "no_ball_search": {"ball_search": 0},
                 "round3": {"ball_search": 0, "narrow_from": 3},
+                # round 6: hit records — since the end of that round in builds of their own (REC_BUILD) — and the late kernel
+                "hit_records": {"hit_records": 1}, "late_kernel": {"hit_records": 1, "late_from": 3},
+                "hit_records_dense_then_narrow": {"hit_records": 1, "ball_search": 0, "narrow_from": 3},
                 # round 4's schedule (a launch per iteration) / the resident tail from iteration 7
                 "tail_from_3": {"resident_tail": 3}, "tail_from_7": {"resident_tail": 7},  # the resident tail (off by default)
                 "no_carry": {"carry_normals": 0},
